@@ -1,0 +1,125 @@
+/*
+ * mbpo_hip.h — C-ABI of libmbpo_hip.so, the MI355X (gfx950) implementation of the
+ * MBPO inner-loop hot path of lasgroup/Model-based-policy-optimizers.
+ *
+ * The reference has no FFI: its hot path is jax.numpy traced under jit/scan/vmap.  Each
+ * entry point below replaces one traced computation; the "replaces" line cites the
+ * reference file:line (relative to the reference repo root) whose arithmetic it computes.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes; every pointer is a DEVICE pointer unless named h_*;
+ *   - the caller owns all memory; no entry point allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return value: MBPO_OK (0) or a negative MBPO_ERR_*; mbpo_last_error() gives text;
+ *   - all floating point is IEEE fp32 (the reference's dtype: sac/sac.py:379,389);
+ *     indices and positions are int32/int64 and bit-exact.
+ *
+ * Parameter layout of an MLP ("flat params"): for layer l = 0..n_layers-1
+ *   W_l[dims[l]][dims[l+1]] row-major (flax Dense kernel layout [in,out]), then b_l[dims[l+1]].
+ * n_nets networks of identical shape sit net_stride floats apart (ensemble members, twin critics).
+ */
+#ifndef MBPO_HIP_H
+#define MBPO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBPO_OK 0
+#define MBPO_ERR_ARG (-1)         /* invalid argument / shape */
+#define MBPO_ERR_UNSUPPORTED (-2) /* valid but outside what the kernels are built for */
+#define MBPO_ERR_LAUNCH (-3)      /* HIP runtime error at launch */
+
+#define MBPO_MAX_LAYERS 8
+
+/* activation ids (reference default: flax.linen.swish — sac/sac.py:86-88, utils/network_utils.py:8) */
+#define MBPO_ACT_SWISH 0
+#define MBPO_ACT_RELU 1
+#define MBPO_ACT_TANH 2
+
+typedef struct mbpo_mlp_desc {
+  const float *params;               /* flat params of net 0 */
+  int64_t net_stride;                /* floats between consecutive nets */
+  int32_t n_nets;                    /* >= 1 (ensemble members / critics) */
+  int32_t n_layers;                  /* Dense layers incl. the output layer, 1..MBPO_MAX_LAYERS */
+  int32_t dims[MBPO_MAX_LAYERS + 1]; /* dims[0] = input size, dims[n_layers] = output size */
+  int32_t activation;                /* MBPO_ACT_*; applied after every layer except the last */
+} mbpo_mlp_desc;
+
+/* ---- library ---- */
+int mbpo_version(void);
+const char *mbpo_last_error(void);
+
+/* ---- R2: ensemble MLP forward -------------------------------------------------------------
+ * replaces: the (new) learned Dynamics.next_state evaluated under vmap —
+ *           mbpo/systems/dynamics/base_dynamics.py:15-20 called from
+ *           mbpo/systems/pendulum_system.py:31-32 / brax_utils/training.py:71-74;
+ *           MLP semantics: sac/networks.py:19-41, utils/network_utils.py:5-17.
+ * x: [n_rows, dims[0]] if shared_input else [n_nets, n_rows, dims[0]];  y: [n_nets, n_rows, dims[n_layers]].
+ */
+int mbpo_ensemble_mlp_forward(const mbpo_mlp_desc *mlp, const float *x, int32_t shared_input,
+                              float *y, int64_t n_rows, void *stream);
+
+/* ---- R1-R8: fused model rollout -----------------------------------------------------------
+ * replaces: SAC.get_experience's scan of acting.actor_step (sac/sac.py:283-296, sac/acting.py:35-55)
+ *           and brax generate_unroll as used by PPO.training_step (ppo/ppo.py:194-208), i.e. per env and step:
+ *           policy inference (sac_networks.py:58-73 / ppo_network.py:59-84, NormalTanh:
+ *           sac/parametric_distribution.py:66-124), AutoReset/Episode bookkeeping
+ *           (brax_utils/training.py:77-137), BraxWrapper.step -> System.step
+ *           (systems/brax_wrapper.py:40-50, pendulum_system.py:18-39), Transition assembly.
+ */
+#define MBPO_SYS_PENDULUM 0 /* analytic PendulumDynamics (dynamics/pendulum_dynamics.py:29-63) */
+#define MBPO_SYS_ENSEMBLE 1 /* learned ensemble MLP behind Dynamics.next_state */
+
+#define MBPO_ENS_MEAN 0  /* x' = E_members[mean_e]  (what System.step consumes: .mean()) */
+#define MBPO_ENS_TS1 1   /* member drawn per (env, step) — MBPO-style trajectory sampling */
+#define MBPO_ENS_TSINF 2 /* env i bound to member i % E */
+
+#define MBPO_REWARD_PENDULUM 0  /* rewards/pendulum_reward.py:27-42; params [angle_cost, control_cost, target_angle] */
+#define MBPO_REWARD_QUADRATIC 1 /* -(sum q_d (x_d - t_d)^2) - sum r_d u_d^2; params [t[x], q[x], r[u]] */
+
+typedef struct mbpo_rollout_desc {
+  mbpo_mlp_desc policy;   /* [x_dim] -> [2*u_dim] */
+  mbpo_mlp_desc dynamics; /* [x_dim+u_dim] -> [2*x_dim] (mean, raw std); ignored for MBPO_SYS_PENDULUM */
+  int32_t x_dim, u_dim;
+  int64_t n_envs;          /* N */
+  int32_t n_steps;         /* S = num_env_steps_between_updates (SAC) or unroll_length (PPO) */
+  int32_t episode_length;  /* model-env horizon H (EpisodeWrapper) */
+  int32_t action_repeat;   /* EpisodeWrapper.action_repeat */
+  int32_t system_kind;     /* MBPO_SYS_* */
+  int32_t ens_mode;        /* MBPO_ENS_* */
+  int32_t ens_predict_delta; /* 1: x' = x + f(x,u) */
+  int32_t ens_sample_noise;  /* 1 (TS modes): x' += sigma_e * eps */
+  float ens_min_std;         /* sigma = softplus(raw) + ens_min_std */
+  int32_t reward_kind;       /* MBPO_REWARD_* */
+  const float *reward_params;
+  const float *sys_params;   /* pendulum: [max_speed, max_torque, dt, g, m, l] */
+  const float *norm_mean;    /* [x_dim] or NULL (normalize_observations=False) */
+  const float *norm_std;     /* [x_dim] or NULL */
+  int32_t deterministic;     /* 1: action = tanh(loc) (mode) */
+  int32_t ppo_extras;        /* 1: rows carry log_prob and raw_action (ppo_network.py:72-80) */
+  int32_t env_major;         /* 0: row = s*N + i (SAC concat order, sac.py:296); 1: row = i*S + s (PPO [B*M,T]) */
+  /* randomness: explicit tensors when non-NULL, else counter-based Philox4x32-10 keyed by (seed, offset) */
+  const float *policy_noise;   /* [S, N, u_dim] standard normal */
+  const float *model_noise;    /* [S, action_repeat, N, x_dim] standard normal */
+  const int32_t *member_idx;   /* [S, action_repeat, N] in [0, E) for MBPO_ENS_TS1 */
+  uint64_t seed, offset;
+  /* env state, updated in place (brax State.obs / info['steps'] / done / info['first_obs']) */
+  float *obs;             /* [N, x_dim] */
+  const float *first_obs; /* [N, x_dim] */
+  float *steps;           /* [N] (float flags, as in the reference) */
+  float *done;            /* [N] */
+  /* output: flattened Transition rows (brax UniformSamplingQueue ravel order)
+   *   [obs(x), action(u), reward, discount, next_obs(x), {log_prob, raw_action(u)}, truncation] */
+  float *transitions;     /* [S*N, row_len] */
+  int32_t row_len;        /* 2x+u+3 (+1+u with ppo_extras) */
+} mbpo_rollout_desc;
+
+int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBPO_HIP_H */

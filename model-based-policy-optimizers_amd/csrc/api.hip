@@ -1,0 +1,45 @@
+// api.hip — library-level entry points and host-side argument validation shared by all kernels.
+#include "common.hpp"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void mbpo_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *mbpo_last_error(void) { return g_err; }
+
+extern "C" int mbpo_version(void) { return 100; /* 0.1.0 */ }
+
+int mbpo_make_mlp_dev(const mbpo_mlp_desc *d, MlpDev *out, const char *name) {
+  MBPO_REQUIRE(d != nullptr, MBPO_ERR_ARG, "%s: null mlp descriptor", name);
+  MBPO_REQUIRE(d->params != nullptr, MBPO_ERR_ARG, "%s: null params", name);
+  MBPO_REQUIRE(d->n_layers >= 1 && d->n_layers <= MBPO_MAX_LAYERS, MBPO_ERR_ARG, "%s: n_layers=%d out of [1,%d]", name,
+               d->n_layers, MBPO_MAX_LAYERS);
+  MBPO_REQUIRE(d->n_nets >= 1, MBPO_ERR_ARG, "%s: n_nets=%d < 1", name, d->n_nets);
+  MBPO_REQUIRE(d->activation >= 0 && d->activation <= 2, MBPO_ERR_ARG, "%s: unknown activation %d", name, d->activation);
+  int off = 0;
+  for (int l = 0; l <= d->n_layers; ++l) {
+    MBPO_REQUIRE(d->dims[l] >= 1 && d->dims[l] <= 4096, MBPO_ERR_ARG, "%s: dims[%d]=%d out of range", name, l, d->dims[l]);
+    out->dims[l] = d->dims[l];
+  }
+  for (int l = 0; l < d->n_layers; ++l) {
+    out->w_off[l] = off;
+    off += d->dims[l] * d->dims[l + 1];
+    out->b_off[l] = off;
+    off += d->dims[l + 1];
+  }
+  MBPO_REQUIRE(d->n_nets == 1 || d->net_stride >= off, MBPO_ERR_ARG, "%s: net_stride=%lld < params per net %d", name,
+               (long long)d->net_stride, off);
+  out->params = d->params;
+  out->net_stride = d->net_stride;
+  out->n_nets = d->n_nets;
+  out->n_layers = d->n_layers;
+  out->act = d->activation;
+  out->n_params = off;
+  return MBPO_OK;
+}

@@ -1,0 +1,130 @@
+// common.hpp — shared device/host helpers for libmbpo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mbpo_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+// ---------------------------------------------------------------- error plumbing (host)
+void mbpo_set_error(const char *fmt, ...);
+
+#define MBPO_REQUIRE(cond, code, ...)        \
+  do {                                       \
+    if (!(cond)) {                           \
+      mbpo_set_error(__VA_ARGS__);           \
+      return (code);                         \
+    }                                        \
+  } while (0)
+
+#define MBPO_CHECK_LAUNCH(what)                                              \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      mbpo_set_error("%s: %s", what, hipGetErrorString(e__));                \
+      return MBPO_ERR_LAUNCH;                                                \
+    }                                                                        \
+  } while (0)
+
+// ---------------------------------------------------------------- device-side MLP description
+struct MlpDev {
+  const float *params;
+  long long net_stride;
+  int n_nets;
+  int n_layers;
+  int dims[MBPO_MAX_LAYERS + 1];
+  int w_off[MBPO_MAX_LAYERS];
+  int b_off[MBPO_MAX_LAYERS];
+  int act;
+  int n_params;  // floats per net
+};
+
+// host: validate + fill offsets. Returns MBPO_OK or error.
+int mbpo_make_mlp_dev(const mbpo_mlp_desc *d, MlpDev *out, const char *name);
+
+// ---------------------------------------------------------------- math
+__device__ __forceinline__ float act_apply(float v, int act) {
+  // swish(x) = x * sigmoid(x)  (flax.linen.swish); relu; tanh
+  if (act == MBPO_ACT_SWISH) return v / (1.0f + expf(-v));
+  if (act == MBPO_ACT_RELU) return fmaxf(v, 0.0f);
+  return tanhf(v);
+}
+
+// d act(v) / dv
+__device__ __forceinline__ float act_grad(float v, int act) {
+  if (act == MBPO_ACT_SWISH) {
+    float sg = 1.0f / (1.0f + expf(-v));
+    return sg * (1.0f + v * (1.0f - sg));
+  }
+  if (act == MBPO_ACT_RELU) return v > 0.0f ? 1.0f : 0.0f;
+  float t = tanhf(v);
+  return 1.0f - t * t;
+}
+
+// jax.nn.softplus(x) = logaddexp(x, 0) = max(x,0) + log1p(exp(-|x|))
+__device__ __forceinline__ float softplus_f(float x) {
+  return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------- Philox4x32-10 (counter-based RNG)
+// Matches oracle/philox.py bit for bit (integer arithmetic only).
+struct Philox4 {
+  uint32_t v[4];
+};
+
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                          uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * c0;
+    uint64_t p1 = (uint64_t)M1 * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c1 ^ k0;
+    uint32_t n1 = lo1;
+    uint32_t n2 = hi0 ^ c3 ^ k1;
+    uint32_t n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  Philox4 o;
+  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+
+// RNG streams (counter word 2): which consumer draws
+#define MBPO_STREAM_POLICY_NOISE 1u
+#define MBPO_STREAM_MODEL_NOISE 2u
+#define MBPO_STREAM_MEMBER 3u
+#define MBPO_STREAM_REPLAY 4u
+#define MBPO_STREAM_SAC_ALPHA 5u
+#define MBPO_STREAM_SAC_CRITIC 6u
+#define MBPO_STREAM_SAC_ACTOR 7u
+#define MBPO_STREAM_PERM 8u
+#define MBPO_STREAM_ENTROPY 9u
+
+// standard normal for element `idx` of stream `stream` at call counter `offset` under `seed`
+// (Box-Muller on two of the four Philox words; one Philox call per element keeps draws order-independent).
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx) {
+  Philox4 p = philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), stream ^ (uint32_t)(offset >> 32) * 0x9E3779B9u,
+                            (uint32_t)offset, (uint32_t)seed, (uint32_t)(seed >> 32));
+  float u1 = ((float)(p.v[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
+  float u2 = (float)(p.v[1] >> 8) * (1.0f / 16777216.0f);           // [0,1)
+  float rad = sqrtf(-2.0f * logf(u1));
+  return rad * cosf(6.28318530717958647692f * u2);
+}
+
+// uniform integer in [lo, hi) for element idx: lo + mulhi(u32, span)   (span = hi-lo > 0)
+__device__ __forceinline__ int32_t philox_randint(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx,
+                                                  int32_t lo, int32_t hi) {
+  Philox4 p = philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), stream ^ (uint32_t)(offset >> 32) * 0x9E3779B9u,
+                            (uint32_t)offset, (uint32_t)seed, (uint32_t)(seed >> 32));
+  uint32_t span = (uint32_t)(hi - lo);
+  return lo + (int32_t)(((uint64_t)p.v[0] * span) >> 32);
+}

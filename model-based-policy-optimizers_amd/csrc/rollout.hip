@@ -1,0 +1,489 @@
+// rollout.hip — R2 ensemble MLP forward and R1-R8 fused model rollout (see include/mbpo_hip.h).
+//
+// Decomposition (MI355X): one 4..16-wave workgroup owns a tile of 16 envs for ALL steps of the rollout and
+// ALL ensemble members, because every step ends in a reduction over members (mean / member pick) that feeds
+// the next step's input.  Waves split each Dense layer by (member, 16-column n-tile) items; activations
+// live in LDS, weights stream from L2 (flat params are ~0.2 MB and shared by every workgroup), the
+// transition row is assembled in LDS and written to HBM as one contiguous block per step.
+// Per (env, step) HBM traffic is one row write (row_len*4 B) — the kernel is MFMA/latency bound by design.
+#include "common.hpp"
+#include "mlp_tile.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// R2: y[e][row][:] = MLP_e(x[row])  — replaces vmap(Dynamics.next_state) (base_dynamics.py:15-20).
+// ------------------------------------------------------------------------------------------------
+struct EnsFwdArgs {
+  MlpDev mlp;
+  const float *x;
+  float *y;
+  long long n_rows;
+  int shared_input;
+  int ld_x, ld_h, ld_y;
+};
+
+template <int H>
+__global__ void __launch_bounds__((H / 16) * 64) k_ensemble_forward(EnsFwdArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int NW = H / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const MlpDev &m = A.mlp;
+  const int E = m.n_nets, din = m.dims[0], dout = m.dims[m.n_layers];
+  const int n_in_nets = A.shared_input ? 1 : E;
+  float *s_x = smem;                                // [n_in_nets][16][ld_x]
+  float *s_hA = s_x + n_in_nets * 16 * A.ld_x;      // [E][16][ld_h]
+  float *s_hB = s_hA + E * 16 * A.ld_h;             // [E][16][ld_h]
+  float *s_y = s_hB + E * 16 * A.ld_h;              // [E][16][ld_y]
+  const long long n_tiles = (A.n_rows + 15) >> 4;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long row0 = tile * 16;
+    for (int idx = tid; idx < n_in_nets * 16 * din; idx += blockDim.x) {
+      int e = idx / (16 * din), rem = idx - e * 16 * din;
+      int r = rem / din, c = rem - r * din;
+      long long row = row0 + r;
+      float v = 0.f;
+      if (row < A.n_rows) v = A.x[((long long)e * A.n_rows + row) * din + c];
+      s_x[(e * 16 + r) * A.ld_x + c] = v;
+    }
+    __syncthreads();
+    mlp_forward_tile<H>(m, E, s_x, A.shared_input ? 0 : 16 * A.ld_x, A.ld_x, s_hA, s_hB, A.ld_h, s_y, A.ld_y, wave, NW,
+                        lane);
+    for (int idx = tid; idx < E * 16 * dout; idx += blockDim.x) {
+      int e = idx / (16 * dout), rem = idx - e * 16 * dout;
+      int r = rem / dout, c = rem - r * dout;
+      long long row = row0 + r;
+      if (row < A.n_rows) A.y[((long long)e * A.n_rows + row) * dout + c] = s_y[(e * 16 + r) * A.ld_y + c];
+    }
+    __syncthreads();
+  }
+}
+
+static int hidden_width(const MlpDev &m) {
+  // all hidden layers must share one width H in {64,128,256}; a 1-layer MLP (no hidden) uses the 64 build.
+  if (m.n_layers == 1) return 64;
+  int H = m.dims[1];
+  for (int l = 2; l < m.n_layers; ++l)
+    if (m.dims[l] != H) return -1;
+  return H;
+}
+
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <typename KernelT>
+static int set_lds(KernelT kern, size_t bytes, const char *what) {
+  if (bytes > 160 * 1024) {
+    mbpo_set_error("%s: needs %zu B of LDS per workgroup (> 160 KiB); reduce ensemble size or hidden width", what, bytes);
+    return MBPO_ERR_UNSUPPORTED;
+  }
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+      mbpo_set_error("%s: hipFuncSetAttribute(%zu): %s", what, bytes, hipGetErrorString(e));
+      return MBPO_ERR_LAUNCH;
+    }
+  }
+  return MBPO_OK;
+}
+
+extern "C" int mbpo_ensemble_mlp_forward(const mbpo_mlp_desc *mlp, const float *x, int32_t shared_input, float *y,
+                                         int64_t n_rows, void *stream) {
+  MBPO_REQUIRE(mlp && x && y, MBPO_ERR_ARG, "ensemble_mlp_forward: null pointer");
+  MBPO_REQUIRE(n_rows >= 0, MBPO_ERR_ARG, "ensemble_mlp_forward: n_rows < 0");
+  EnsFwdArgs A;
+  int rc = mbpo_make_mlp_dev(mlp, &A.mlp, "ensemble_mlp_forward");
+  if (rc != MBPO_OK) return rc;
+  if (n_rows == 0) return MBPO_OK;
+  const int H = hidden_width(A.mlp);
+  MBPO_REQUIRE(H == 64 || H == 128 || H == 256, MBPO_ERR_UNSUPPORTED,
+               "ensemble_mlp_forward: hidden layers must share one width in {64,128,256}");
+  A.x = x;
+  A.y = y;
+  A.n_rows = n_rows;
+  A.shared_input = shared_input ? 1 : 0;
+  A.ld_x = A.mlp.dims[0] | 1;
+  A.ld_h = H + 1;
+  A.ld_y = A.mlp.dims[A.mlp.n_layers] | 1;
+  const int E = A.mlp.n_nets;
+  size_t lds = sizeof(float) * ((size_t)(shared_input ? 1 : E) * 16 * A.ld_x + 2ull * E * 16 * A.ld_h + (size_t)E * 16 * A.ld_y);
+  long long n_tiles = (n_rows + 15) >> 4;
+  int grid = (int)(n_tiles < 8LL * num_cus() ? n_tiles : 8LL * num_cus());
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_ENS(HH)                                                          \
+  {                                                                             \
+    rc = set_lds(k_ensemble_forward<HH>, lds, "ensemble_mlp_forward");          \
+    if (rc != MBPO_OK) return rc;                                               \
+    hipLaunchKernelGGL(k_ensemble_forward<HH>, dim3(grid), dim3((HH / 16) * 64), lds, st, A); \
+  }
+  if (H == 64) LAUNCH_ENS(64) else if (H == 128) LAUNCH_ENS(128) else LAUNCH_ENS(256)
+#undef LAUNCH_ENS
+  MBPO_CHECK_LAUNCH("ensemble_mlp_forward");
+  return MBPO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// R1-R8 fused rollout.
+// ------------------------------------------------------------------------------------------------
+struct RolloutArgs {
+  MlpDev policy, dyn;
+  int x_dim, u_dim;
+  long long n_envs;
+  int n_steps, episode_length, action_repeat;
+  int system_kind, ens_mode, ens_predict_delta, ens_sample_noise;
+  float ens_min_std;
+  int reward_kind;
+  const float *reward_params, *sys_params, *norm_mean, *norm_std;
+  int deterministic, ppo_extras, env_major;
+  const float *policy_noise, *model_noise;
+  const int *member_idx;
+  unsigned long long seed, offset;
+  float *obs;
+  const float *first_obs;
+  float *steps, *done;
+  float *transitions;
+  int row_len;
+  // LDS geometry
+  int ld_x, ld_xu, ld_h, ld_y, n_slots;
+};
+
+// PendulumDynamics.next_state (dynamics/pendulum_dynamics.py:29-63), fp32, same operation order.
+__device__ __forceinline__ void pendulum_step(const float *x, float u, const float *sp, float *xn) {
+  const float max_speed = sp[0], max_torque = sp[1], dt = sp[2], g = sp[3], mm = sp[4], l = sp[5];
+  const float th = atan2f(x[1], x[0]);
+  const float thdot = x[2];
+  const float uc = fminf(fmaxf(u, -1.0f), 1.0f) * max_torque;
+  const float thdd = (3.0f * g) / (2.0f * l) * sinf(th) + 3.0f / (mm * (l * l)) * uc;
+  float nthdot = thdot + thdd * dt;
+  nthdot = fminf(fmaxf(nthdot, -max_speed), max_speed);
+  const float nth = th + nthdot * dt;  // dx[0] = clipped newthdot (ode :61-63)
+  float nthdot2 = thdot + thdd * dt;   // dx[-1] = newthddot (:41)
+  nthdot2 = fminf(fmaxf(nthdot2, -max_speed), max_speed);
+  xn[0] = cosf(nth);
+  xn[1] = sinf(nth);
+  xn[2] = nthdot2;
+}
+
+// PendulumReward.__call__ (rewards/pendulum_reward.py:32-41): uses pre-step x and the unclipped action.
+__device__ __forceinline__ float pendulum_reward(const float *x, float u, const float *rp) {
+  const float angle_cost = rp[0], control_cost = rp[1], target = rp[2];
+  const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
+  const float theta = atan2f(x[1], x[0]), omega = x[2];
+  float d = theta - target;
+  float t = d + PI_F;
+  float mpy = fmodf(t, TWO_PI_F);  // python/jnp % : result takes the sign of the divisor
+  if (mpy < 0.0f) mpy += TWO_PI_F;
+  d = mpy - PI_F;
+  return -(angle_cost * (d * d) + 0.1f * (omega * omega)) - control_cost * (u * u);
+}
+
+template <int H>
+__global__ void __launch_bounds__((H / 16) * 64) k_model_rollout(RolloutArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int NW = H / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int X = A.x_dim, U = A.u_dim, D = A.row_len;
+  const int E = (A.system_kind == MBPO_SYS_ENSEMBLE) ? A.dyn.n_nets : 0;
+  const long long N = A.n_envs;
+  const int AR = A.action_repeat;
+
+  // ---- LDS carve (floats) ----
+  float *s_obs = smem;                           // [16][ld_x]  current raw obs
+  float *s_first = s_obs + 16 * A.ld_x;          // [16][ld_x]
+  float *s_pin = s_first + 16 * A.ld_x;          // [16][ld_x]  normalised obs (policy input)
+  float *s_xu = s_pin + 16 * A.ld_x;             // [16][ld_xu] dynamics input [x,u]
+  float *s_hA = s_xu + 16 * A.ld_xu;             // [n_slots][16][ld_h]
+  float *s_hB = s_hA + A.n_slots * 16 * A.ld_h;  // [n_slots][16][ld_h]
+  float *s_y = s_hB + A.n_slots * 16 * A.ld_h;   // [n_slots][16][ld_y]
+  float *s_row = s_y + A.n_slots * 16 * A.ld_y;  // [16][D]
+  float *s_steps = s_row + 16 * D;               // [16]
+  float *s_done = s_steps + 16;                  // [16]
+  float *s_rew = s_done + 16;                    // [16]
+
+  const long long n_tiles = (N + 15) >> 4;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long env0 = tile * 16;
+    // ---- load env state ----
+    for (int idx = tid; idx < 16 * X; idx += nthreads) {
+      int r = idx / X, c = idx - r * X;
+      long long env = env0 + r;
+      float o = 0.f, f = 0.f;
+      if (env < N) {
+        o = A.obs[env * X + c];
+        f = A.first_obs[env * X + c];
+      }
+      s_obs[r * A.ld_x + c] = o;
+      s_first[r * A.ld_x + c] = f;
+    }
+    if (tid < 16) {
+      long long env = env0 + tid;
+      s_steps[tid] = env < N ? A.steps[env] : 0.f;
+      s_done[tid] = env < N ? A.done[env] : 0.f;
+    }
+    __syncthreads();
+
+    for (int s = 0; s < A.n_steps; ++s) {
+      // ---- policy input: running_statistics.normalize = (obs - mean) / std ----
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        int r = idx / X, c = idx - r * X;
+        float o = s_obs[r * A.ld_x + c];
+        s_pin[r * A.ld_x + c] = A.norm_mean ? (o - A.norm_mean[c]) / A.norm_std[c] : o;
+      }
+      __syncthreads();
+      // ---- policy MLP -> logits in s_y[0] ----
+      mlp_forward_tile<H>(A.policy, 1, s_pin, 0, A.ld_x, s_hA, s_hB, A.ld_h, s_y, A.ld_y, wave, NW, lane);
+      // ---- NormalTanh sample (parametric_distribution.py:97-124) + AutoReset pre-step (training.py:119-124) ----
+      for (int idx = tid; idx < 16 * U; idx += nthreads) {
+        int r = idx / U, d = idx - r * U;
+        long long env = env0 + r;
+        float loc = s_y[r * A.ld_y + d], raw = s_y[r * A.ld_y + U + d];
+        float sigma = softplus_f(raw) + 0.001f;
+        float eps = 0.f;
+        if (!A.deterministic && env < N) {
+          long long nidx = ((long long)s * N + env) * U + d;
+          eps = A.policy_noise ? A.policy_noise[nidx]
+                               : philox_normal(A.seed, A.offset, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
+        }
+        float z = loc + sigma * eps;
+        float a = tanhf(z);
+        s_xu[r * A.ld_xu + X + d] = a;
+        s_row[r * D + X + d] = a;
+        if (A.ppo_extras) {
+          // log N(z; loc, sigma) - log|d tanh/dz|, per action dim; summed below
+          float lp = -0.5f * eps * eps - logf(sigma) - 0.91893853320467274178f;
+          float ldj = 2.0f * (0.69314718055994530942f - z - softplus_f(-2.0f * z));
+          s_row[r * D + 2 * X + U + 2 + 1 + d] = z;               // raw_action
+          s_hA[r * U + d] = lp - ldj;                             // scratch: per-dim log-prob
+        }
+      }
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        int r = idx / X, c = idx - r * X;
+        float o = s_obs[r * A.ld_x + c];
+        s_xu[r * A.ld_xu + c] = o;
+        s_row[r * D + c] = o;  // Transition.observation = env_state.obs (acting.py:47)
+      }
+      if (tid < 16) {
+        // AutoReset: steps <- 0 where previously done; done <- 0
+        if (s_done[tid] != 0.f) s_steps[tid] = 0.f;
+        s_done[tid] = 0.f;
+        s_rew[tid] = 0.f;
+      }
+      __syncthreads();
+      if (A.ppo_extras && tid < 16) {
+        float lp = 0.f;
+        for (int d = 0; d < U; ++d) lp += s_hA[tid * U + d];
+        s_row[tid * D + 2 * X + U + 2] = lp;  // log_prob (summed over action dims)
+      }
+      if (A.ppo_extras) __syncthreads();
+
+      // ---- EpisodeWrapper inner scan over action_repeat (training.py:91-97) ----
+      for (int ar = 0; ar < AR; ++ar) {
+        if (A.system_kind == MBPO_SYS_ENSEMBLE) {
+          mlp_forward_tile<H>(A.dyn, E, s_xu, 0, A.ld_xu, s_hA, s_hB, A.ld_h, s_y, A.ld_y, wave, NW, lane);
+        }
+        // reward uses the pre-step x and the action; next state from the system
+        if (tid < 16) {
+          const int r = tid;
+          const float *xr = s_xu + r * A.ld_xu;
+          float rew;
+          if (A.reward_kind == MBPO_REWARD_PENDULUM) {
+            rew = pendulum_reward(xr, xr[X], A.reward_params);
+          } else {
+            const float *tp = A.reward_params, *qp = tp + X, *rp = qp + X;
+            float cx = 0.f, cu = 0.f;
+            for (int c = 0; c < X; ++c) { float dd = xr[c] - tp[c]; cx += qp[c] * (dd * dd); }
+            for (int d = 0; d < U; ++d) { float uu = xr[X + d]; cu += rp[d] * (uu * uu); }
+            rew = -cx - cu;
+          }
+          s_rew[r] += rew;
+        }
+        __syncthreads();
+        if (A.system_kind == MBPO_SYS_PENDULUM) {
+          if (tid < 16) {
+            float xn[3];
+            pendulum_step(s_xu + tid * A.ld_xu, s_xu[tid * A.ld_xu + X], A.sys_params, xn);
+            s_xu[tid * A.ld_xu + 0] = xn[0];
+            s_xu[tid * A.ld_xu + 1] = xn[1];
+            s_xu[tid * A.ld_xu + 2] = xn[2];
+          }
+        } else {
+          for (int idx = tid; idx < 16 * X; idx += nthreads) {
+            int r = idx / X, c = idx - r * X;
+            long long env = env0 + r;
+            float base = A.ens_predict_delta ? s_xu[r * A.ld_xu + c] : 0.f;
+            float v;
+            if (A.ens_mode == MBPO_ENS_MEAN) {
+              float acc = 0.f;
+              for (int e = 0; e < E; ++e) acc += s_y[(e * 16 + r) * A.ld_y + c];
+              v = base + acc / (float)E;
+            } else {
+              int mem = 0;
+              long long eidx = ((long long)s * AR + ar) * N + env;
+              if (env < N) {
+                if (A.ens_mode == MBPO_ENS_TSINF) mem = (int)(env % E);
+                else mem = A.member_idx ? A.member_idx[eidx]
+                                        : philox_randint(A.seed, A.offset, MBPO_STREAM_MEMBER, (unsigned long long)eidx, 0, E);
+              }
+              float mu = s_y[(mem * 16 + r) * A.ld_y + c];
+              v = base + mu;
+              if (A.ens_sample_noise && env < N) {
+                float sg = softplus_f(s_y[(mem * 16 + r) * A.ld_y + X + c]) + A.ens_min_std;
+                long long nidx = eidx * X + c;
+                float eps = A.model_noise ? A.model_noise[nidx]
+                                          : philox_normal(A.seed, A.offset, MBPO_STREAM_MODEL_NOISE, (unsigned long long)nidx);
+                v += sg * eps;
+              }
+            }
+            s_hA[r * X + c] = v;  // scratch (s_y must stay intact until every thread has read it)
+          }
+          __syncthreads();
+          for (int idx = tid; idx < 16 * X; idx += nthreads) {
+            int r = idx / X, c = idx - r * X;
+            s_xu[r * A.ld_xu + c] = s_hA[r * X + c];
+          }
+        }
+        __syncthreads();
+      }
+
+      // ---- EpisodeWrapper / AutoReset post-step (training.py:98-107, 126-137) + Transition (acting.py:46-55) ----
+      if (tid < 16) {
+        const int r = tid;
+        float st = s_steps[r] + (float)AR;
+        float sys_done = 0.f;  // SystemState.done default (base_systems.py:25)
+        float dn = (st >= (float)A.episode_length) ? 1.f : sys_done;
+        float trunc = (st >= (float)A.episode_length) ? (1.f - sys_done) : 0.f;
+        s_steps[r] = st;
+        s_done[r] = dn;
+        s_row[r * D + X + U] = s_rew[r];
+        s_row[r * D + X + U + 1] = 1.f - dn;
+        s_row[r * D + D - 1] = trunc;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        int r = idx / X, c = idx - r * X;
+        float v = (s_done[r] != 0.f) ? s_first[r * A.ld_x + c] : s_xu[r * A.ld_xu + c];
+        s_obs[r * A.ld_x + c] = v;
+        s_row[r * D + X + U + 2 + c] = v;  // next_observation = nstate.obs (post auto-reset)
+      }
+      __syncthreads();
+      // ---- write the tile's 16 rows ----
+      for (int idx = tid; idx < 16 * D; idx += nthreads) {
+        int r = idx / D, c = idx - r * D;
+        long long env = env0 + r;
+        if (env < N) {
+          long long row = A.env_major ? (env * A.n_steps + s) : ((long long)s * N + env);
+          A.transitions[row * D + c] = s_row[idx];
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- write back env state ----
+    for (int idx = tid; idx < 16 * X; idx += nthreads) {
+      int r = idx / X, c = idx - r * X;
+      long long env = env0 + r;
+      if (env < N) A.obs[env * X + c] = s_obs[r * A.ld_x + c];
+    }
+    if (tid < 16) {
+      long long env = env0 + tid;
+      if (env < N) {
+        A.steps[env] = s_steps[tid];
+        A.done[env] = s_done[tid];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
+  MBPO_REQUIRE(d, MBPO_ERR_ARG, "model_rollout: null descriptor");
+  MBPO_REQUIRE(d->x_dim > 0 && d->u_dim > 0, MBPO_ERR_ARG, "model_rollout: x_dim/u_dim must be positive");
+  MBPO_REQUIRE(d->n_envs >= 0 && d->n_steps >= 0, MBPO_ERR_ARG, "model_rollout: negative n_envs/n_steps");
+  MBPO_REQUIRE(d->episode_length > 0 && d->action_repeat > 0, MBPO_ERR_ARG,
+               "model_rollout: episode_length and action_repeat must be positive");
+  const bool empty = (d->n_envs == 0 || d->n_steps == 0);  // empty tensors carry NULL data pointers
+  MBPO_REQUIRE(empty || (d->obs && d->first_obs && d->steps && d->done && d->transitions), MBPO_ERR_ARG,
+               "model_rollout: null state/output pointer");
+  MBPO_REQUIRE((d->norm_mean == nullptr) == (d->norm_std == nullptr), MBPO_ERR_ARG,
+               "model_rollout: norm_mean and norm_std must both be set or both NULL");
+  MBPO_REQUIRE(d->reward_params, MBPO_ERR_ARG, "model_rollout: reward_params is NULL");
+  const int X = d->x_dim, U = d->u_dim;
+  const int want_row = 2 * X + U + 3 + (d->ppo_extras ? 1 + U : 0);
+  MBPO_REQUIRE(d->row_len == want_row, MBPO_ERR_ARG, "model_rollout: row_len %d != expected %d", d->row_len, want_row);
+  MBPO_REQUIRE(d->reward_kind == MBPO_REWARD_PENDULUM || d->reward_kind == MBPO_REWARD_QUADRATIC, MBPO_ERR_ARG,
+               "model_rollout: unknown reward_kind %d", d->reward_kind);
+  MBPO_REQUIRE(d->reward_kind != MBPO_REWARD_PENDULUM || (X == 3 && U == 1), MBPO_ERR_ARG,
+               "model_rollout: pendulum reward needs x_dim=3,u_dim=1");
+  RolloutArgs A;
+  int rc = mbpo_make_mlp_dev(&d->policy, &A.policy, "model_rollout.policy");
+  if (rc != MBPO_OK) return rc;
+  MBPO_REQUIRE(A.policy.n_nets == 1, MBPO_ERR_ARG, "model_rollout: policy.n_nets must be 1");
+  MBPO_REQUIRE(A.policy.dims[0] == X && A.policy.dims[A.policy.n_layers] == 2 * U, MBPO_ERR_ARG,
+               "model_rollout: policy must map [x_dim] -> [2*u_dim]");
+  int H = hidden_width(A.policy);
+  int E = 0;
+  int dyn_out = 0;
+  if (d->system_kind == MBPO_SYS_ENSEMBLE) {
+    rc = mbpo_make_mlp_dev(&d->dynamics, &A.dyn, "model_rollout.dynamics");
+    if (rc != MBPO_OK) return rc;
+    E = A.dyn.n_nets;
+    dyn_out = A.dyn.dims[A.dyn.n_layers];
+    MBPO_REQUIRE(A.dyn.dims[0] == X + U, MBPO_ERR_ARG, "model_rollout: dynamics input must be x_dim+u_dim");
+    MBPO_REQUIRE(dyn_out == 2 * X || (dyn_out == X && !(d->ens_sample_noise && d->ens_mode != MBPO_ENS_MEAN)),
+                 MBPO_ERR_ARG, "model_rollout: dynamics output must be 2*x_dim (mean, raw std) or x_dim (mean only, no sampling)");
+    MBPO_REQUIRE(d->ens_mode >= 0 && d->ens_mode <= 2, MBPO_ERR_ARG, "model_rollout: unknown ens_mode");
+    int Hd = hidden_width(A.dyn);
+    if (A.policy.n_layers == 1) H = Hd;
+    MBPO_REQUIRE(Hd == H || A.dyn.n_layers == 1, MBPO_ERR_UNSUPPORTED,
+                 "model_rollout: policy and dynamics hidden widths must match (got %d vs %d)", H, Hd);
+  } else if (d->system_kind == MBPO_SYS_PENDULUM) {
+    MBPO_REQUIRE(X == 3 && U == 1, MBPO_ERR_ARG, "model_rollout: pendulum system needs x_dim=3,u_dim=1");
+    MBPO_REQUIRE(d->sys_params, MBPO_ERR_ARG, "model_rollout: sys_params is NULL");
+    A.dyn = A.policy;  // unused
+  } else {
+    MBPO_REQUIRE(false, MBPO_ERR_ARG, "model_rollout: unknown system_kind %d", d->system_kind);
+  }
+  MBPO_REQUIRE(H == 64 || H == 128 || H == 256, MBPO_ERR_UNSUPPORTED,
+               "model_rollout: hidden layers must share one width in {64,128,256}");
+  if (d->n_envs == 0 || d->n_steps == 0) return MBPO_OK;
+
+  A.x_dim = X; A.u_dim = U; A.n_envs = d->n_envs; A.n_steps = d->n_steps;
+  A.episode_length = d->episode_length; A.action_repeat = d->action_repeat;
+  A.system_kind = d->system_kind; A.ens_mode = d->ens_mode; A.ens_predict_delta = d->ens_predict_delta;
+  A.ens_sample_noise = d->ens_sample_noise; A.ens_min_std = d->ens_min_std;
+  A.reward_kind = d->reward_kind; A.reward_params = d->reward_params; A.sys_params = d->sys_params;
+  A.norm_mean = d->norm_mean; A.norm_std = d->norm_std;
+  A.deterministic = d->deterministic; A.ppo_extras = d->ppo_extras; A.env_major = d->env_major;
+  A.policy_noise = d->policy_noise; A.model_noise = d->model_noise; A.member_idx = d->member_idx;
+  A.seed = d->seed; A.offset = d->offset;
+  A.obs = d->obs; A.first_obs = d->first_obs; A.steps = d->steps; A.done = d->done;
+  A.transitions = d->transitions; A.row_len = d->row_len;
+  A.n_slots = E > 1 ? E : 1;
+  A.ld_x = X | 1;
+  A.ld_xu = (X + U) | 1;
+  A.ld_h = H + 1;
+  int ymax = 2 * U > dyn_out ? 2 * U : dyn_out;
+  A.ld_y = ymax | 1;
+  size_t lds_f = 3ull * 16 * A.ld_x + 16ull * A.ld_xu + 2ull * A.n_slots * 16 * A.ld_h + (size_t)A.n_slots * 16 * A.ld_y +
+                 16ull * d->row_len + 48;
+  size_t lds = lds_f * sizeof(float);
+  long long n_tiles = (d->n_envs + 15) >> 4;
+  int grid = (int)(n_tiles < 4LL * num_cus() ? n_tiles : 4LL * num_cus());
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_RO(HH)                                                        \
+  {                                                                          \
+    rc = set_lds(k_model_rollout<HH>, lds, "model_rollout");                 \
+    if (rc != MBPO_OK) return rc;                                            \
+    hipLaunchKernelGGL(k_model_rollout<HH>, dim3(grid), dim3((HH / 16) * 64), lds, st, A); \
+  }
+  if (H == 64) LAUNCH_RO(64) else if (H == 128) LAUNCH_RO(128) else LAUNCH_RO(256)
+#undef LAUNCH_RO
+  MBPO_CHECK_LAUNCH("model_rollout");
+  return MBPO_OK;
+}

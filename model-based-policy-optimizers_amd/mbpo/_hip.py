@@ -1,0 +1,171 @@
+"""ctypes binding of libmbpo_hip.so (include/mbpo_hip.h).
+
+The product path has NO CPU fallback: importing this module without the built library, or calling an op
+with a non-CUDA(HIP) tensor, raises.  torch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional, Sequence
+
+import torch
+
+MBPO_MAX_LAYERS = 8
+ACT_IDS = {"swish": 0, "silu": 0, "relu": 1, "tanh": 2}
+
+SYS_PENDULUM, SYS_ENSEMBLE = 0, 1
+ENS_MEAN, ENS_TS1, ENS_TSINF = 0, 1, 2
+REWARD_PENDULUM, REWARD_QUADRATIC = 0, 1
+
+_LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libmbpo_hip.so"
+
+
+class MbpoHipError(RuntimeError):
+    pass
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [
+        ("params", C.c_void_p),
+        ("net_stride", C.c_int64),
+        ("n_nets", C.c_int32),
+        ("n_layers", C.c_int32),
+        ("dims", C.c_int32 * (MBPO_MAX_LAYERS + 1)),
+        ("activation", C.c_int32),
+    ]
+
+
+class RolloutDesc(C.Structure):
+    _fields_ = [
+        ("policy", MlpDesc),
+        ("dynamics", MlpDesc),
+        ("x_dim", C.c_int32),
+        ("u_dim", C.c_int32),
+        ("n_envs", C.c_int64),
+        ("n_steps", C.c_int32),
+        ("episode_length", C.c_int32),
+        ("action_repeat", C.c_int32),
+        ("system_kind", C.c_int32),
+        ("ens_mode", C.c_int32),
+        ("ens_predict_delta", C.c_int32),
+        ("ens_sample_noise", C.c_int32),
+        ("ens_min_std", C.c_float),
+        ("reward_kind", C.c_int32),
+        ("reward_params", C.c_void_p),
+        ("sys_params", C.c_void_p),
+        ("norm_mean", C.c_void_p),
+        ("norm_std", C.c_void_p),
+        ("deterministic", C.c_int32),
+        ("ppo_extras", C.c_int32),
+        ("env_major", C.c_int32),
+        ("policy_noise", C.c_void_p),
+        ("model_noise", C.c_void_p),
+        ("member_idx", C.c_void_p),
+        ("seed", C.c_uint64),
+        ("offset", C.c_uint64),
+        ("obs", C.c_void_p),
+        ("first_obs", C.c_void_p),
+        ("steps", C.c_void_p),
+        ("done", C.c_void_p),
+        ("transitions", C.c_void_p),
+        ("row_len", C.c_int32),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("MBPO_HIP_LIB", str(_LIB_PATH)))
+
+
+def load() -> C.CDLL:
+    """Load the library once.  Raises MbpoHipError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not p.exists():
+        raise MbpoHipError(
+            f"{p} not found: build it with `python model-based-policy-optimizers_amd/build.py` "
+            "(needs hipcc; this framework has no CPU fallback)")
+    lib = C.CDLL(str(p))
+    lib.mbpo_version.restype = C.c_int
+    lib.mbpo_last_error.restype = C.c_char_p
+    lib.mbpo_ensemble_mlp_forward.restype = C.c_int
+    lib.mbpo_ensemble_mlp_forward.argtypes = [C.POINTER(MlpDesc), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                              C.c_void_p]
+    lib.mbpo_model_rollout.restype = C.c_int
+    lib.mbpo_model_rollout.argtypes = [C.POINTER(RolloutDesc), C.c_void_p]
+    _bind_optional(lib)
+    _lib = lib
+    return lib
+
+
+def _bind_optional(lib: C.CDLL) -> None:
+    """Signatures of the remaining entry points (bound when present so partial builds still load)."""
+    i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
+    sigs = {
+        "mbpo_replay_insert": [vp, i64, i32, vp, vp, vp, i64, vp],
+        "mbpo_replay_gather": [vp, i64, i32, vp, vp, i64, vp, vp],
+        "mbpo_replay_sample": [vp, i64, i32, vp, u64, u64, i64, vp, vp, vp],
+        "mbpo_running_stats_update": [vp, i64, i32, i32, vp, vp, vp, vp, vp],
+        "mbpo_gae_scan": [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp],
+        "mbpo_lambda_return_scan": [vp, vp, vp, i64, i32, f32, f32, i32, vp],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = C.c_int
+            fn.argtypes = argtypes
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().mbpo_last_error().decode("utf-8", "replace")
+        raise MbpoHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def require_device_tensor(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise MbpoHipError(f"{name}: tensor is on {t.device}; the HIP path needs a GPU tensor (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def mlp_desc(params: torch.Tensor, dims: Sequence[int], activation: str = "swish", n_nets: int = 1,
+             net_stride: Optional[int] = None) -> MlpDesc:
+    """Describe `n_nets` MLPs stored in `params` (flat; see mbpo_hip.h for the layout)."""
+    dims = [int(d) for d in dims]
+    n_layers = len(dims) - 1
+    if not (1 <= n_layers <= MBPO_MAX_LAYERS):
+        raise ValueError(f"n_layers={n_layers} outside [1,{MBPO_MAX_LAYERS}]")
+    per_net = sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(n_layers))
+    if net_stride is None:
+        net_stride = per_net
+    if params.numel() < (n_nets - 1) * net_stride + per_net:
+        raise ValueError(f"params has {params.numel()} floats; need {(n_nets - 1) * net_stride + per_net}")
+    d = MlpDesc()
+    d.params = params.data_ptr()
+    d.net_stride = net_stride
+    d.n_nets = n_nets
+    d.n_layers = n_layers
+    for i, v in enumerate(dims):
+        d.dims[i] = v
+    d.activation = ACT_IDS[activation]
+    return d
