@@ -119,6 +119,50 @@ typedef struct mbpo_rollout_desc {
 
 int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream);
 
+/* ---- R9: replay buffer (brax UniformSamplingQueue semantics, INT32-exact) --------------------
+ * replaces: replay_buffer.insert / .sample as called at sac/sac.py:303,318 and systems/brax_wrapper.py:29,
+ *           bptt_optimizer.py:459,479 ([3P] brax.training.replay_buffers.UniformSamplingQueue; field use
+ *           evidenced by bptt_optimizer.py:447-456).
+ * The logical array data[max_size][row_len] of the reference is stored as a ring: logical row i lives at
+ * physical row (i + head) % max_size, so the reference's jnp.roll on overflow is an O(1) head move.
+ * state (device, int32[4]) = {insert_position, sample_position, head, total_inserted_low32}.
+ */
+int mbpo_replay_insert(float *data, int64_t max_size, int32_t row_len, int32_t *state, const float *rows,
+                       int64_t n_rows, void *stream);
+/* out[j] = data_logical[wrap(idx[j])]   (jnp.take(..., mode='wrap')); idx are LOGICAL indices */
+int mbpo_replay_gather(const float *data, int64_t max_size, int32_t row_len, const int32_t *state, const int32_t *idx,
+                       int64_t n, float *out, void *stream);
+/* idx[j] = randint(sample_position, insert_position) from Philox(seed, offset, stream=REPLAY, j), then gather.
+ * idx_out may be NULL.  Fused sample+gather: sac/sac.py:318 (UniformSamplingQueue.sample). */
+int mbpo_replay_sample(const float *data, int64_t max_size, int32_t row_len, const int32_t *state, uint64_t seed,
+                       uint64_t offset, int64_t n, int32_t *idx_out, float *out, void *stream);
+
+/* ---- R8: running_statistics.update ([3P] brax.training.acme.running_statistics; call sites
+ * sac/sac.py:298-301, ppo/ppo.py:216-219), in the reference's own two-pass form, split so that a multi-GPU
+ * host can all-reduce `sums` after each pass (the live form of `pmap_axis_name`'s two psums):
+ *   pass 0: sums[0] = n, sums[1..x] = sum(d),  d = obs - mean_old  over rows[:, col_off : col_off+x_dim]
+ *   pass 1: sums[1+x..1+2x) = sum(d * (d - upd)),  upd = sums[1..x] / (count + sums[0])
+ *   apply : count += n; mean += sum_d/count; summed_variance += pass-1 sums;
+ *           std = clip(sqrt(max(summed_variance,0)/count), 1e-6, 1e6)
+ * stats (device, fp32) = [count, mean[x], summed_variance[x], std[x]];  workspace >= 64*x_dim floats.
+ */
+int mbpo_running_stats_reduce(const float *rows, int64_t n_rows, int32_t row_len, int32_t col_off, int32_t x_dim,
+                              const float *stats, float *sums, float *workspace, int32_t pass, void *stream);
+int mbpo_running_stats_apply(float *stats, const float *sums, int32_t x_dim, void *stream);
+
+/* ---- P4: GAE (ppo/losses.py:128-184) and B2: lambda-return (utils/optimizer_utils.py:119-152) -------
+ * Reverse first-order linear recurrences evaluated as wavefront-shuffle segmented scans.
+ * Layout: time_major=1 -> arrays are [T,B] (the reference's layout after its swapaxes, losses.py:79);
+ *         time_major=0 -> [B,T] (PPO's native data layout, ppo.py:210-213; no transpose needed).
+ * gae:  vs, adv (both stop_gradient in the reference) from truncation, termination, rewards, values, bootstrap[B].
+ * lambda_return: returns[t] = r_t + gamma*(1-lam)*v'_t + gamma*lam*returns[t+1], returns[T] = v'_{T-1}.
+ */
+int mbpo_gae_scan(const float *truncation, const float *termination, const float *rewards, const float *values,
+                  const float *bootstrap, float *vs, float *advantages, int64_t B, int32_t T, float gamma,
+                  float lam, int32_t time_major, void *stream);
+int mbpo_lambda_return_scan(const float *rewards, const float *next_values, float *returns, int64_t B, int32_t T,
+                            float gamma, float lam, int32_t time_major, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

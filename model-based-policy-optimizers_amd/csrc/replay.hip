@@ -1,0 +1,226 @@
+// replay.hip — R9 UniformSamplingQueue (insert / gather / sample) and R8 running_statistics (see mbpo_hip.h).
+//
+// HBM-bound byte movers: rows are moved as dwords with consecutive lanes on consecutive floats of the
+// flattened [n_rows*row_len] range, so every wave-instruction touches 256 contiguous bytes on the
+// contiguous side of the copy (the gather side is row-granular: row_len*4 B segments).
+// All position arithmetic is int32/int64 and identical to the reference's (bit-exact requirement).
+#include "common.hpp"
+
+// state = {insert_position, sample_position, head, total_inserted}
+struct ReplayPos {
+  int pos, roll, head;
+};
+
+__device__ __forceinline__ ReplayPos replay_plan(const int *state, long long max_size, long long n) {
+  // insert_internal [3P brax]: roll = min(0, len(data) - position - len(update)); data = roll(data, roll);
+  // position += roll; dynamic_update_slice at position.
+  ReplayPos p;
+  long long pos = state[0];
+  long long roll = max_size - pos - n;
+  if (roll > 0) roll = 0;
+  p.roll = (int)roll;
+  p.pos = (int)(pos + roll);
+  // jnp.roll(data, roll<0): new[i] = old[(i - roll) % max]  =>  head' = (head - roll) % max
+  p.head = (int)(((long long)state[2] - roll) % max_size);
+  return p;
+}
+
+__global__ void __launch_bounds__(256) k_replay_insert(float *data, long long max_size, int D, const int *state,
+                                                        const float *rows, long long n_rows) {
+  const ReplayPos p = replay_plan(state, max_size, n_rows);
+  const long long total = n_rows * D;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long r = i / D;
+    int c = (int)(i - r * D);
+    long long phys = (p.pos + r + p.head) % max_size;
+    data[phys * D + c] = rows[i];
+  }
+}
+
+__global__ void k_replay_advance(int *state, long long max_size, long long n_rows) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const ReplayPos p = replay_plan(state, max_size, n_rows);
+    long long newpos = ((long long)p.pos + n_rows) % (max_size + 1);  // position = (position + len(update)) % (len(data)+1)
+    long long sp = (long long)state[1] + p.roll;                        // sample_position = max(0, sample_position + roll)
+    state[0] = (int)newpos;
+    state[1] = (int)(sp > 0 ? sp : 0);
+    state[2] = p.head;
+    state[3] = (int)((unsigned)state[3] + (unsigned)n_rows);
+  }
+}
+
+extern "C" int mbpo_replay_insert(float *data, int64_t max_size, int32_t row_len, int32_t *state, const float *rows,
+                                  int64_t n_rows, void *stream) {
+  MBPO_REQUIRE(data && state, MBPO_ERR_ARG, "replay_insert: null pointer");
+  MBPO_REQUIRE(max_size > 0 && max_size < (1LL << 31) - 1 && row_len > 0, MBPO_ERR_ARG, "replay_insert: bad max_size/row_len");
+  MBPO_REQUIRE(n_rows >= 0 && n_rows <= max_size, MBPO_ERR_ARG,
+               "replay_insert: %lld rows do not fit a buffer of %lld rows", (long long)n_rows, (long long)max_size);
+  if (n_rows == 0) return MBPO_OK;
+  MBPO_REQUIRE(rows, MBPO_ERR_ARG, "replay_insert: null rows");
+  long long total = n_rows * row_len;
+  int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_replay_insert, dim3(grid), dim3(256), 0, st, data, (long long)max_size, row_len, state, rows,
+                     (long long)n_rows);
+  hipLaunchKernelGGL(k_replay_advance, dim3(1), dim3(64), 0, st, state, (long long)max_size, (long long)n_rows);
+  MBPO_CHECK_LAUNCH("replay_insert");
+  return MBPO_OK;
+}
+
+// SAMPLE: false -> idx given (gather); true -> idx from Philox
+template <bool SAMPLE>
+__global__ void __launch_bounds__(256) k_replay_gather(const float *data, long long max_size, int D, const int *state,
+                                                        const int *idx, unsigned long long seed, unsigned long long offset,
+                                                        long long n, int *idx_out, float *out) {
+  const int head = state[2];
+  const int lo = state[1], hi = state[0];
+  const long long total = n * D;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long j = i / D;
+    int c = (int)(i - j * D);
+    long long li;
+    if (SAMPLE) {
+      // jax.random.randint(sample_key, (n,), minval=sample_position, maxval=insert_position) — stream restated with Philox
+      li = philox_randint(seed, offset, MBPO_STREAM_REPLAY, (unsigned long long)j, lo, hi);
+      if (idx_out && c == 0) idx_out[j] = (int)li;
+    } else {
+      li = idx[j];
+    }
+    // jnp.take(mode='wrap'): python-style modulo
+    long long w = li % max_size;
+    if (w < 0) w += max_size;
+    long long phys = (w + head) % max_size;
+    out[i] = data[phys * D + c];
+  }
+}
+
+extern "C" int mbpo_replay_gather(const float *data, int64_t max_size, int32_t row_len, const int32_t *state,
+                                  const int32_t *idx, int64_t n, float *out, void *stream) {
+  MBPO_REQUIRE(data && state, MBPO_ERR_ARG, "replay_gather: null pointer");
+  MBPO_REQUIRE(max_size > 0 && row_len > 0 && n >= 0, MBPO_ERR_ARG, "replay_gather: bad sizes");
+  if (n == 0) return MBPO_OK;
+  MBPO_REQUIRE(idx && out, MBPO_ERR_ARG, "replay_gather: null idx/out");
+  long long total = n * row_len;
+  int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_replay_gather<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, (long long)max_size, row_len,
+                     state, idx, 0ull, 0ull, (long long)n, (int *)nullptr, out);
+  MBPO_CHECK_LAUNCH("replay_gather");
+  return MBPO_OK;
+}
+
+extern "C" int mbpo_replay_sample(const float *data, int64_t max_size, int32_t row_len, const int32_t *state, uint64_t seed,
+                                  uint64_t offset, int64_t n, int32_t *idx_out, float *out, void *stream) {
+  MBPO_REQUIRE(data && state, MBPO_ERR_ARG, "replay_sample: null pointer");
+  MBPO_REQUIRE(max_size > 0 && row_len > 0 && n >= 0, MBPO_ERR_ARG, "replay_sample: bad sizes");
+  if (n == 0) return MBPO_OK;
+  MBPO_REQUIRE(out, MBPO_ERR_ARG, "replay_sample: null out");
+  long long total = n * row_len;
+  int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_replay_gather<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, (long long)max_size, row_len,
+                     state, (const int *)nullptr, (unsigned long long)seed, (unsigned long long)offset, (long long)n, idx_out, out);
+  MBPO_CHECK_LAUNCH("replay_sample");
+  return MBPO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// running_statistics.update, split into reduce (per-rank sums) and apply.
+// ------------------------------------------------------------------------------------------------
+#define STATS_WGS 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// Two passes, exactly as acme's update (so n=1 / constant columns give summed_variance == 0 exactly):
+//   pass 0: partial[g][X] = sum over the workgroup's rows of d = obs - mean_old
+//   pass 1: partial[g][X] = sum of d * (d - upd), upd = sum_d / (count + n)  (sum_d, n read from `sums`,
+//           which a multi-GPU host has all-reduced in between — the reference's psum under pmap_axis_name)
+// Fixed summation order everywhere (deterministic).
+template <int PASS>
+__global__ void __launch_bounds__(256) k_stats_partial(const float *rows, long long n_rows, int D, int col_off, int X,
+                                                        const float *stats, const float *sums, float *partial) {
+  const int tid = threadIdx.x;
+  const float *mean = stats + 1;
+  const int rows_per_pass = 256 / X;
+  const int c = tid % X, r0 = tid / X;
+  float acc = 0.f;
+  if (r0 < rows_per_pass) {
+    const float m = mean[c];
+    float upd = 0.f;
+    if (PASS == 1) upd = sums[1 + c] / (stats[0] + sums[0]);
+    for (long long r = (long long)blockIdx.x * rows_per_pass + r0; r < n_rows; r += (long long)gridDim.x * rows_per_pass) {
+      float d = rows[r * D + col_off + c] - m;
+      acc += (PASS == 0) ? d : d * (d - upd);
+    }
+  }
+  __shared__ float s_all[256];
+  s_all[tid] = acc;
+  __syncthreads();
+  if (tid < X) {
+    float a = 0.f;
+    for (int t = tid; t < rows_per_pass * X; t += X) a += s_all[t];
+    partial[(long long)blockIdx.x * X + tid] = a;
+  }
+}
+
+template <int PASS>
+__global__ void k_stats_sums(const float *partial, int n_parts, int X, long long n_rows, float *sums) {
+  const int tid = threadIdx.x;
+  if (tid < X) {
+    float acc = 0.f;
+    for (int g = 0; g < n_parts; ++g) acc += partial[g * X + tid];
+    sums[1 + PASS * X + tid] = acc;
+  }
+  if (PASS == 0 && tid == 0) sums[0] = (float)n_rows;
+}
+
+extern "C" int mbpo_running_stats_reduce(const float *rows, int64_t n_rows, int32_t row_len, int32_t col_off, int32_t x_dim,
+                                         const float *stats, float *sums, float *workspace, int32_t pass, void *stream) {
+  MBPO_REQUIRE(stats && sums && workspace, MBPO_ERR_ARG, "running_stats_reduce: null pointer");
+  MBPO_REQUIRE(x_dim > 0 && x_dim <= 128 && row_len > 0 && col_off >= 0 && col_off + x_dim <= row_len, MBPO_ERR_ARG,
+               "running_stats_reduce: bad column range (x_dim must be <= 128)");
+  MBPO_REQUIRE(n_rows >= 0 && (n_rows == 0 || rows), MBPO_ERR_ARG, "running_stats_reduce: bad rows");
+  MBPO_REQUIRE(pass == 0 || pass == 1, MBPO_ERR_ARG, "running_stats_reduce: pass must be 0 or 1");
+  hipStream_t st = (hipStream_t)stream;
+  int rows_per_pass = 256 / x_dim;
+  long long want = (n_rows + rows_per_pass - 1) / rows_per_pass;
+  int grid = (int)(want < 1 ? 1 : (want < STATS_WGS ? want : STATS_WGS));
+  if (pass == 0) {
+    hipLaunchKernelGGL(k_stats_partial<0>, dim3(grid), dim3(256), 0, st, rows, (long long)n_rows, row_len, col_off, x_dim, stats,
+                       (const float *)sums, workspace);
+    hipLaunchKernelGGL(k_stats_sums<0>, dim3(1), dim3(128), 0, st, workspace, grid, x_dim, (long long)n_rows, sums);
+  } else {
+    hipLaunchKernelGGL(k_stats_partial<1>, dim3(grid), dim3(256), 0, st, rows, (long long)n_rows, row_len, col_off, x_dim, stats,
+                       (const float *)sums, workspace);
+    hipLaunchKernelGGL(k_stats_sums<1>, dim3(1), dim3(128), 0, st, workspace, grid, x_dim, (long long)n_rows, sums);
+  }
+  MBPO_CHECK_LAUNCH("running_stats_reduce");
+  return MBPO_OK;
+}
+
+__global__ void k_stats_apply(float *stats, const float *sums, int X) {
+  const int c = threadIdx.x;
+  // [3P] running_statistics.update: count = state.count + step_increment; mean += sum(diff_to_old_mean)/count;
+  // summed_variance += sum(diff_to_old * diff_to_new); std = clip(sqrt(max(sv,0)/count), 1e-6, 1e6)
+  const float count = stats[0] + sums[0];
+  if (c < X && count > 0.f) {
+    float *mean = stats + 1, *sv = stats + 1 + X, *sd = stats + 1 + 2 * X;
+    mean[c] = mean[c] + sums[1 + c] / count;
+    float nsv = sv[c] + sums[1 + X + c];
+    sv[c] = nsv;
+    float s = sqrtf(fmaxf(nsv, 0.f) / count);
+    sd[c] = fminf(fmaxf(s, 1e-6f), 1e6f);
+  }
+  __syncthreads();
+  if (c == 0) stats[0] = count;
+}
+
+extern "C" int mbpo_running_stats_apply(float *stats, const float *sums, int32_t x_dim, void *stream) {
+  MBPO_REQUIRE(stats && sums, MBPO_ERR_ARG, "running_stats_apply: null pointer");
+  MBPO_REQUIRE(x_dim > 0 && x_dim <= 128, MBPO_ERR_ARG, "running_stats_apply: x_dim out of range");
+  hipLaunchKernelGGL(k_stats_apply, dim3(1), dim3(128), 0, (hipStream_t)stream, stats, sums, x_dim);
+  MBPO_CHECK_LAUNCH("running_stats_apply");
+  return MBPO_OK;
+}

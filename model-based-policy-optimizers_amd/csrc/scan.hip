@@ -1,0 +1,180 @@
+// scan.hip — P4 GAE (ppo/losses.py:128-184) and B2 lambda-return (utils/optimizer_utils.py:119-152).
+//
+// Both are reverse first-order linear recurrences  A_t = d_t + c_t * A_{t+1}.  HBM-bound: GAE moves
+// 4 reads + 2 writes = 24 B per (t,b) element (+4/T for the bootstrap), lambda-return 2 reads + 1 write = 12 B.
+//
+// batch-major [B,T] (PPO's native layout): the time axis sits on the LANES of a wavefront.  Each element
+// is the affine map f_t(a) = d_t + c_t*a; a Hillis-Steele suffix scan over lanes with __shfl_down composes
+// (c1,d1) o (c2,d2) = (c1*c2, d1 + c1*d2) in log2(Tp) steps.  Rows shorter than 64 are packed 64/Tp per
+// wave (segmented scan, Tp = next power of two >= T) so loads stay coalesced; rows longer than 64 are
+// walked in 64-step chunks from the end with a scalar carry.
+// time-major [T,B] (the reference's layout after its transpose): lane <-> b, sequential over t, coalesced.
+#include "common.hpp"
+
+#define MODE_GAE 0
+#define MODE_LAMBDA 1
+
+struct ScanArgs {
+  const float *trunc, *term, *rew, *val, *boot;  // GAE inputs; lambda: rew, val = next_values
+  float *out0, *out1;                            // GAE: vs, adv;  lambda: returns
+  long long B;
+  int T;
+  float gamma, lam;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_scan_time_major(ScanArgs A) {
+  const long long B = A.B;
+  const int T = A.T;
+  for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long long)gridDim.x * blockDim.x) {
+    if (MODE == MODE_GAE) {
+      const float boot = A.boot[b];
+      float acc = 0.f;        // acc = zeros_like(bootstrap_value)   (losses.py:161)
+      float v_next = boot;    // values_t_plus_1[-1] = bootstrap      (:155-156)
+      float vs_next = boot;   // vs_t_plus_1[-1] = bootstrap          (:179-180)
+      for (int t = T - 1; t >= 0; --t) {
+        const long long i = (long long)t * B + b;
+        const float tr = A.trunc[i], te = A.term[i], r = A.rew[i], v = A.val[i];
+        const float m = 1.f - tr;
+        const float g1 = A.gamma * (1.f - te);
+        const float delta = (r + g1 * v_next - v) * m;        // :157-158
+        acc = delta + g1 * m * A.lam * acc;                   // :166
+        const float vs = acc + v;                             // :176
+        A.out0[i] = vs;
+        A.out1[i] = (r + g1 * vs_next - v) * m;               // :181-182
+        v_next = v;
+        vs_next = vs;
+      }
+    } else {
+      float agg = A.val[(long long)(T - 1) * B + b];          // start = next_values[-1] (optimizer_utils.py:131)
+      const float gl = A.gamma * A.lam;
+      for (int t = T - 1; t >= 0; --t) {
+        const long long i = (long long)t * B + b;
+        const float inp = A.rew[i] + A.gamma * A.val[i] * (1.f - A.lam);   // :128
+        agg = inp + gl * agg;                                              // :130
+        A.out0[i] = agg;
+      }
+    }
+  }
+}
+
+// TP: segment width on the lanes (power of two, <= 64)
+template <int MODE, int TP>
+__global__ void __launch_bounds__(256) k_scan_batch_major(ScanArgs A) {
+  constexpr int RPW = 64 / TP;  // rows per wave
+  const int lane = threadIdx.x & 63;
+  const int seg = lane / TP, tl = lane % TP;
+  const long long wave_global = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long n_groups = (A.B + RPW - 1) / RPW;
+  const int T = A.T;
+  const int n_chunks = (T + TP - 1) / TP;  // > 1 only when TP == 64
+  for (long long grp = wave_global; grp < n_groups; grp += n_waves) {
+    const long long b = grp * RPW + seg;
+    const bool row_ok = b < A.B;
+    float carry_a, carry_vs = 0.f;
+    float boot = 0.f;
+    if (MODE == MODE_GAE) {
+      boot = row_ok ? A.boot[b] : 0.f;
+      carry_a = 0.f;
+      carry_vs = boot;
+    } else {
+      carry_a = row_ok ? A.val[b * T + (T - 1)] : 0.f;
+    }
+    for (int ch = n_chunks - 1; ch >= 0; --ch) {
+      const int t = ch * TP + tl;
+      const bool ok = row_ok && t < T;
+      const long long i = b * T + t;
+      float c = 1.f, d = 0.f, v = 0.f, r = 0.f, m = 0.f, g1 = 0.f;
+      if (ok) {
+        if (MODE == MODE_GAE) {
+          const float tr = A.trunc[i], te = A.term[i];
+          r = A.rew[i];
+          v = A.val[i];
+          const float v_next = (t == T - 1) ? boot : A.val[i + 1];
+          m = 1.f - tr;
+          g1 = A.gamma * (1.f - te);
+          d = (r + g1 * v_next - v) * m;
+          c = g1 * m * A.lam;
+        } else {
+          d = A.rew[i] + A.gamma * A.val[i] * (1.f - A.lam);
+          c = A.gamma * A.lam;
+        }
+      }
+      // lanes past the end of the row are the identity map (c=1,d=0): they pass the carry through
+      // inclusive suffix scan within the segment
+#pragma unroll
+      for (int off = 1; off < TP; off <<= 1) {
+        float c2 = __shfl_down(c, off, TP);
+        float d2 = __shfl_down(d, off, TP);
+        if (tl + off < TP) {
+          d = d + c * d2;
+          c = c * c2;
+        }
+      }
+      const float a = d + c * carry_a;  // A_t
+      if (MODE == MODE_GAE) {
+        const float vs = a + v;
+        float vs_next = __shfl_down(vs, 1, TP);
+        // the last valid lane of the chunk takes the carry (bootstrap, or the first vs of the later chunk)
+        const bool last_in_chunk = (tl == TP - 1) || (t == T - 1);
+        if (last_in_chunk) vs_next = carry_vs;
+        if (ok) {
+          A.out0[i] = vs;
+          A.out1[i] = (r + g1 * vs_next - v) * m;
+        }
+        carry_vs = __shfl(vs, seg * TP, 64);
+      } else {
+        if (ok) A.out0[i] = a;
+      }
+      carry_a = __shfl(a, seg * TP, 64);
+    }
+  }
+}
+
+template <int MODE>
+static int launch_scan(const ScanArgs &A, int time_major, hipStream_t st, const char *what) {
+  if (A.B == 0 || A.T == 0) return MBPO_OK;
+  if (time_major) {
+    long long blocks = (A.B + 255) / 256;
+    int grid = (int)(blocks < 2048 ? blocks : 2048);
+    hipLaunchKernelGGL(k_scan_time_major<MODE>, dim3(grid), dim3(256), 0, st, A);
+  } else {
+    int tp = 1;
+    while (tp < A.T && tp < 64) tp <<= 1;
+    long long groups = (A.B + (64 / tp) - 1) / (64 / tp);
+    long long blocks = (groups + 3) / 4;
+    int grid = (int)(blocks < 2048 ? blocks : 2048);
+#define CASE_TP(V) case V: hipLaunchKernelGGL((k_scan_batch_major<MODE, V>), dim3(grid), dim3(256), 0, st, A); break;
+    switch (tp) {
+      CASE_TP(1) CASE_TP(2) CASE_TP(4) CASE_TP(8) CASE_TP(16) CASE_TP(32) CASE_TP(64)
+    }
+#undef CASE_TP
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    mbpo_set_error("%s: %s", what, hipGetErrorString(e));
+    return MBPO_ERR_LAUNCH;
+  }
+  return MBPO_OK;
+}
+
+extern "C" int mbpo_gae_scan(const float *truncation, const float *termination, const float *rewards, const float *values,
+                             const float *bootstrap, float *vs, float *advantages, int64_t B, int32_t T, float gamma,
+                             float lam, int32_t time_major, void *stream) {
+  MBPO_REQUIRE(B >= 0 && T >= 0, MBPO_ERR_ARG, "gae_scan: negative size");
+  if (B == 0 || T == 0) return MBPO_OK;
+  MBPO_REQUIRE(truncation && termination && rewards && values && bootstrap && vs && advantages, MBPO_ERR_ARG,
+               "gae_scan: null pointer");
+  ScanArgs A{truncation, termination, rewards, values, bootstrap, vs, advantages, B, T, gamma, lam};
+  return launch_scan<MODE_GAE>(A, time_major, (hipStream_t)stream, "gae_scan");
+}
+
+extern "C" int mbpo_lambda_return_scan(const float *rewards, const float *next_values, float *returns, int64_t B, int32_t T,
+                                       float gamma, float lam, int32_t time_major, void *stream) {
+  MBPO_REQUIRE(B >= 0 && T >= 0, MBPO_ERR_ARG, "lambda_return_scan: negative size");
+  if (B == 0 || T == 0) return MBPO_OK;
+  MBPO_REQUIRE(rewards && next_values && returns, MBPO_ERR_ARG, "lambda_return_scan: null pointer");
+  ScanArgs A{nullptr, nullptr, rewards, next_values, nullptr, returns, nullptr, B, T, gamma, lam};
+  return launch_scan<MODE_LAMBDA>(A, time_major, (hipStream_t)stream, "lambda_return_scan");
+}

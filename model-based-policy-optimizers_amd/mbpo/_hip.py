@@ -108,10 +108,12 @@ def _bind_optional(lib: C.CDLL) -> None:
     """Signatures of the remaining entry points (bound when present so partial builds still load)."""
     i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
     sigs = {
-        "mbpo_replay_insert": [vp, i64, i32, vp, vp, vp, i64, vp],
+        # name: argtypes (see include/mbpo_hip.h)
+        "mbpo_replay_insert": [vp, i64, i32, vp, vp, i64, vp],
         "mbpo_replay_gather": [vp, i64, i32, vp, vp, i64, vp, vp],
         "mbpo_replay_sample": [vp, i64, i32, vp, u64, u64, i64, vp, vp, vp],
-        "mbpo_running_stats_update": [vp, i64, i32, i32, vp, vp, vp, vp, vp],
+        "mbpo_running_stats_reduce": [vp, i64, i32, i32, i32, vp, vp, vp, i32, vp],
+        "mbpo_running_stats_apply": [vp, vp, i32, vp],
         "mbpo_gae_scan": [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp],
         "mbpo_lambda_return_scan": [vp, vp, vp, i64, i32, f32, f32, i32, vp],
     }

@@ -123,3 +123,104 @@ def model_rollout(*, policy_params: torch.Tensor, policy_spec: MlpSpec, x_dim: i
     d.transitions, d.row_len = out.data_ptr(), D
     check(lib.mbpo_model_rollout(C.byref(d), current_stream_ptr()), "mbpo_model_rollout")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ replay (R9)
+def replay_insert(data: torch.Tensor, state: torch.Tensor, rows: torch.Tensor) -> None:
+    """UniformSamplingQueue.insert on a ring-stored buffer.  data [max,D]; state int32[4]; rows [n,D]."""
+    lib = load()
+    _req(data, "data"); _req(state, "state", torch.int32); _req(rows, "rows")
+    if rows.dim() != 2 or rows.shape[1] != data.shape[1]:
+        raise ValueError(f"rows must be [n,{data.shape[1]}], got {tuple(rows.shape)}")
+    check(lib.mbpo_replay_insert(data.data_ptr(), data.shape[0], data.shape[1], state.data_ptr(), rows.data_ptr(),
+                                 rows.shape[0], current_stream_ptr()), "mbpo_replay_insert")
+
+
+def replay_gather(data: torch.Tensor, state: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """jnp.take(data_logical, idx, axis=0, mode='wrap')."""
+    lib = load()
+    _req(data, "data"); _req(state, "state", torch.int32); _req(idx, "idx", torch.int32)
+    out = torch.empty((idx.numel(), data.shape[1]), device=data.device, dtype=torch.float32)
+    check(lib.mbpo_replay_gather(data.data_ptr(), data.shape[0], data.shape[1], state.data_ptr(), idx.data_ptr(),
+                                 idx.numel(), out.data_ptr(), current_stream_ptr()), "mbpo_replay_gather")
+    return out
+
+
+def replay_sample(data: torch.Tensor, state: torch.Tensor, n: int, seed: int, offset: int, return_idx: bool = False,
+                  out: Optional[torch.Tensor] = None):
+    """UniformSamplingQueue.sample: Philox randint in [sample_position, insert_position) + gather, one launch."""
+    lib = load()
+    _req(data, "data"); _req(state, "state", torch.int32)
+    if out is None:
+        out = torch.empty((n, data.shape[1]), device=data.device, dtype=torch.float32)
+    idx = torch.empty((n,), device=data.device, dtype=torch.int32) if return_idx else None
+    check(lib.mbpo_replay_sample(data.data_ptr(), data.shape[0], data.shape[1], state.data_ptr(), seed, offset, n,
+                                 ptr(idx), out.data_ptr(), current_stream_ptr()), "mbpo_replay_sample")
+    return (out, idx) if return_idx else out
+
+
+# ------------------------------------------------------------------------------------------------ running statistics (R8)
+STATS_WORKSPACE_FLOATS = 64 * 2 * 128
+
+
+def running_stats_reduce(rows: torch.Tensor, col_off: int, x_dim: int, stats: torch.Tensor, pass_: int,
+                         sums: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One pass of running_statistics.update's reductions (pass 0: n, sum d; pass 1: sum d*(d-upd))."""
+    lib = load()
+    _req(rows, "rows"); _req(stats, "stats")
+    if sums is None:
+        sums = torch.zeros(1 + 2 * x_dim, device=rows.device, dtype=torch.float32)
+    if workspace is None:
+        workspace = torch.empty(64 * x_dim, device=rows.device, dtype=torch.float32)
+    check(lib.mbpo_running_stats_reduce(rows.data_ptr(), rows.shape[0], rows.shape[1], col_off, x_dim, stats.data_ptr(),
+                                        sums.data_ptr(), workspace.data_ptr(), pass_, current_stream_ptr()),
+          "mbpo_running_stats_reduce")
+    return sums
+
+
+def running_stats_update(rows: torch.Tensor, col_off: int, x_dim: int, stats: torch.Tensor, all_reduce=None) -> None:
+    """running_statistics.update(state, rows[:, col_off:col_off+x_dim]); `all_reduce(t)` sums `t` over ranks in place
+    (the reference's psum under pmap_axis_name, sac/sac.py:298-301)."""
+    sums = running_stats_reduce(rows, col_off, x_dim, stats, 0)
+    if all_reduce is not None:
+        all_reduce(sums)
+    running_stats_reduce(rows, col_off, x_dim, stats, 1, sums=sums)
+    if all_reduce is not None:
+        all_reduce(sums[1 + x_dim:])
+    running_stats_apply(stats, sums, x_dim)
+
+
+def running_stats_apply(stats: torch.Tensor, sums: torch.Tensor, x_dim: int) -> None:
+    lib = load()
+    _req(stats, "stats"); _req(sums, "sums")
+    check(lib.mbpo_running_stats_apply(stats.data_ptr(), sums.data_ptr(), x_dim, current_stream_ptr()),
+          "mbpo_running_stats_apply")
+
+
+# ------------------------------------------------------------------------------------------------ scans (P4, B2)
+def gae_scan(truncation, termination, rewards, values, bootstrap, gamma: float, lam: float, time_major: bool = False):
+    """compute_gae (ppo/losses.py:128-184).  Arrays [B,T] (time_major=False) or [T,B]; bootstrap [B]."""
+    lib = load()
+    for t, nm in ((truncation, "truncation"), (termination, "termination"), (rewards, "rewards"), (values, "values"),
+                  (bootstrap, "bootstrap")):
+        _req(t, nm)
+    B, T = (values.shape[1], values.shape[0]) if time_major else (values.shape[0], values.shape[1])
+    if bootstrap.shape != (B,):
+        raise ValueError("bootstrap must be [B]")
+    vs = torch.empty_like(values)
+    adv = torch.empty_like(values)
+    check(lib.mbpo_gae_scan(truncation.data_ptr(), termination.data_ptr(), rewards.data_ptr(), values.data_ptr(),
+                            bootstrap.data_ptr(), vs.data_ptr(), adv.data_ptr(), B, T, gamma, lam, int(time_major),
+                            current_stream_ptr()), "mbpo_gae_scan")
+    return vs, adv
+
+
+def lambda_return_scan(rewards, next_values, gamma: float, lam: float, time_major: bool = False):
+    """lambda_return (utils/optimizer_utils.py:119-152)."""
+    lib = load()
+    _req(rewards, "rewards"); _req(next_values, "next_values")
+    B, T = (rewards.shape[1], rewards.shape[0]) if time_major else (rewards.shape[0], rewards.shape[1])
+    out = torch.empty_like(rewards)
+    check(lib.mbpo_lambda_return_scan(rewards.data_ptr(), next_values.data_ptr(), out.data_ptr(), B, T, gamma, lam,
+                                      int(time_major), current_stream_ptr()), "mbpo_lambda_return_scan")
+    return out
