@@ -163,6 +163,51 @@ int mbpo_gae_scan(const float *truncation, const float *termination, const float
 int mbpo_lambda_return_scan(const float *rewards, const float *next_values, float *returns, int64_t B, int32_t T,
                             float gamma, float lam, int32_t time_major, void *stream);
 
+/* ---- S3-S8: SAC sgd_step (sac/sac.py:227-281) -------------------------------------------------
+ * replaces: SAC.sgd_step = alpha_update + critic_update + actor_update (all three evaluated at the OLD
+ *           (alpha, policy, q) parameters, sac.py:234-258) + Polyak target update (sac.py:260-261);
+ *           losses sac/losses.py:61-125; gradient_update_fn + optax chain(clip_by_global_norm, adamw)
+ *           sac/utils.py:36-63, sac/sac.py:175-186.
+ *
+ * Flat train state (device, fp32), NP = P + 2*Q + 1 with P = policy params, Q = params of one critic:
+ *   params   [NP] = [ policy | critic 0 | critic 1 | log_alpha ]
+ *   target_q [2Q];  adam_m [NP];  adam_v [NP];  step_count [1] (optimizer step count, as float)
+ *   grads    [NP]   written by mbpo_sac_grads, read by mbpo_sac_apply (all-reduce it in between for N>1 ranks —
+ *                   the live form of the reference's dead jax.lax.pmean, sac/utils.py:29-33)
+ * Three entry points so that the multi-GPU exchange sits at the reference's pmean position:
+ *   mbpo_sac_grads      : per-sample forward/backward of the three losses on one minibatch -> grads, metrics[0..2]
+ *                         (critic_loss, actor_loss, alpha_loss); also bumps step_count and leaves per-group
+ *                         sum-of-squares partials of `grads` in the workspace.
+ *   mbpo_sac_grad_norms : recompute those partials from `grads` (call after an all-reduce changed it).
+ *   mbpo_sac_apply      : grads *= grad_scale; clip_by_global_norm per optimizer; AdamW; target <- (1-tau) target + tau q_new;
+ *                         metrics[3] = exp(new log_alpha).
+ * Noise: explicit standard-normal tensors [B,u] or NULL -> Philox(seed, offset + step_count), streams 5/6/7.
+ */
+typedef struct mbpo_sac_desc {
+  int32_t x_dim, u_dim;
+  int32_t policy_layers;                     /* Dense layers of the policy: dims policy_dims[0..policy_layers] */
+  int32_t policy_dims[MBPO_MAX_LAYERS + 1];  /* [x_dim, hidden..., 2*u_dim] */
+  int32_t q_layers;
+  int32_t q_dims[MBPO_MAX_LAYERS + 1];       /* [x_dim+u_dim, hidden..., 1] */
+  int32_t policy_activation, q_activation;   /* MBPO_ACT_* */
+  float *params, *target_q, *adam_m, *adam_v, *step_count, *grads;
+  float *workspace;                          /* >= mbpo_sac_workspace_floats() floats */
+  float *metrics;                            /* [4] critic_loss, actor_loss, alpha_loss, alpha */
+  const float *batch;                        /* [batch_size, row_len] SAC transition rows (2x+u+3) */
+  int32_t batch_size, row_len;
+  const float *norm_mean, *norm_std;         /* [x_dim] or NULL */
+  const float *noise_alpha, *noise_critic, *noise_actor; /* [batch_size, u_dim] or NULL */
+  uint64_t seed, offset;
+  float discounting, reward_scaling, target_entropy, tau;
+  float lr_policy, lr_q, lr_alpha, wd_policy, wd_q, wd_alpha, max_grad_norm;
+  float grad_scale;                          /* 1/world_size when grads were all-reduced with SUM, else 1 */
+} mbpo_sac_desc;
+
+int64_t mbpo_sac_workspace_floats(const mbpo_sac_desc *d);
+int mbpo_sac_grads(const mbpo_sac_desc *d, void *stream);
+int mbpo_sac_grad_norms(const mbpo_sac_desc *d, void *stream);
+int mbpo_sac_apply(const mbpo_sac_desc *d, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

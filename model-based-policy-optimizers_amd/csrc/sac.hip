@@ -1,0 +1,502 @@
+// sac.hip — S3-S8: SAC sgd_step as three kernels (see include/mbpo_hip.h for the flat state layout).
+//
+//   k_sac_fwd_bwd   2 workgroups per 16-sample tile: a CRITIC role (pi(s') fwd, target-Q fwd, Q fwd+bwd) and an
+//                   ACTOR role (pi(s) fwd+bwd, alpha loss, Q fwd + input-gradient bwd).  All three losses are taken
+//                   at the OLD parameters (sac/sac.py:234-258), so the roles are independent.  fp32 MFMA; activations,
+//                   pre-activations and deltas live in LDS; each workgroup writes its weight gradients to a private
+//                   SLAB laid out like the flat params (no atomics: the cross-tile sum is a fixed-order reduce ->
+//                   bitwise reproducible).
+//   k_sac_reduce    grads[i] = sum over tiles of slab[t][i]; loss metrics; per-group sum-of-squares partials.
+//   k_sac_apply     clip_by_global_norm + AdamW per optimizer group + Polyak on the critics.
+//
+// Algorithmic work per sample per sgd_step: 2*(5P + 12Q) FLOP — latency-bound at B=256, hence the
+// few fat launches and the slab scheme instead of a tree of small kernels.
+#include "common.hpp"
+#include "mlp_tile.hpp"
+
+#define LOG_SQRT_2PI 0.91893853320467274178f
+#define LOG_2 0.69314718055994530942f
+
+struct SacArgs {
+  MlpDev pi, q, qt;
+  int X, U, B, D;
+  const float *batch, *norm_mean, *norm_std, *log_alpha;
+  const float *noise_alpha, *noise_critic, *noise_actor;
+  unsigned long long seed, offset;
+  const float *step_count;
+  float discounting, reward_scaling, target_entropy;
+  float *slab_pi, *slab_q, *slab_ex;
+  int ld_x, ld_xu, ld_h, ld_y, LH;
+};
+
+// per action-dim pieces of NormalTanh (sac/parametric_distribution.py:66-73,117-120)
+struct ActSample {
+  float z, a, sigma, lp;
+};
+__device__ __forceinline__ ActSample normal_tanh_sample(float loc, float raw, float eps) {
+  ActSample o;
+  o.sigma = softplus_f(raw) + 0.001f;
+  o.z = loc + o.sigma * eps;
+  o.a = tanhf(o.z);
+  // log N(z; loc, sigma) with (z-loc)/sigma == eps, minus Tanh.forward_log_det_jacobian(z)
+  const float ldj = 2.0f * (LOG_2 - o.z - softplus_f(-2.0f * o.z));
+  o.lp = -0.5f * eps * eps - logf(o.sigma) - LOG_SQRT_2PI - ldj;
+  return o;
+}
+
+template <int H>
+__global__ void __launch_bounds__((H / 16) * 64) k_sac_fwd_bwd(SacArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int NW = H / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int role = blockIdx.x & 1;  // 0 = critic, 1 = actor(+alpha)
+  const int tile = blockIdx.x >> 1;
+  const int X = A.X, U = A.U, D = A.D, B = A.B;
+  const int row0 = tile * 16;
+  const int ld_x = A.ld_x, ld_xu = A.ld_xu, ld_h = A.ld_h, ld_y = A.ld_y, LH = A.LH;
+  const int hns = 16 * ld_h;  // per-net stride of a hidden tile
+
+  // ---- LDS carve ----
+  float *s_row = smem;                      // [16][D]
+  float *s_sn = s_row + 16 * D;             // [16][ld_x]   normalised obs
+  float *s_sn2 = s_sn + 16 * ld_x;          // [16][ld_x]   normalised next obs
+  float *s_qin = s_sn2 + 16 * ld_x;         // [16][ld_xu]  [sn, a]
+  float *s_qin2 = s_qin + 16 * ld_xu;       // [16][ld_xu]  [s'n, a']
+  float *s_pp = s_qin2 + 16 * ld_xu;        // [2][2][16][ld_h]  ping-pong hidden / delta buffers (2 nets)
+  float *s_store = s_pp + 4 * hns;          // [LH*4][16][ld_h]  stored z / h (role dependent split)
+  float *s_y = s_store + LH * 4 * hns;      // [2][16][ld_y]
+  float *s_dy = s_y + 2 * 16 * ld_y;        // [2][16][ld_y]
+  float *s_dx = s_dy + 2 * 16 * ld_y;       // [2][16][ld_xu]
+  float *s_eps = s_dx + 2 * 16 * ld_xu;     // [16][U]
+  float *s_a = s_eps + 16 * U;              // [16][U]
+  float *s_sig = s_a + 16 * U;              // [16][U]
+  float *s_raw = s_sig + 16 * U;            // [16][U]
+  float *s_lp = s_raw + 16 * U;             // [16][U] per-dim log-prob (critic: next action; actor: actor-loss sample)
+  float *s_lpa = s_lp + 16 * U;             // [16][U] per-dim log-prob of the alpha-loss sample
+  float *s_scal = s_lpa + 16 * U;           // [4][16] per-row scalars
+  float *s_pp_a = s_pp, *s_pp_b = s_pp + 2 * hns;
+
+  const float alpha = expf(A.log_alpha[0]);
+  const float invB = 1.0f / (float)B;
+  const unsigned long long rng_off = A.offset + (unsigned long long)A.step_count[0];
+
+  // ---- load the tile's transitions; normalise observations (q and policy both preprocess obs: sac/networks.py:76-78,96-98)
+  for (int idx = tid; idx < 16 * D; idx += nthreads) {
+    int r = idx / D, c = idx - r * D;
+    s_row[idx] = (row0 + r < B) ? A.batch[(long long)(row0 + r) * D + c] : 0.f;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 16 * X; idx += nthreads) {
+    int r = idx / X, c = idx - r * X;
+    float o = s_row[r * D + c], o2 = s_row[r * D + X + U + 2 + c];
+    if (A.norm_mean) {
+      o = (o - A.norm_mean[c]) / A.norm_std[c];
+      o2 = (o2 - A.norm_mean[c]) / A.norm_std[c];
+    }
+    s_sn[r * ld_x + c] = o;
+    s_sn2[r * ld_x + c] = o2;
+    s_qin[r * ld_xu + c] = o;
+    s_qin2[r * ld_xu + c] = o2;
+  }
+  if (role == 0) {
+    for (int idx = tid; idx < 16 * U; idx += nthreads) {
+      int r = idx / U, d = idx - r * U;
+      s_qin[r * ld_xu + X + d] = s_row[r * D + X + d];  // transitions.action
+    }
+  }
+  __syncthreads();
+
+  if (role == 0) {
+    // ============================== CRITIC (sac/losses.py:74-110) ==============================
+    // next_dist_params = policy(next_observation); next_action ~ ; next_log_prob          (:80-86)
+    mlp_forward_tile<H>(A.pi, 1, s_sn2, 0, ld_x, s_pp_a, s_pp_b, ld_h, s_y, ld_y, wave, NW, lane);
+    for (int idx = tid; idx < 16 * U; idx += nthreads) {
+      int r = idx / U, d = idx - r * U;
+      long long nidx = (long long)(row0 + r) * U + d;
+      float eps = 0.f;
+      if (row0 + r < B)
+        eps = A.noise_critic ? A.noise_critic[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_CRITIC, (unsigned long long)nidx);
+      ActSample sm = normal_tanh_sample(s_y[r * ld_y + d], s_y[r * ld_y + U + d], eps);
+      s_qin2[r * ld_xu + X + d] = sm.a;  // postprocess(next_action)                              (:87)
+      s_lp[idx] = sm.lp;
+    }
+    __syncthreads();
+    // next_q = q(target_q_params, next_observation, next_action)                                 (:88-89)
+    mlp_forward_tile<H>(A.qt, 2, s_qin2, 0, ld_xu, s_pp_a, s_pp_b, ld_h, s_y, ld_y, wave, NW, lane);
+    if (tid < 16) {
+      const int r = tid;
+      float nlp = 0.f;
+      for (int d = 0; d < U; ++d) nlp += s_lp[r * U + d];
+      const float nq = fminf(s_y[r * ld_y], s_y[(16 + r) * ld_y]);
+      const float next_v = nq - alpha * nlp;                                                   // :89
+      const float rew = s_row[r * D + X + U], disc = s_row[r * D + X + U + 1];
+      s_scal[r] = rew * A.reward_scaling + disc * A.discounting * next_v;                        // target_q :101-103
+    }
+    __syncthreads();
+    // q_old_action = q(q_params, observation, action)                                            (:78-79)
+    float *zq = s_store, *hq = s_store + LH * 2 * hns;
+    mlp_forward_tile_store<H>(A.q, 2, s_qin, 0, ld_xu, zq, hq, false, ld_h, s_y, ld_y, wave, NW, lane);
+    if (tid < 32) {
+      const int k = tid >> 4, r = tid & 15;
+      const bool ok = row0 + r < B;
+      const float trunc = s_row[r * D + D - 1];
+      const float err = ok ? (s_y[(k * 16 + r) * ld_y] - s_scal[r]) * (1.f - trunc) : 0.f;      // q_error :104-108
+      s_scal[16 + tid] = err * err;
+      // loss = 0.5*mean(err^2) over [B,2]  ->  dL/dq = err*(1-trunc)/(2B)
+      s_dy[(k * 16 + r) * ld_y] = err * (1.f - trunc) * (0.5f * invB);
+    }
+    __syncthreads();
+    float *slab = A.slab_q + (long long)tile * (2 * A.q.n_params);
+    mlp_backward_tile<H>(A.q, 2, s_qin, 0, ld_xu, zq, hq, ld_h, s_dy, ld_y, s_pp_a, s_pp_b, slab, nullptr, wave, NW, lane,
+                         tid, nthreads);
+    if (tid == 0) {
+      float acc = 0.f;
+      for (int i = 0; i < 32; ++i) acc += s_scal[16 + i];
+      A.slab_ex[tile * 4 + 0] = acc;
+    }
+  } else {
+    // ============================== ACTOR + ALPHA (sac/losses.py:61-72, 112-125) ==============================
+    float *zp = s_store, *hp = s_store + LH * hns;            // policy: z, h   [LH][1][16][ld_h] each
+    float *zq = s_store + 2 * LH * hns;                       // critics: z only [LH][2][16][ld_h]
+    mlp_forward_tile_store<H>(A.pi, 1, s_sn, 0, ld_x, zp, hp, false, ld_h, s_y, ld_y, wave, NW, lane);
+    for (int idx = tid; idx < 16 * U; idx += nthreads) {
+      int r = idx / U, d = idx - r * U;
+      long long nidx = (long long)(row0 + r) * U + d;
+      const bool ok = row0 + r < B;
+      const float loc = s_y[r * ld_y + d], raw = s_y[r * ld_y + U + d];
+      float e_al = 0.f, e_ac = 0.f;
+      if (ok) {
+        e_al = A.noise_alpha ? A.noise_alpha[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ALPHA, (unsigned long long)nidx);
+        e_ac = A.noise_actor ? A.noise_actor[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ACTOR, (unsigned long long)nidx);
+      }
+      ActSample sal = normal_tanh_sample(loc, raw, e_al);   // alpha loss sample (:66-68)
+      ActSample sac = normal_tanh_sample(loc, raw, e_ac);   // actor loss sample (:117-119)
+      s_lp[idx] = sac.lp;
+      s_lpa[idx] = sal.lp;
+      s_eps[idx] = e_ac;
+      s_a[idx] = sac.a;
+      s_sig[idx] = sac.sigma;
+      s_raw[idx] = raw;
+      s_qin[r * ld_xu + X + d] = sac.a;  // postprocess(action) (:120)
+    }
+    __syncthreads();
+    if (tid < 16) {
+      const int r = tid;
+      const bool ok = row0 + r < B;
+      float lp_al = 0.f, lp_ac = 0.f;
+      for (int d = 0; d < U; ++d) {
+        lp_al += s_lpa[r * U + d];
+        lp_ac += s_lp[r * U + d];
+      }
+      // alpha_loss = alpha * stop_gradient(-log_prob - target_entropy); d/dlog_alpha = the same value   (:70-72)
+      s_scal[r] = ok ? alpha * (-lp_al - A.target_entropy) : 0.f;
+      s_scal[16 + r] = ok ? lp_ac : 0.f;
+    }
+    __syncthreads();
+    // q_action = q(q_params, observation, action)  with the OLD q_params (sac.py:253)              (:121-122)
+    mlp_forward_tile_store<H>(A.q, 2, s_qin, 0, ld_xu, zq, s_pp, true, ld_h, s_y, ld_y, wave, NW, lane);
+    if (tid < 16) {
+      const int r = tid;
+      const bool ok = row0 + r < B;
+      const float q0 = s_y[r * ld_y], q1 = s_y[(16 + r) * ld_y];
+      const float mq = fminf(q0, q1);
+      s_scal[32 + r] = ok ? (alpha * s_scal[16 + r] - mq) : 0.f;   // actor_loss = alpha*log_prob - min_q   (:123-124)
+      // d(mean(-min_q))/dq_k: -1/B on the arg-min critic (ties split evenly, as jnp.min's gradient does)
+      float g0 = 0.f, g1 = 0.f;
+      if (ok) {
+        if (q0 < q1) g0 = -invB;
+        else if (q1 < q0) g1 = -invB;
+        else g0 = g1 = -0.5f * invB;
+      }
+      s_dy[r * ld_y] = g0;
+      s_dy[(16 + r) * ld_y] = g1;
+    }
+    __syncthreads();
+    // backward through the critics: input gradient only (no weight gradients: q_params are not the actor's variables)
+    mlp_backward_tile<H>(A.q, 2, s_qin, 0, ld_xu, zq, nullptr, ld_h, s_dy, ld_y, s_pp_a, s_pp_b, nullptr, s_dx, wave, NW,
+                         lane, tid, nthreads);
+    for (int idx = tid; idx < 16 * U; idx += nthreads) {
+      int r = idx / U, d = idx - r * U;
+      const bool ok = row0 + r < B;
+      const float a = s_a[idx], sg = s_sig[idx], eps = s_eps[idx], raw = s_raw[idx];
+      const float dLda = s_dx[r * ld_xu + X + d] + s_dx[(16 + r) * ld_xu + X + d];
+      // z = loc + sigma*eps;  log_prob = const - log(sigma) - log(1 - tanh(z)^2)  =>  dlp/dz = 2a, dlp/dsigma = -1/sigma
+      const float gz = dLda * (1.f - a * a) + alpha * invB * 2.f * a;
+      const float gsig = gz * eps - alpha * invB / sg;
+      s_dy[r * ld_y + d] = ok ? gz : 0.f;                              // d/dloc
+      s_dy[r * ld_y + U + d] = ok ? gsig * sigmoid_f(raw) : 0.f;       // d/draw = d/dsigma * softplus'(raw)
+    }
+    __syncthreads();
+    float *slab = A.slab_pi + (long long)tile * A.pi.n_params;
+    mlp_backward_tile<H>(A.pi, 1, s_sn, 0, ld_x, zp, hp, ld_h, s_dy, ld_y, s_pp_a, s_pp_b, slab, nullptr, wave, NW, lane, tid,
+                         nthreads);
+    if (tid == 0) {
+      float al = 0.f, ac = 0.f;
+      for (int i = 0; i < 16; ++i) {
+        al += s_scal[i];
+        ac += s_scal[32 + i];
+      }
+      A.slab_ex[tile * 4 + 1] = ac;
+      A.slab_ex[tile * 4 + 2] = al;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct SacReduceArgs {
+  const float *slab_pi, *slab_q, *slab_ex;
+  int n_tiles, P, Q2, B;
+  float *grads, *metrics, *ss_part, *step_count;
+};
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// sum-of-squares partials per workgroup and optimizer group (0 policy, 1 critics, 2 alpha), fixed order
+__device__ __forceinline__ void group_sumsq(float g, int i, int P, int Q2, int NP, float *ss_part) {
+  __shared__ float s_ss[3][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float gg = (i < NP) ? g * g : 0.f;
+  const int grp = (i < P) ? 0 : (i < P + Q2 ? 1 : 2);
+  float v0 = wave_sum64(grp == 0 ? gg : 0.f), v1 = wave_sum64(grp == 1 ? gg : 0.f), v2 = wave_sum64(grp == 2 ? gg : 0.f);
+  if (lane == 0) {
+    s_ss[0][wave] = v0;
+    s_ss[1][wave] = v1;
+    s_ss[2][wave] = v2;
+  }
+  __syncthreads();
+  if (tid < 3) ss_part[blockIdx.x * 3 + tid] = s_ss[tid][0] + s_ss[tid][1] + s_ss[tid][2] + s_ss[tid][3];
+}
+
+__global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
+  const int NP = A.P + A.Q2 + 1;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float g = 0.f;
+  if (i < A.P) {
+    for (int t = 0; t < A.n_tiles; ++t) g += A.slab_pi[(long long)t * A.P + i];
+  } else if (i < A.P + A.Q2) {
+    const int j = i - A.P;
+    for (int t = 0; t < A.n_tiles; ++t) g += A.slab_q[(long long)t * A.Q2 + j];
+  } else if (i == NP - 1) {
+    float ce = 0.f, ac = 0.f, al = 0.f;
+    for (int t = 0; t < A.n_tiles; ++t) {
+      ce += A.slab_ex[t * 4 + 0];
+      ac += A.slab_ex[t * 4 + 1];
+      al += A.slab_ex[t * 4 + 2];
+    }
+    const float invB = 1.0f / (float)A.B;
+    g = al * invB;                          // d alpha_loss / d log_alpha
+    A.metrics[0] = 0.5f * ce * (0.5f * invB);  // critic_loss = 0.5 * mean over [B,2]
+    A.metrics[1] = ac * invB;
+    A.metrics[2] = al * invB;
+    A.step_count[0] = A.step_count[0] + 1.0f;  // optimizer count (read by apply; fwd_bwd of this step already ran)
+  }
+  if (i < NP) A.grads[i] = g;
+  group_sumsq(g, i, A.P, A.Q2, NP, A.ss_part);
+}
+
+__global__ void __launch_bounds__(256) k_sac_sumsq(const float *grads, int P, int Q2, float *ss_part) {
+  const int NP = P + Q2 + 1;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float g = i < NP ? grads[i] : 0.f;
+  group_sumsq(g, i, P, Q2, NP, ss_part);
+}
+
+struct SacApplyArgs {
+  float *params, *target_q, *adam_m, *adam_v, *grads, *metrics;
+  const float *step_count, *ss_part;
+  int n_parts, P, Q2;
+  float lr[3], wd[3];
+  float max_norm, tau, one_minus_tau, grad_scale;
+};
+
+__global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
+  __shared__ float s_scale[3];
+  const int tid = threadIdx.x;
+  if (tid < 3) {
+    float ss = 0.f;
+    for (int p = 0; p < A.n_parts; ++p) ss += A.ss_part[p * 3 + tid];
+    // [3P optax.clip_by_global_norm] g_norm = sqrt(sum g^2); g <- g if g_norm < max_norm else (g / g_norm) * max_norm
+    const float gnorm = sqrtf(ss) * A.grad_scale;
+    s_scale[tid] = gnorm;
+  }
+  __syncthreads();
+  const int NP = A.P + A.Q2 + 1;
+  const int i = blockIdx.x * 256 + tid;
+  if (i >= NP) return;
+  const int grp = (i < A.P) ? 0 : (i < A.P + A.Q2 ? 1 : 2);
+  const float gnorm = s_scale[grp];
+  float g = A.grads[i] * A.grad_scale;
+  if (!(gnorm < A.max_norm)) g = (g / gnorm) * A.max_norm;
+  // [3P optax.adamw] scale_by_adam(b1=.9,b2=.999,eps=1e-8) -> add_decayed_weights(wd) -> scale(-lr)
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+  const float count = A.step_count[0];  // already incremented for this step
+  // optax forms (1 - decay) in Python double and only then casts: f32(0.1), f32(0.001) — not 1.f - 0.999f
+  const float mu = b1 * A.adam_m[i] + 0.1f * g;
+  const float nu = b2 * A.adam_v[i] + 0.001f * (g * g);
+  A.adam_m[i] = mu;
+  A.adam_v[i] = nu;
+  const float mu_hat = mu / (1.f - powf(b1, count));
+  const float nu_hat = nu / (1.f - powf(b2, count));
+  float upd = mu_hat / (sqrtf(nu_hat) + eps);
+  const float p = A.params[i];
+  upd = upd + A.wd[grp] * p;
+  const float pn = p + (-A.lr[grp]) * upd;  // optax.apply_updates: p + u, u = -lr * upd
+  A.params[i] = pn;
+  if (grp == 1) {
+    const int j = i - A.P;
+    A.target_q[j] = A.target_q[j] * A.one_minus_tau + pn * A.tau;   // sac.py:260-261 ((1 - tau) formed in double on the host)
+  } else if (grp == 2) {
+    A.metrics[3] = expf(pn);                                      // 'alpha': exp(alpha_params) (sac.py:267)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct SacPlan {
+  MlpDev pi, q, qt;
+  int P, Q, NP, n_tiles, H, LH, n_red;
+  size_t lds;
+  int ld_x, ld_xu, ld_h, ld_y;
+  // workspace offsets (floats)
+  long long off_slab_pi, off_slab_q, off_slab_ex, off_ss, total;
+};
+
+static int same_hidden(const int *dims, int n_layers) {
+  if (n_layers < 2) return -1;
+  for (int l = 2; l < n_layers; ++l)
+    if (dims[l] != dims[1]) return -1;
+  return dims[1];
+}
+
+static int sac_plan(const mbpo_sac_desc *d, SacPlan *pl, bool need_ptrs) {
+  MBPO_REQUIRE(d, MBPO_ERR_ARG, "sac: null descriptor");
+  MBPO_REQUIRE(d->x_dim > 0 && d->u_dim > 0 && d->batch_size > 0, MBPO_ERR_ARG, "sac: x_dim/u_dim/batch_size must be positive");
+  MBPO_REQUIRE(d->row_len == 2 * d->x_dim + d->u_dim + 3, MBPO_ERR_ARG, "sac: row_len %d != 2x+u+3", d->row_len);
+  MBPO_REQUIRE(d->policy_layers >= 2 && d->policy_layers <= MBPO_MAX_LAYERS && d->q_layers >= 2 && d->q_layers <= MBPO_MAX_LAYERS,
+               MBPO_ERR_ARG, "sac: networks need at least one hidden layer and at most %d Dense layers", MBPO_MAX_LAYERS);
+  MBPO_REQUIRE(d->policy_dims[0] == d->x_dim && d->policy_dims[d->policy_layers] == 2 * d->u_dim, MBPO_ERR_ARG,
+               "sac: policy must map [x_dim] -> [2*u_dim]");
+  MBPO_REQUIRE(d->q_dims[0] == d->x_dim + d->u_dim && d->q_dims[d->q_layers] == 1, MBPO_ERR_ARG,
+               "sac: critic must map [x_dim+u_dim] -> [1]");
+  const int Hp = same_hidden(d->policy_dims, d->policy_layers), Hq = same_hidden(d->q_dims, d->q_layers);
+  MBPO_REQUIRE(Hp == Hq && (Hp == 64 || Hp == 128), MBPO_ERR_UNSUPPORTED,
+               "sac: policy and critic hidden layers must share one width in {64,128} (got %d, %d)", Hp, Hq);
+  mbpo_mlp_desc md;
+  md.net_stride = 0;
+  // policy
+  md.params = d->params ? d->params : (const float *)16;  // placeholder for size queries
+  md.n_nets = 1;
+  md.n_layers = d->policy_layers;
+  for (int l = 0; l <= d->policy_layers; ++l) md.dims[l] = d->policy_dims[l];
+  md.activation = d->policy_activation;
+  int rc = mbpo_make_mlp_dev(&md, &pl->pi, "sac.policy");
+  if (rc != MBPO_OK) return rc;
+  pl->P = pl->pi.n_params;
+  // critics
+  md.n_layers = d->q_layers;
+  for (int l = 0; l <= d->q_layers; ++l) md.dims[l] = d->q_dims[l];
+  md.activation = d->q_activation;
+  md.n_nets = 1;
+  rc = mbpo_make_mlp_dev(&md, &pl->q, "sac.q");
+  if (rc != MBPO_OK) return rc;
+  pl->Q = pl->q.n_params;
+  pl->q.n_nets = 2;
+  pl->q.net_stride = pl->Q;
+  pl->q.params = d->params ? d->params + pl->P : nullptr;
+  pl->qt = pl->q;
+  pl->qt.params = d->target_q;
+  pl->NP = pl->P + 2 * pl->Q + 1;
+  pl->H = Hp;
+  const int lhp = d->policy_layers - 1, lhq = d->q_layers - 1;
+  pl->LH = lhp > lhq ? lhp : lhq;
+  pl->n_tiles = (d->batch_size + 15) / 16;
+  pl->n_red = (pl->NP + 255) / 256;
+  pl->ld_x = d->x_dim | 1;
+  pl->ld_xu = (d->x_dim + d->u_dim) | 1;
+  pl->ld_h = Hp + 1;
+  pl->ld_y = (2 * d->u_dim) | 1;
+  const int U = d->u_dim;
+  size_t f = 16ull * d->row_len + 2ull * 16 * pl->ld_x + 2ull * 16 * pl->ld_xu + 4ull * 16 * pl->ld_h +
+             (size_t)pl->LH * 4 * 16 * pl->ld_h + 4ull * 16 * pl->ld_y + 2ull * 16 * pl->ld_xu + 6ull * 16 * U + 64;
+  pl->lds = f * sizeof(float);
+  pl->off_slab_pi = 0;
+  pl->off_slab_q = pl->off_slab_pi + (long long)pl->n_tiles * pl->P;
+  pl->off_slab_ex = pl->off_slab_q + (long long)pl->n_tiles * 2 * pl->Q;
+  pl->off_ss = pl->off_slab_ex + (long long)pl->n_tiles * 4;
+  pl->total = pl->off_ss + (long long)pl->n_red * 3;
+  if (need_ptrs) {
+    MBPO_REQUIRE(d->params && d->target_q && d->adam_m && d->adam_v && d->step_count && d->grads && d->workspace && d->metrics,
+                 MBPO_ERR_ARG, "sac: null state pointer");
+  }
+  return MBPO_OK;
+}
+
+extern "C" int64_t mbpo_sac_workspace_floats(const mbpo_sac_desc *d) {
+  SacPlan pl;
+  int rc = sac_plan(d, &pl, false);
+  if (rc != MBPO_OK) return rc;
+  return pl.total;
+}
+
+extern "C" int mbpo_sac_grads(const mbpo_sac_desc *d, void *stream) {
+  SacPlan pl;
+  int rc = sac_plan(d, &pl, true);
+  if (rc != MBPO_OK) return rc;
+  MBPO_REQUIRE(d->batch, MBPO_ERR_ARG, "sac_grads: null batch");
+  MBPO_REQUIRE((d->norm_mean == nullptr) == (d->norm_std == nullptr), MBPO_ERR_ARG, "sac_grads: norm_mean/norm_std mismatch");
+  MBPO_REQUIRE(pl.lds <= 160 * 1024, MBPO_ERR_UNSUPPORTED, "sac_grads: needs %zu B of LDS (> 160 KiB)", pl.lds);
+  SacArgs A;
+  A.pi = pl.pi; A.q = pl.q; A.qt = pl.qt;
+  A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.D = d->row_len;
+  A.batch = d->batch; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std;
+  A.log_alpha = d->params + pl.NP - 1;
+  A.noise_alpha = d->noise_alpha; A.noise_critic = d->noise_critic; A.noise_actor = d->noise_actor;
+  A.seed = d->seed; A.offset = d->offset; A.step_count = d->step_count;
+  A.discounting = d->discounting; A.reward_scaling = d->reward_scaling; A.target_entropy = d->target_entropy;
+  A.slab_pi = d->workspace + pl.off_slab_pi; A.slab_q = d->workspace + pl.off_slab_q; A.slab_ex = d->workspace + pl.off_slab_ex;
+  A.ld_x = pl.ld_x; A.ld_xu = pl.ld_xu; A.ld_h = pl.ld_h; A.ld_y = pl.ld_y; A.LH = pl.LH;
+  hipStream_t st = (hipStream_t)stream;
+  if (pl.H == 64) {
+    if (pl.lds > 48 * 1024) hipFuncSetAttribute((const void *)k_sac_fwd_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    hipLaunchKernelGGL(k_sac_fwd_bwd<64>, dim3(2 * pl.n_tiles), dim3(256), pl.lds, st, A);
+  } else {
+    if (pl.lds > 48 * 1024) hipFuncSetAttribute((const void *)k_sac_fwd_bwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    hipLaunchKernelGGL(k_sac_fwd_bwd<128>, dim3(2 * pl.n_tiles), dim3(512), pl.lds, st, A);
+  }
+  SacReduceArgs R;
+  R.slab_pi = A.slab_pi; R.slab_q = A.slab_q; R.slab_ex = A.slab_ex;
+  R.n_tiles = pl.n_tiles; R.P = pl.P; R.Q2 = 2 * pl.Q; R.B = d->batch_size;
+  R.grads = d->grads; R.metrics = d->metrics; R.ss_part = d->workspace + pl.off_ss; R.step_count = d->step_count;
+  hipLaunchKernelGGL(k_sac_reduce, dim3(pl.n_red), dim3(256), 0, st, R);
+  MBPO_CHECK_LAUNCH("sac_grads");
+  return MBPO_OK;
+}
+
+extern "C" int mbpo_sac_grad_norms(const mbpo_sac_desc *d, void *stream) {
+  SacPlan pl;
+  int rc = sac_plan(d, &pl, true);
+  if (rc != MBPO_OK) return rc;
+  hipLaunchKernelGGL(k_sac_sumsq, dim3(pl.n_red), dim3(256), 0, (hipStream_t)stream, (const float *)d->grads, pl.P, 2 * pl.Q,
+                     d->workspace + pl.off_ss);
+  MBPO_CHECK_LAUNCH("sac_grad_norms");
+  return MBPO_OK;
+}
+
+extern "C" int mbpo_sac_apply(const mbpo_sac_desc *d, void *stream) {
+  SacPlan pl;
+  int rc = sac_plan(d, &pl, true);
+  if (rc != MBPO_OK) return rc;
+  SacApplyArgs A;
+  A.params = d->params; A.target_q = d->target_q; A.adam_m = d->adam_m; A.adam_v = d->adam_v; A.grads = d->grads;
+  A.metrics = d->metrics; A.step_count = d->step_count; A.ss_part = d->workspace + pl.off_ss;
+  A.n_parts = pl.n_red; A.P = pl.P; A.Q2 = 2 * pl.Q;
+  A.lr[0] = d->lr_policy; A.lr[1] = d->lr_q; A.lr[2] = d->lr_alpha;
+  A.wd[0] = d->wd_policy; A.wd[1] = d->wd_q; A.wd[2] = d->wd_alpha;
+  A.max_norm = d->max_grad_norm; A.tau = d->tau; A.one_minus_tau = (float)(1.0 - (double)d->tau); A.grad_scale = d->grad_scale;
+  hipLaunchKernelGGL(k_sac_apply, dim3(pl.n_red), dim3(256), 0, (hipStream_t)stream, A);
+  MBPO_CHECK_LAUNCH("sac_apply");
+  return MBPO_OK;
+}

@@ -74,6 +74,26 @@ class RolloutDesc(C.Structure):
     ]
 
 
+class SacDesc(C.Structure):
+    _fields_ = [
+        ("x_dim", C.c_int32), ("u_dim", C.c_int32),
+        ("policy_layers", C.c_int32), ("policy_dims", C.c_int32 * (MBPO_MAX_LAYERS + 1)),
+        ("q_layers", C.c_int32), ("q_dims", C.c_int32 * (MBPO_MAX_LAYERS + 1)),
+        ("policy_activation", C.c_int32), ("q_activation", C.c_int32),
+        ("params", C.c_void_p), ("target_q", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
+        ("step_count", C.c_void_p), ("grads", C.c_void_p),
+        ("workspace", C.c_void_p), ("metrics", C.c_void_p),
+        ("batch", C.c_void_p), ("batch_size", C.c_int32), ("row_len", C.c_int32),
+        ("norm_mean", C.c_void_p), ("norm_std", C.c_void_p),
+        ("noise_alpha", C.c_void_p), ("noise_critic", C.c_void_p), ("noise_actor", C.c_void_p),
+        ("seed", C.c_uint64), ("offset", C.c_uint64),
+        ("discounting", C.c_float), ("reward_scaling", C.c_float), ("target_entropy", C.c_float), ("tau", C.c_float),
+        ("lr_policy", C.c_float), ("lr_q", C.c_float), ("lr_alpha", C.c_float),
+        ("wd_policy", C.c_float), ("wd_q", C.c_float), ("wd_alpha", C.c_float), ("max_grad_norm", C.c_float),
+        ("grad_scale", C.c_float),
+    ]
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -122,6 +142,15 @@ def _bind_optional(lib: C.CDLL) -> None:
         if fn is not None:
             fn.restype = C.c_int
             fn.argtypes = argtypes
+    for name in ("mbpo_sac_grads", "mbpo_sac_grad_norms", "mbpo_sac_apply"):
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = C.c_int
+            fn.argtypes = [C.POINTER(SacDesc), vp]
+    fn = getattr(lib, "mbpo_sac_workspace_floats", None)
+    if fn is not None:
+        fn.restype = C.c_int64
+        fn.argtypes = [C.POINTER(SacDesc)]
 
 
 def check(rc: int, what: str) -> None:

@@ -224,3 +224,96 @@ def lambda_return_scan(rewards, next_values, gamma: float, lam: float, time_majo
     check(lib.mbpo_lambda_return_scan(rewards.data_ptr(), next_values.data_ptr(), out.data_ptr(), B, T, gamma, lam,
                                       int(time_major), current_stream_ptr()), "mbpo_lambda_return_scan")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ SAC sgd_step (S3-S8)
+class SacUpdater:
+    """Owns the flat SAC train state on one GPU and drives mbpo_sac_grads / _grad_norms / _apply.
+
+    Flat layout (include/mbpo_hip.h): params = [policy | critic0 | critic1 | log_alpha]; target_q; adam m/v; step count.
+    `all_reduce(t)`, when given, must SUM `t` over ranks in place (torch.distributed.all_reduce) — it is called on the
+    flat gradient between grads and apply, the position of the reference's jax.lax.pmean (sac/utils.py:29-33).
+    """
+
+    def __init__(self, *, x_dim: int, u_dim: int, policy_dims: Sequence[int], q_dims: Sequence[int], batch_size: int,
+                 device, policy_activation: str = "swish", q_activation: str = "swish", discounting: float = 0.9,
+                 reward_scaling: float = 1.0, target_entropy: Optional[float] = None, tau: float = 0.005,
+                 lr_policy: float = 1e-4, lr_q: float = 1e-4, lr_alpha: float = 1e-4, wd_policy: float = 0.0,
+                 wd_q: float = 0.0, wd_alpha: float = 0.0, max_grad_norm: float = 1e5, seed: int = 0,
+                 all_reduce=None, world_size: int = 1):
+        self.lib = load()
+        self.x_dim, self.u_dim, self.batch_size = x_dim, u_dim, batch_size
+        self.policy_spec = MlpSpec(list(policy_dims), policy_activation, 1)
+        self.q_spec = MlpSpec(list(q_dims), q_activation, 2)
+        self.P, self.Q = self.policy_spec.n_params, self.q_spec.n_params
+        self.NP = self.P + 2 * self.Q + 1
+        self.device = torch.device(device)
+        f = lambda n: torch.zeros(n, device=self.device, dtype=torch.float32)
+        self.params, self.target_q, self.adam_m, self.adam_v = f(self.NP), f(2 * self.Q), f(self.NP), f(self.NP)
+        self.step_count, self.grads, self.metrics = f(1), f(self.NP), f(4)
+        self.all_reduce, self.world_size = all_reduce, world_size
+        d = _hip.SacDesc()
+        d.x_dim, d.u_dim = x_dim, u_dim
+        d.policy_layers, d.q_layers = len(policy_dims) - 1, len(q_dims) - 1
+        for i, v in enumerate(policy_dims):
+            d.policy_dims[i] = int(v)
+        for i, v in enumerate(q_dims):
+            d.q_dims[i] = int(v)
+        d.policy_activation, d.q_activation = _hip.ACT_IDS[policy_activation], _hip.ACT_IDS[q_activation]
+        d.batch_size, d.row_len = batch_size, transition_row_len(x_dim, u_dim)
+        d.discounting, d.reward_scaling, d.tau = discounting, reward_scaling, tau
+        d.target_entropy = -0.5 * u_dim if target_entropy is None else target_entropy      # losses.py:49-50
+        d.lr_policy, d.lr_q, d.lr_alpha = lr_policy, lr_q, lr_alpha
+        d.wd_policy, d.wd_q, d.wd_alpha, d.max_grad_norm = wd_policy, wd_q, wd_alpha, max_grad_norm
+        d.grad_scale = 1.0 / world_size
+        d.seed, d.offset = seed, 0
+        nws = self.lib.mbpo_sac_workspace_floats(C.byref(d))
+        if nws < 0:
+            check(int(nws), "mbpo_sac_workspace_floats")
+        self.workspace = f(int(nws))
+        d.params, d.target_q, d.adam_m, d.adam_v = (t.data_ptr() for t in (self.params, self.target_q, self.adam_m, self.adam_v))
+        d.step_count, d.grads, d.workspace, d.metrics = (t.data_ptr() for t in (self.step_count, self.grads, self.workspace, self.metrics))
+        self.desc = d
+
+    # views into the flat state
+    @property
+    def policy_params(self) -> torch.Tensor:
+        return self.params[:self.P]
+
+    @property
+    def q_params(self) -> torch.Tensor:
+        return self.params[self.P:self.P + 2 * self.Q]
+
+    @property
+    def log_alpha(self) -> torch.Tensor:
+        return self.params[self.NP - 1:]
+
+    def load_state(self, params, target_q=None, adam_m=None, adam_v=None, count: float = 0.0):
+        self.params.copy_(params)
+        self.target_q.copy_(self.params[self.P:self.P + 2 * self.Q] if target_q is None else target_q)
+        self.adam_m.zero_() if adam_m is None else self.adam_m.copy_(adam_m)
+        self.adam_v.zero_() if adam_v is None else self.adam_v.copy_(adam_v)
+        self.step_count.fill_(count)
+
+    def sgd_step(self, batch: torch.Tensor, norm_mean=None, norm_std=None, noise_alpha=None, noise_critic=None,
+                 noise_actor=None, offset: int = 0) -> None:
+        """One SAC.sgd_step (sac/sac.py:227-281) on `batch` [B, 2x+u+3]; metrics land in self.metrics (device)."""
+        _req(batch, "batch")
+        if batch.shape != (self.batch_size, self.desc.row_len):
+            raise ValueError(f"batch must be [{self.batch_size},{self.desc.row_len}], got {tuple(batch.shape)}")
+        d = self.desc
+        d.batch = batch.data_ptr()
+        d.norm_mean, d.norm_std = ptr(norm_mean), ptr(norm_std)
+        for t, nm in ((noise_alpha, "noise_alpha"), (noise_critic, "noise_critic"), (noise_actor, "noise_actor")):
+            if t is not None:
+                _req(t, nm)
+                if t.numel() != self.batch_size * self.u_dim:
+                    raise ValueError(f"{nm} must be [B,u]")
+        d.noise_alpha, d.noise_critic, d.noise_actor = ptr(noise_alpha), ptr(noise_critic), ptr(noise_actor)
+        d.offset = offset
+        st = current_stream_ptr()
+        check(self.lib.mbpo_sac_grads(C.byref(d), st), "mbpo_sac_grads")
+        if self.all_reduce is not None:
+            self.all_reduce(self.grads)
+            check(self.lib.mbpo_sac_grad_norms(C.byref(d), st), "mbpo_sac_grad_norms")
+        check(self.lib.mbpo_sac_apply(C.byref(d), st), "mbpo_sac_apply")

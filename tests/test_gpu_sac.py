@@ -1,0 +1,158 @@
+"""GPU parity: SAC sgd_step (S3-S8) — hand-written HIP forward/backward + clip/AdamW/Polyak vs torch-autograd oracle.
+
+Tolerance (fp32): flat gradients agree to atol 2e-6 + rtol 2e-4 against the fp32 oracle and atol 2e-6 + rtol 1e-4 against the
+fp64 oracle (gradient magnitudes are O(1e-3..1)); after one optimizer step parameters agree to 2e-6 absolute
+(lr*O(1) updates); after 20 chained steps to 2e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as onets
+from oracle import sac as osac
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(X, U, hidden, B, seed, normalize, trunc_p=0.2, **cfgkw):
+    g = torch.Generator().manual_seed(seed)
+    cfg = osac.SacConfig(x_dim=X, u_dim=U, policy_dims=[X, *hidden, 2 * U], q_dims=[X + U, *hidden, 1], **cfgkw)
+    st = osac.init_state(cfg, g, init_log_alpha=-0.3)
+    st.params = st.params + 0.03 * torch.randn(st.params.shape, generator=g)      # non-zero biases
+    st.target_q = st.params[cfg.P:cfg.P + 2 * cfg.Q] + 0.02 * torch.randn(2 * cfg.Q, generator=g)
+    D = 2 * X + U + 3
+    batch = torch.randn(B, D, generator=g)
+    batch[:, X:X + U] = torch.tanh(batch[:, X:X + U])
+    batch[:, X + U + 1] = (torch.rand(B, generator=g) > 0.1).float()      # discount
+    batch[:, D - 1] = (torch.rand(B, generator=g) < trunc_p).float()      # truncation
+    noise = [torch.randn(B, U, generator=g) for _ in range(3)]
+    nm = torch.randn(X, generator=g) * 0.3 if normalize else None
+    ns = torch.rand(X, generator=g) + 0.5 if normalize else None
+    return cfg, st, batch, noise, nm, ns
+
+
+def _updater(dev, cfg, B, **kw):
+    from mbpo import ops
+    return ops.SacUpdater(x_dim=cfg.x_dim, u_dim=cfg.u_dim, policy_dims=cfg.policy_dims, q_dims=cfg.q_dims, batch_size=B,
+                          device=dev, discounting=cfg.discounting, reward_scaling=cfg.reward_scaling,
+                          target_entropy=cfg.target_entropy, tau=cfg.tau, lr_policy=cfg.lr_policy, lr_q=cfg.lr_q,
+                          lr_alpha=cfg.lr_alpha, wd_policy=cfg.wd_policy, wd_q=cfg.wd_q, wd_alpha=cfg.wd_alpha,
+                          max_grad_norm=cfg.max_grad_norm, **kw)
+
+
+@pytest.mark.parametrize("X,U,hidden,B,normalize", [
+    (4, 1, (64, 64, 64), 256, False),     # BASELINE config 2 networks (defaults sac.py:84-88)
+    (3, 1, (64, 64, 64), 256, True),
+    (3, 1, (128, 128, 128), 64, True),    # reference test config (tests/test_sac.py:30-57)
+    (4, 1, (64, 64), 32, False),          # exp.py-like B=32
+    (17, 6, (64, 64, 64), 48, True),      # config 5 shape
+    (4, 2, (64, 64, 64), 40, False),      # ragged: B not a multiple of 16
+])
+def test_sac_gradients_and_step(dev, X, U, hidden, B, normalize):
+    cfg, st, batch, noise, nm, ns = _make(X, U, hidden, B, 0, normalize, discounting=0.99, reward_scaling=1.5,
+                                           lr_policy=3e-4, lr_q=3e-4, lr_alpha=3e-4, wd_q=1e-3)
+    g_ref, (cl, ac, al) = osac.grads(cfg, st.params, st.target_q, batch, *noise, nm, ns)
+    to64 = lambda t: None if t is None else t.double()
+    g_ref64, (cl64, ac64, al64) = osac.grads(cfg, st.params.double(), st.target_q.double(), batch.double(),
+                                             *[n.double() for n in noise], to64(nm), to64(ns))
+    up = _updater(dev, cfg, B)
+    up.load_state(st.params.to(dev), st.target_q.to(dev))
+    d = lambda t: None if t is None else t.to(dev)
+    up.sgd_step(batch.to(dev), d(nm), d(ns), *[n.to(dev) for n in noise])
+    torch.cuda.synchronize()
+    g = up.grads.cpu()
+    # optimizer parity is checked GIVEN the device gradient: Adam's first step g/(|g|+eps) turns a 1e-9 difference on a
+    # near-zero gradient element into an O(lr) parameter difference, which says nothing about either implementation
+    st_new, met, _ = osac.sgd_step(cfg, st, batch, *noise, nm, ns, grad_override=g)
+    P, Q = cfg.P, cfg.Q
+    for name, sl in (("policy", slice(0, P)), ("critic", slice(P, P + 2 * Q)), ("alpha", slice(P + 2 * Q, None))):
+        torch.testing.assert_close(g[sl], g_ref[sl], atol=2e-6, rtol=2e-4, msg=lambda m: f"{name} grad vs fp32 oracle: {m}")
+        torch.testing.assert_close(g[sl].double(), g_ref64[sl], atol=2e-6, rtol=1e-4,
+                                   msg=lambda m: f"{name} grad vs fp64 oracle: {m}")
+    m = up.metrics.cpu().tolist()
+    np.testing.assert_allclose(m[:3], [cl64, ac64, al64], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(m[3], met["alpha"], rtol=1e-6)
+    torch.testing.assert_close(up.params.cpu(), st_new.params, atol=1e-7, rtol=1e-6)
+    torch.testing.assert_close(up.target_q.cpu(), st_new.target_q, atol=1e-7, rtol=1e-6)
+    torch.testing.assert_close(up.adam_m.cpu(), st_new.adam_m, atol=1e-9, rtol=1e-5)
+    torch.testing.assert_close(up.adam_v.cpu(), st_new.adam_v, atol=1e-12, rtol=1e-5)
+    assert float(up.step_count.cpu()) == 1.0
+
+
+def test_sac_clip_triggers(dev):
+    """max_grad_norm small enough to clip every group (the reference default 1e5 never does)."""
+    cfg, st, batch, noise, nm, ns = _make(4, 1, (64, 64, 64), 64, 1, False, max_grad_norm=1e-3, lr_policy=1e-3, lr_q=1e-3,
+                                           lr_alpha=1e-3)
+    up = _updater(dev, cfg, 64)
+    up.load_state(st.params.to(dev), st.target_q.to(dev))
+    up.sgd_step(batch.to(dev), None, None, *[n.to(dev) for n in noise])
+    g = up.grads.cpu()
+    for sl in (slice(0, cfg.P), slice(cfg.P, cfg.P + 2 * cfg.Q), slice(cfg.P + 2 * cfg.Q, None)):
+        assert float(torch.sqrt((g[sl] ** 2).sum())) > 1e-3          # every group really clips
+    st_new, _, _ = osac.sgd_step(cfg, st, batch, *noise, grad_override=g)
+    torch.testing.assert_close(up.params.cpu(), st_new.params, atol=1e-7, rtol=1e-6)
+    torch.testing.assert_close(up.adam_m.cpu(), st_new.adam_m, atol=1e-10, rtol=1e-5)
+
+
+def test_sac_all_truncated_rows_give_zero_critic_grad(dev):
+    cfg, st, batch, noise, nm, ns = _make(3, 1, (64, 64, 64), 32, 2, False, trunc_p=1.1)
+    up = _updater(dev, cfg, 32)
+    up.load_state(st.params.to(dev), st.target_q.to(dev))
+    up.sgd_step(batch.to(dev), None, None, *[n.to(dev) for n in noise])
+    g = up.grads.cpu()
+    assert torch.count_nonzero(g[cfg.P:cfg.P + 2 * cfg.Q]) == 0
+    assert float(up.metrics.cpu()[0]) == 0.0
+
+
+def test_sac_chained_steps(dev):
+    """20 chained sgd_steps (fresh minibatch + noise each) against the independent oracle trajectory: relative L2
+    distance of the parameter vectors < 1e-3 and loss metrics within 1e-3 (element-wise closeness is not meaningful:
+    Adam's g/(sqrt(v)+eps) amplifies rounding on near-zero-gradient elements)."""
+    X, U, B = 4, 1, 64
+    cfg, st, _, _, _, _ = _make(X, U, (64, 64, 64), B, 3, False, lr_policy=1e-3, lr_q=1e-3, lr_alpha=1e-3, discounting=0.95)
+    up = _updater(dev, cfg, B)
+    up.load_state(st.params.to(dev), st.target_q.to(dev))
+    g = torch.Generator().manual_seed(11)
+    D = 2 * X + U + 3
+    for k in range(20):
+        batch = torch.randn(B, D, generator=g)
+        batch[:, X + U + 1] = 1.0
+        batch[:, D - 1] = (torch.rand(B, generator=g) < 0.2).float()
+        noise = [torch.randn(B, U, generator=g) for _ in range(3)]
+        st, met, _ = osac.sgd_step(cfg, st, batch, *noise)
+        up.sgd_step(batch.to(dev), None, None, *[n.to(dev) for n in noise])
+        m = up.metrics.cpu().tolist()
+        np.testing.assert_allclose(m, [met["critic_loss"], met["actor_loss"], met["alpha_loss"], met["alpha"]],
+                                   rtol=1e-3, atol=1e-3)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(up.params.cpu(), st.params) < 1e-3
+    assert rel(up.target_q.cpu(), st.target_q) < 1e-3
+    assert float(up.step_count.cpu()) == 20.0
+
+
+def test_sac_philox_noise_path(dev):
+    """NULL noise pointers -> device Philox; must equal feeding oracle/philox.py draws explicitly."""
+    from oracle import philox
+    cfg, st, batch, _, _, _ = _make(4, 1, (64, 64, 64), 64, 4, False)
+    seed, offset, B, U = 777, 13, 64, 1
+    idx = np.arange(B * U, dtype=np.uint64)
+    noise = [torch.from_numpy(philox.philox_normal(seed, offset, s, idx)).reshape(B, U)
+             for s in (philox.STREAM_SAC_ALPHA, philox.STREAM_SAC_CRITIC, philox.STREAM_SAC_ACTOR)]
+    outs = []
+    for explicit in (True, False):
+        up = _updater(dev, cfg, B, seed=seed)
+        up.load_state(st.params.to(dev), st.target_q.to(dev))
+        if explicit:
+            up.sgd_step(batch.to(dev), None, None, *[n.to(dev) for n in noise])
+        else:
+            up.sgd_step(batch.to(dev), offset=offset)
+        outs.append(up.grads.cpu())
+    torch.testing.assert_close(outs[0], outs[1], atol=1e-6, rtol=1e-4)
+
+
+def test_sac_bad_args(dev):
+    from mbpo import ops, _hip
+    with pytest.raises(_hip.MbpoHipError):
+        ops.SacUpdater(x_dim=3, u_dim=1, policy_dims=[3, 64, 32, 2], q_dims=[4, 64, 32, 1], batch_size=32, device=dev)
+    with pytest.raises(_hip.MbpoHipError):
+        ops.SacUpdater(x_dim=3, u_dim=1, policy_dims=[3, 256, 256, 2], q_dims=[4, 256, 256, 1], batch_size=32, device=dev)
