@@ -1,0 +1,278 @@
+#!/usr/bin/env python
+"""bench.py — MBPO inner loop on MI355X: model-rollout transitions/s (+ SAC updates/s).
+
+Workload = BASELINE.json configs[1] ("Pendulum SAC-MBPO, 4096 parallel envs, 5-ens, horizon-5 rollouts, 1xMI355X") with
+the north_star's obs/act shape: x=4, u=1, 5-member ensemble [5->64->64->64->8] swish, policy/twin-Q 64x3 swish,
+N=4096 envs PER GPU, episode_length=5, num_env_steps_between_updates S=5, batch_size B=256 per GPU,
+grad_updates_per_step G=64, normalize_observations=True, synthetic data, random-init weights.
+
+One "step" = one SAC.training_step (sac/sac.py:306-327): fused rollout of S*N transitions + running statistics +
+replay insert + sample of B*G rows + G sgd_steps (each: fwd/bwd of the three losses, [all-reduce,] clip+AdamW+Polyak).
+value = transitions written per second by the whole job = n_gpus * N * S * steps / time  (weak scaling: per-GPU work fixed).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "model-based-policy-optimizers_amd"))
+
+import torch  # noqa: E402
+
+X_DIM, U_DIM, N_MEMBERS = 4, 1, 5
+HIDDEN = (64, 64, 64)
+N_ENVS, EPISODE_LEN, S_STEPS, BATCH, GRAD_UPDATES = 4096, 5, 5, 256, 64
+MAX_REPLAY = 2 ** 20
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak (spec)
+
+
+def mlp_macs(dims):
+    return sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+
+
+def build_trainer(device, process_group, use_graph):
+    from mbpo.optimizers.policy_optimizers.sac.sac import SAC
+    from mbpo.replay import UniformSamplingQueue
+    from mbpo.systems import EnsembleDynamics, EnsembleSystem, QuadraticReward
+    from mbpo.systems.brax_wrapper import BraxWrapper
+    from mbpo.types import Transition
+
+    dyn = EnsembleDynamics(X_DIM, U_DIM, n_members=N_MEMBERS, hidden_layer_sizes=HIDDEN, device=device)
+    system = EnsembleSystem(dyn, QuadraticReward(X_DIM, U_DIM), mode="mean", predict_delta=True)
+    sys_params = system.init_params(1)
+    # damp the random ensemble so 5-step rollouts stay O(1) (random-init lecun nets are ~unit gain)
+    sys_params.dynamics_params.params.mul_(0.5)
+    # synthetic TRUE buffer: 2^16 rows of (obs, act, reward, discount, next_obs)  
+    g = torch.Generator().manual_seed(0)
+    n_true = 2 ** 16
+    th = (torch.rand(n_true, generator=g) * 2 - 1) * 3.14159265
+    obs = torch.stack([torch.cos(th), torch.sin(th), (torch.rand(n_true, generator=g) * 2 - 1) * 8,
+                       (torch.rand(n_true, generator=g) * 2 - 1) * 8], dim=1)
+    act = torch.rand(n_true, U_DIM, generator=g) * 2 - 1
+    dummy = Transition(observation=torch.zeros(X_DIM), action=torch.zeros(U_DIM), reward=torch.zeros(1),
+                       discount=torch.zeros(1), next_observation=torch.zeros(X_DIM))
+    true_buffer = UniformSamplingQueue(n_true, dummy, 1, device=device)
+    tbs = true_buffer.init(0)
+    rows = torch.cat([obs, act, torch.zeros(n_true, 1), torch.ones(n_true, 1), obs], dim=1).to(device)
+    tbs = true_buffer.insert_rows(tbs, rows)
+    env = BraxWrapper(system, sys_params, tbs, true_buffer)
+    steps_per_train = N_ENVS * S_STEPS
+    trainer = SAC(environment=env, num_timesteps=steps_per_train * 1000, episode_length=EPISODE_LEN,
+                  num_env_steps_between_updates=S_STEPS, num_envs=N_ENVS, batch_size=BATCH,
+                  grad_updates_per_step=GRAD_UPDATES, normalize_observations=True, discounting=0.99, lr_policy=3e-4,
+                  lr_q=3e-4, lr_alpha=3e-4, min_replay_size=steps_per_train, max_replay_size=MAX_REPLAY,
+                  policy_hidden_layer_sizes=HIDDEN, critic_hidden_layer_sizes=HIDDEN, use_graph=use_graph,
+                  process_group=process_group)
+    return trainer
+
+
+def time_kernel_alone(trainer, reps=200):
+    """Average duration of the dominant kernel (k_sac_fwd_bwd) from HIP events on the launch stream."""
+    import ctypes as C
+    from mbpo import _hip
+    lib = _hip.load()
+    up = trainer.updater
+    d = up.desc
+    d.batch = trainer._batch_rows.data_ptr()
+    st = torch.cuda.current_stream()
+    for _ in range(10):
+        _hip.check(lib.mbpo_sac_grads_phase(C.byref(d), 1, st.cuda_stream), "fwd_bwd")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        _hip.check(lib.mbpo_sac_grads_phase(C.byref(d), 1, st.cuda_stream), "fwd_bwd")
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def time_rollout_alone(trainer, ts, env_state, buffer_state, reps=30):
+    st = torch.cuda.current_stream()
+    from mbpo import ops
+    spec = trainer.env.system.rollout_spec(env_state.system_params, trainer.device)
+    nm, ns = trainer._norm(ts.normalizer_params)
+
+    def run():
+        ops.model_rollout(policy_params=ts.policy_params, policy_spec=trainer.policy_spec, x_dim=X_DIM, u_dim=U_DIM,
+                          obs=env_state.obs, first_obs=env_state.info['first_obs'], steps=env_state.info['steps'],
+                          done=env_state.done, n_steps=S_STEPS, episode_length=EPISODE_LEN, norm_mean=nm, norm_std=ns,
+                          seed=3, out=trainer._rollout_rows, **spec)
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        run()
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle's torch-CPU restatement of the same training_step, timed on this box's host cores."""
+    from oracle import nets, sac as osac, systems as osys, trainer as otr
+    g = torch.Generator().manual_seed(0)
+    dd = [X_DIM + U_DIM, *HIDDEN, 2 * X_DIM]
+    dpar = torch.cat([nets.init_mlp_flat(dd, g) * 0.5 for _ in range(N_MEMBERS)])
+    rf = lambda x, u: osys.quadratic_reward(x, u, torch.zeros(X_DIM), torch.ones(X_DIM), torch.ones(U_DIM) * 0.1)
+    system = osys.EnsembleSystem(dpar, dd, N_MEMBERS, X_DIM, U_DIM, reward_fn=rf)
+    cfg = osac.SacConfig(X_DIM, U_DIM, [X_DIM, *HIDDEN, 2 * U_DIM], [X_DIM + U_DIM, *HIDDEN, 1], discounting=0.99,
+                         lr_policy=3e-4, lr_q=3e-4, lr_alpha=3e-4)
+    torch.set_num_threads(os.cpu_count() or 1)
+    loop = otr.CpuSacLoop(cfg, system, N_ENVS, S_STEPS, EPISODE_LEN, BATCH, GRAD_UPDATES, MAX_REPLAY, True)
+    loop.training_step(n_sgd=2)   # warm-up
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < budget_s or n == 0:
+        loop.training_step()
+        n += 1
+    dt = time.time() - t0
+    return {"value": N_ENVS * S_STEPS * n / dt, "unit": "transitions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full SAC training_steps (N={N_ENVS}, S={S_STEPS}, G={GRAD_UPDATES}, B={BATCH}) of oracle/trainer.py "
+                      f"(torch-CPU restatement, not XLA-CPU) in {dt:.1f} s",
+            "sac_updates_per_s": GRAD_UPDATES * n / dt}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+        pg = dist.group.WORLD
+
+    log(f"building trainer on {device} (world={world})")
+    trainer = build_trainer(device, pg, use_graph=not args.no_graph)
+    from mbpo.utils import keys as K
+    ts = trainer.init_training_state(7)
+    env_state = trainer.reset_envs(trainer.env, 11 + rank, N_ENVS)
+    buffer_state = trainer.replay_buffer.init(13 + rank)
+    ts, env_state, buffer_state, _ = trainer.prefill_replay_buffer(ts, env_state, buffer_state, 17 + rank)
+    torch.cuda.synchronize()
+    log("prefill done")
+
+    use_graph = trainer.use_graph and world == 1
+    key = 23 + rank
+
+    def one_step():
+        nonlocal ts, env_state, buffer_state, key
+        key, k = K.split(key)
+        ts, env_state, buffer_state = trainer.training_step(ts, env_state, buffer_state, k)
+
+    graph = None
+    # warm-up: W eager steps (also compiles/loads every kernel), then capture
+    for _ in range(max(args.warmup, 1)):
+        one_step()
+    torch.cuda.synchronize()
+    log(f"{max(args.warmup, 1)} eager warm-up steps done")
+    if use_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            trainer.training_step(ts, env_state, buffer_state, 29)
+        log("graph captured")
+        graph.replay()   # one untimed replay
+        torch.cuda.synchronize()
+        log("graph replayed once")
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if graph is not None:
+            graph.replay()
+        else:
+            one_step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
+    finite = bool(torch.isfinite(trainer.updater.params).all())
+    if rank == 0:
+        P = mlp_macs([X_DIM, *HIDDEN, 2 * U_DIM])
+        Q = mlp_macs([X_DIM + U_DIM, *HIDDEN, 1])
+        M = mlp_macs([X_DIM + U_DIM, *HIDDEN, 2 * X_DIM])
+        flop_per_sample = 2 * (5 * P + 12 * Q)                 # per sgd_step sample
+        flop_per_transition = 2 * N_MEMBERS * M + 2 * P        # per model-rollout transition
+        t_kernel = time_kernel_alone(trainer)
+        t_roll = time_rollout_alone(trainer, ts, env_state, buffer_state)
+        achieved = BATCH * flop_per_sample / t_kernel / 1e12
+        out = {
+            "metric": "model-rollout transitions/sec + SAC updates/sec, Pendulum 5-ens h=5",
+            "value": world * N_ENVS * S_STEPS * args.steps / dt,
+            "unit": "transitions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SAC-MBPO training_step, BASELINE configs[1]: x=4 u=1, 5-member ensemble 64x3, "
+                                   "N=4096 envs/GPU, episode_length=5, S=5, B=256/GPU, G=64, nets 64x3, normalize_observations",
+                       "n_envs_per_gpu": N_ENVS, "horizon": EPISODE_LEN, "env_steps_between_updates": S_STEPS,
+                       "batch_size_per_gpu": BATCH, "grad_updates_per_step": GRAD_UPDATES, "ensemble": N_MEMBERS,
+                       "hipgraph": graph is not None, "parallelism": f"dp{world} (envs+minibatch sharded, flat grad all-reduce per sgd_step)"},
+            "sac_updates_per_s": GRAD_UPDATES * args.steps / dt,
+            "sac_update_samples_per_s": world * BATCH * GRAD_UPDATES * args.steps / dt,
+            "params_finite": finite,
+            "roofline": {"bound": "mfma", "kernel": "k_sac_fwd_bwd<64>", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_us": t_kernel * 1e6, "algorithmic_flop_per_launch": BATCH * flop_per_sample,
+                         "launches_per_step": GRAD_UPDATES},
+            "rollout_kernel": {"kernel": "k_model_rollout<64>", "avg_launch_us": t_roll * 1e6,
+                               "transitions_per_s_alone": N_ENVS * S_STEPS / t_roll,
+                               "achieved_tflops": N_ENVS * S_STEPS * flop_per_transition / t_roll / 1e12,
+                               "frac_of_fp32_mfma_peak": N_ENVS * S_STEPS * flop_per_transition / t_roll / 1e12 / FP32_MFMA_PEAK_TFLOPS},
+        }
+        log("kernel timings done")
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+            log("cpu baseline done")
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

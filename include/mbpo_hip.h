@@ -101,11 +101,15 @@ typedef struct mbpo_rollout_desc {
   int32_t deterministic;     /* 1: action = tanh(loc) (mode) */
   int32_t ppo_extras;        /* 1: rows carry log_prob and raw_action (ppo_network.py:72-80) */
   int32_t env_major;         /* 0: row = s*N + i (SAC concat order, sac.py:296); 1: row = i*S + s (PPO [B*M,T]) */
+  const float *actions;        /* optional [S, N, u_dim] open-loop actions: the policy is skipped (`policy` may be zeroed) —
+                                  rollout_actions (utils/optimizer_utils.py:11-59) and, with S=1, System.step itself */
   /* randomness: explicit tensors when non-NULL, else counter-based Philox4x32-10 keyed by (seed, offset) */
   const float *policy_noise;   /* [S, N, u_dim] standard normal */
   const float *model_noise;    /* [S, action_repeat, N, x_dim] standard normal */
   const int32_t *member_idx;   /* [S, action_repeat, N] in [0, E) for MBPO_ENS_TS1 */
   uint64_t seed, offset;
+  const float *offset_dev;     /* optional device scalar added to `offset` at run time (e.g. the optimizer step count):
+                                  lets a captured hipGraph draw fresh numbers on every replay */
   /* env state, updated in place (brax State.obs / info['steps'] / done / info['first_obs']) */
   float *obs;             /* [N, x_dim] */
   const float *first_obs; /* [N, x_dim] */
@@ -133,9 +137,10 @@ int mbpo_replay_insert(float *data, int64_t max_size, int32_t row_len, int32_t *
 int mbpo_replay_gather(const float *data, int64_t max_size, int32_t row_len, const int32_t *state, const int32_t *idx,
                        int64_t n, float *out, void *stream);
 /* idx[j] = randint(sample_position, insert_position) from Philox(seed, offset, stream=REPLAY, j), then gather.
- * idx_out may be NULL.  Fused sample+gather: sac/sac.py:318 (UniformSamplingQueue.sample). */
+ * idx_out may be NULL; offset_dev (optional device scalar) is added to offset at run time.
+ * Fused sample+gather: sac/sac.py:318 (UniformSamplingQueue.sample). */
 int mbpo_replay_sample(const float *data, int64_t max_size, int32_t row_len, const int32_t *state, uint64_t seed,
-                       uint64_t offset, int64_t n, int32_t *idx_out, float *out, void *stream);
+                       uint64_t offset, const float *offset_dev, int64_t n, int32_t *idx_out, float *out, void *stream);
 
 /* ---- R8: running_statistics.update ([3P] brax.training.acme.running_statistics; call sites
  * sac/sac.py:298-301, ppo/ppo.py:216-219), in the reference's own two-pass form, split so that a multi-GPU
@@ -193,6 +198,8 @@ typedef struct mbpo_sac_desc {
   float *params, *target_q, *adam_m, *adam_v, *step_count, *grads;
   float *workspace;                          /* >= mbpo_sac_workspace_floats() floats */
   float *metrics;                            /* [4] critic_loss, actor_loss, alpha_loss, alpha */
+  float *metrics_accum;                      /* optional [5]: running sums of the four metrics + step count, for the
+                                                epoch means of sac/sac.py:360 without a host round trip per step */
   const float *batch;                        /* [batch_size, row_len] SAC transition rows (2x+u+3) */
   int32_t batch_size, row_len;
   const float *norm_mean, *norm_std;         /* [x_dim] or NULL */
@@ -205,6 +212,9 @@ typedef struct mbpo_sac_desc {
 
 int64_t mbpo_sac_workspace_floats(const mbpo_sac_desc *d);
 int mbpo_sac_grads(const mbpo_sac_desc *d, void *stream);
+/* measurement hook: run only part of mbpo_sac_grads — phase_mask bit0 = forward/backward kernel (k_sac_fwd_bwd),
+ * bit1 = slab reduce (k_sac_reduce).  mbpo_sac_grads == phase_mask 3.  Used by bench.py to time the dominant kernel. */
+int mbpo_sac_grads_phase(const mbpo_sac_desc *d, int32_t phase_mask, void *stream);
 int mbpo_sac_grad_norms(const mbpo_sac_desc *d, void *stream);
 int mbpo_sac_apply(const mbpo_sac_desc *d, void *stream);
 

@@ -16,7 +16,8 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT_DIR = HERE / "mbpo" / "_lib"
 LIB = OUT_DIR / "libmbpo_hip.so"
-OBJ_DIR = HERE / "build"
+# objects and -save-temps output stay out of the tree (the tree is what gpurun ships); only the .so lives in-tree
+OBJ_DIR = Path(os.environ.get("MBPO_BUILD_DIR", "/tmp/mbpo_hip_build"))
 
 ARCH = "gfx950"
 CXXFLAGS = [

@@ -30,6 +30,27 @@ void mbpo_set_error(const char *fmt, ...);
     }                                                                        \
   } while (0)
 
+// Raise a kernel's dynamic-LDS limit when needed.  The attribute is sticky per kernel, so it is set only when a launch
+// needs more than any earlier one did: steady-state launches (and hipGraph capture) issue no attribute call at all.
+// The kernel is a template ARGUMENT, so every kernel instantiation owns its own `granted`.
+template <auto Kern>
+int mbpo_ensure_lds(size_t bytes, const char *what) {
+  static size_t granted = 48 * 1024;
+  if (bytes > 160 * 1024) {
+    mbpo_set_error("%s: needs %zu B of LDS per workgroup (> 160 KiB); reduce ensemble size, hidden width or depth", what, bytes);
+    return MBPO_ERR_UNSUPPORTED;
+  }
+  if (bytes > granted) {
+    hipError_t e = hipFuncSetAttribute((const void *)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+      mbpo_set_error("%s: hipFuncSetAttribute(%zu): %s", what, bytes, hipGetErrorString(e));
+      return MBPO_ERR_LAUNCH;
+    }
+    granted = bytes;
+  }
+  return MBPO_OK;
+}
+
 // ---------------------------------------------------------------- device-side MLP description
 struct MlpDev {
   const float *params;

@@ -71,7 +71,8 @@ extern "C" int mbpo_replay_insert(float *data, int64_t max_size, int32_t row_len
 template <bool SAMPLE>
 __global__ void __launch_bounds__(256) k_replay_gather(const float *data, long long max_size, int D, const int *state,
                                                         const int *idx, unsigned long long seed, unsigned long long offset,
-                                                        long long n, int *idx_out, float *out) {
+                                                        const float *offset_dev, long long n, int *idx_out, float *out) {
+  if (SAMPLE && offset_dev) offset += (unsigned long long)offset_dev[0];
   const int head = state[2];
   const int lo = state[1], hi = state[0];
   const long long total = n * D;
@@ -103,13 +104,14 @@ extern "C" int mbpo_replay_gather(const float *data, int64_t max_size, int32_t r
   long long total = n * row_len;
   int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(k_replay_gather<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, (long long)max_size, row_len,
-                     state, idx, 0ull, 0ull, (long long)n, (int *)nullptr, out);
+                     state, idx, 0ull, 0ull, (const float *)nullptr, (long long)n, (int *)nullptr, out);
   MBPO_CHECK_LAUNCH("replay_gather");
   return MBPO_OK;
 }
 
 extern "C" int mbpo_replay_sample(const float *data, int64_t max_size, int32_t row_len, const int32_t *state, uint64_t seed,
-                                  uint64_t offset, int64_t n, int32_t *idx_out, float *out, void *stream) {
+                                  uint64_t offset, const float *offset_dev, int64_t n, int32_t *idx_out, float *out,
+                                  void *stream) {
   MBPO_REQUIRE(data && state, MBPO_ERR_ARG, "replay_sample: null pointer");
   MBPO_REQUIRE(max_size > 0 && row_len > 0 && n >= 0, MBPO_ERR_ARG, "replay_sample: bad sizes");
   if (n == 0) return MBPO_OK;
@@ -117,7 +119,7 @@ extern "C" int mbpo_replay_sample(const float *data, int64_t max_size, int32_t r
   long long total = n * row_len;
   int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(k_replay_gather<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, (long long)max_size, row_len,
-                     state, (const int *)nullptr, (unsigned long long)seed, (unsigned long long)offset, (long long)n, idx_out, out);
+                     state, (const int *)nullptr, (unsigned long long)seed, (unsigned long long)offset, offset_dev, (long long)n, idx_out, out);
   MBPO_CHECK_LAUNCH("replay_sample");
   return MBPO_OK;
 }

@@ -8,6 +8,7 @@
 // Per (env, step) HBM traffic is one row write (row_len*4 B) — the kernel is MFMA/latency bound by design.
 #include "common.hpp"
 #include "mlp_tile.hpp"
+#include <string.h>
 
 // ------------------------------------------------------------------------------------------------
 // R2: y[e][row][:] = MLP_e(x[row])  — replaces vmap(Dynamics.next_state) (base_dynamics.py:15-20).
@@ -77,22 +78,6 @@ static int num_cus() {
   return n;
 }
 
-template <typename KernelT>
-static int set_lds(KernelT kern, size_t bytes, const char *what) {
-  if (bytes > 160 * 1024) {
-    mbpo_set_error("%s: needs %zu B of LDS per workgroup (> 160 KiB); reduce ensemble size or hidden width", what, bytes);
-    return MBPO_ERR_UNSUPPORTED;
-  }
-  if (bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) {
-      mbpo_set_error("%s: hipFuncSetAttribute(%zu): %s", what, bytes, hipGetErrorString(e));
-      return MBPO_ERR_LAUNCH;
-    }
-  }
-  return MBPO_OK;
-}
-
 extern "C" int mbpo_ensemble_mlp_forward(const mbpo_mlp_desc *mlp, const float *x, int32_t shared_input, float *y,
                                          int64_t n_rows, void *stream) {
   MBPO_REQUIRE(mlp && x && y, MBPO_ERR_ARG, "ensemble_mlp_forward: null pointer");
@@ -118,7 +103,7 @@ extern "C" int mbpo_ensemble_mlp_forward(const mbpo_mlp_desc *mlp, const float *
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_ENS(HH)                                                          \
   {                                                                             \
-    rc = set_lds(k_ensemble_forward<HH>, lds, "ensemble_mlp_forward");          \
+    rc = mbpo_ensure_lds<k_ensemble_forward<HH>>(lds, "ensemble_mlp_forward");          \
     if (rc != MBPO_OK) return rc;                                               \
     hipLaunchKernelGGL(k_ensemble_forward<HH>, dim3(grid), dim3((HH / 16) * 64), lds, st, A); \
   }
@@ -141,9 +126,11 @@ struct RolloutArgs {
   int reward_kind;
   const float *reward_params, *sys_params, *norm_mean, *norm_std;
   int deterministic, ppo_extras, env_major;
+  const float *actions;
   const float *policy_noise, *model_noise;
   const int *member_idx;
   unsigned long long seed, offset;
+  const float *offset_dev;
   float *obs;
   const float *first_obs;
   float *steps, *done;
@@ -206,6 +193,7 @@ __global__ void __launch_bounds__((H / 16) * 64) k_model_rollout(RolloutArgs A) 
   float *s_done = s_steps + 16;                  // [16]
   float *s_rew = s_done + 16;                    // [16]
 
+  const unsigned long long rng_off = A.offset + (A.offset_dev ? (unsigned long long)A.offset_dev[0] : 0ull);
   const long long n_tiles = (N + 15) >> 4;
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long env0 = tile * 16;
@@ -229,6 +217,16 @@ __global__ void __launch_bounds__((H / 16) * 64) k_model_rollout(RolloutArgs A) 
     __syncthreads();
 
     for (int s = 0; s < A.n_steps; ++s) {
+      if (A.actions) {
+        // open-loop actions (rollout_actions, optimizer_utils.py:26-38): no policy
+        for (int idx = tid; idx < 16 * U; idx += nthreads) {
+          int r = idx / U, d = idx - r * U;
+          long long env = env0 + r;
+          float a = env < N ? A.actions[((long long)s * N + env) * U + d] : 0.f;
+          s_xu[r * A.ld_xu + X + d] = a;
+          s_row[r * D + X + d] = a;
+        }
+      } else {
       // ---- policy input: running_statistics.normalize = (obs - mean) / std ----
       for (int idx = tid; idx < 16 * X; idx += nthreads) {
         int r = idx / X, c = idx - r * X;
@@ -248,7 +246,7 @@ __global__ void __launch_bounds__((H / 16) * 64) k_model_rollout(RolloutArgs A) 
         if (!A.deterministic && env < N) {
           long long nidx = ((long long)s * N + env) * U + d;
           eps = A.policy_noise ? A.policy_noise[nidx]
-                               : philox_normal(A.seed, A.offset, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
+                               : philox_normal(A.seed, rng_off, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
         }
         float z = loc + sigma * eps;
         float a = tanhf(z);
@@ -261,6 +259,7 @@ __global__ void __launch_bounds__((H / 16) * 64) k_model_rollout(RolloutArgs A) 
           s_row[r * D + 2 * X + U + 2 + 1 + d] = z;               // raw_action
           s_hA[r * U + d] = lp - ldj;                             // scratch: per-dim log-prob
         }
+      }
       }
       for (int idx = tid; idx < 16 * X; idx += nthreads) {
         int r = idx / X, c = idx - r * X;
@@ -328,7 +327,7 @@ __global__ void __launch_bounds__((H / 16) * 64) k_model_rollout(RolloutArgs A) 
               if (env < N) {
                 if (A.ens_mode == MBPO_ENS_TSINF) mem = (int)(env % E);
                 else mem = A.member_idx ? A.member_idx[eidx]
-                                        : philox_randint(A.seed, A.offset, MBPO_STREAM_MEMBER, (unsigned long long)eidx, 0, E);
+                                        : philox_randint(A.seed, rng_off, MBPO_STREAM_MEMBER, (unsigned long long)eidx, 0, E);
               }
               float mu = s_y[(mem * 16 + r) * A.ld_y + c];
               v = base + mu;
@@ -336,7 +335,7 @@ __global__ void __launch_bounds__((H / 16) * 64) k_model_rollout(RolloutArgs A) 
                 float sg = softplus_f(s_y[(mem * 16 + r) * A.ld_y + X + c]) + A.ens_min_std;
                 long long nidx = eidx * X + c;
                 float eps = A.model_noise ? A.model_noise[nidx]
-                                          : philox_normal(A.seed, A.offset, MBPO_STREAM_MODEL_NOISE, (unsigned long long)nidx);
+                                          : philox_normal(A.seed, rng_off, MBPO_STREAM_MODEL_NOISE, (unsigned long long)nidx);
                 v += sg * eps;
               }
             }
@@ -421,12 +420,18 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   MBPO_REQUIRE(d->reward_kind != MBPO_REWARD_PENDULUM || (X == 3 && U == 1), MBPO_ERR_ARG,
                "model_rollout: pendulum reward needs x_dim=3,u_dim=1");
   RolloutArgs A;
-  int rc = mbpo_make_mlp_dev(&d->policy, &A.policy, "model_rollout.policy");
-  if (rc != MBPO_OK) return rc;
-  MBPO_REQUIRE(A.policy.n_nets == 1, MBPO_ERR_ARG, "model_rollout: policy.n_nets must be 1");
-  MBPO_REQUIRE(A.policy.dims[0] == X && A.policy.dims[A.policy.n_layers] == 2 * U, MBPO_ERR_ARG,
-               "model_rollout: policy must map [x_dim] -> [2*u_dim]");
-  int H = hidden_width(A.policy);
+  int rc;
+  int H = 64;
+  const bool has_policy = (d->actions == nullptr);
+  MBPO_REQUIRE(has_policy || !d->ppo_extras, MBPO_ERR_ARG, "model_rollout: ppo_extras needs a policy (actions must be NULL)");
+  if (has_policy) {
+    rc = mbpo_make_mlp_dev(&d->policy, &A.policy, "model_rollout.policy");
+    if (rc != MBPO_OK) return rc;
+    MBPO_REQUIRE(A.policy.n_nets == 1, MBPO_ERR_ARG, "model_rollout: policy.n_nets must be 1");
+    MBPO_REQUIRE(A.policy.dims[0] == X && A.policy.dims[A.policy.n_layers] == 2 * U, MBPO_ERR_ARG,
+                 "model_rollout: policy must map [x_dim] -> [2*u_dim]");
+    H = hidden_width(A.policy);
+  }
   int E = 0;
   int dyn_out = 0;
   if (d->system_kind == MBPO_SYS_ENSEMBLE) {
@@ -439,13 +444,13 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
                  MBPO_ERR_ARG, "model_rollout: dynamics output must be 2*x_dim (mean, raw std) or x_dim (mean only, no sampling)");
     MBPO_REQUIRE(d->ens_mode >= 0 && d->ens_mode <= 2, MBPO_ERR_ARG, "model_rollout: unknown ens_mode");
     int Hd = hidden_width(A.dyn);
-    if (A.policy.n_layers == 1) H = Hd;
+    if (!has_policy || A.policy.n_layers == 1) H = Hd;
     MBPO_REQUIRE(Hd == H || A.dyn.n_layers == 1, MBPO_ERR_UNSUPPORTED,
                  "model_rollout: policy and dynamics hidden widths must match (got %d vs %d)", H, Hd);
   } else if (d->system_kind == MBPO_SYS_PENDULUM) {
     MBPO_REQUIRE(X == 3 && U == 1, MBPO_ERR_ARG, "model_rollout: pendulum system needs x_dim=3,u_dim=1");
     MBPO_REQUIRE(d->sys_params, MBPO_ERR_ARG, "model_rollout: sys_params is NULL");
-    A.dyn = A.policy;  // unused
+    memset(&A.dyn, 0, sizeof(A.dyn));  // unused
   } else {
     MBPO_REQUIRE(false, MBPO_ERR_ARG, "model_rollout: unknown system_kind %d", d->system_kind);
   }
@@ -460,8 +465,10 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   A.reward_kind = d->reward_kind; A.reward_params = d->reward_params; A.sys_params = d->sys_params;
   A.norm_mean = d->norm_mean; A.norm_std = d->norm_std;
   A.deterministic = d->deterministic; A.ppo_extras = d->ppo_extras; A.env_major = d->env_major;
+  A.actions = d->actions;
+  if (!has_policy) memset(&A.policy, 0, sizeof(A.policy));
   A.policy_noise = d->policy_noise; A.model_noise = d->model_noise; A.member_idx = d->member_idx;
-  A.seed = d->seed; A.offset = d->offset;
+  A.seed = d->seed; A.offset = d->offset; A.offset_dev = d->offset_dev;
   A.obs = d->obs; A.first_obs = d->first_obs; A.steps = d->steps; A.done = d->done;
   A.transitions = d->transitions; A.row_len = d->row_len;
   A.n_slots = E > 1 ? E : 1;
@@ -478,7 +485,7 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_RO(HH)                                                        \
   {                                                                          \
-    rc = set_lds(k_model_rollout<HH>, lds, "model_rollout");                 \
+    rc = mbpo_ensure_lds<k_model_rollout<HH>>(lds, "model_rollout");                 \
     if (rc != MBPO_OK) return rc;                                            \
     hipLaunchKernelGGL(k_model_rollout<HH>, dim3(grid), dim3((HH / 16) * 64), lds, st, A); \
   }

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__((H / 16) * 64) k_sac_fwd_bwd(SacArgs A) {
 struct SacReduceArgs {
   const float *slab_pi, *slab_q, *slab_ex;
   int n_tiles, P, Q2, B;
-  float *grads, *metrics, *ss_part, *step_count;
+  float *grads, *metrics, *metrics_accum, *ss_part, *step_count;
 };
 
 __device__ __forceinline__ float wave_sum64(float v) {
@@ -292,6 +292,12 @@ __global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
     A.metrics[0] = 0.5f * ce * (0.5f * invB);  // critic_loss = 0.5 * mean over [B,2]
     A.metrics[1] = ac * invB;
     A.metrics[2] = al * invB;
+    if (A.metrics_accum) {
+      A.metrics_accum[0] += A.metrics[0];
+      A.metrics_accum[1] += A.metrics[1];
+      A.metrics_accum[2] += A.metrics[2];
+      A.metrics_accum[4] += 1.0f;
+    }
     A.step_count[0] = A.step_count[0] + 1.0f;  // optimizer count (read by apply; fwd_bwd of this step already ran)
   }
   if (i < NP) A.grads[i] = g;
@@ -306,7 +312,7 @@ __global__ void __launch_bounds__(256) k_sac_sumsq(const float *grads, int P, in
 }
 
 struct SacApplyArgs {
-  float *params, *target_q, *adam_m, *adam_v, *grads, *metrics;
+  float *params, *target_q, *adam_m, *adam_v, *grads, *metrics, *metrics_accum;
   const float *step_count, *ss_part;
   int n_parts, P, Q2;
   float lr[3], wd[3];
@@ -351,6 +357,7 @@ __global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
     A.target_q[j] = A.target_q[j] * A.one_minus_tau + pn * A.tau;   // sac.py:260-261 ((1 - tau) formed in double on the host)
   } else if (grp == 2) {
     A.metrics[3] = expf(pn);                                      // 'alpha': exp(alpha_params) (sac.py:267)
+    if (A.metrics_accum) A.metrics_accum[3] += A.metrics[3];
   }
 }
 
@@ -441,13 +448,12 @@ extern "C" int64_t mbpo_sac_workspace_floats(const mbpo_sac_desc *d) {
   return pl.total;
 }
 
-extern "C" int mbpo_sac_grads(const mbpo_sac_desc *d, void *stream) {
+static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream) {
   SacPlan pl;
   int rc = sac_plan(d, &pl, true);
   if (rc != MBPO_OK) return rc;
   MBPO_REQUIRE(d->batch, MBPO_ERR_ARG, "sac_grads: null batch");
   MBPO_REQUIRE((d->norm_mean == nullptr) == (d->norm_std == nullptr), MBPO_ERR_ARG, "sac_grads: norm_mean/norm_std mismatch");
-  MBPO_REQUIRE(pl.lds <= 160 * 1024, MBPO_ERR_UNSUPPORTED, "sac_grads: needs %zu B of LDS (> 160 KiB)", pl.lds);
   SacArgs A;
   A.pi = pl.pi; A.q = pl.q; A.qt = pl.qt;
   A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.D = d->row_len;
@@ -459,20 +465,35 @@ extern "C" int mbpo_sac_grads(const mbpo_sac_desc *d, void *stream) {
   A.slab_pi = d->workspace + pl.off_slab_pi; A.slab_q = d->workspace + pl.off_slab_q; A.slab_ex = d->workspace + pl.off_slab_ex;
   A.ld_x = pl.ld_x; A.ld_xu = pl.ld_xu; A.ld_h = pl.ld_h; A.ld_y = pl.ld_y; A.LH = pl.LH;
   hipStream_t st = (hipStream_t)stream;
-  if (pl.H == 64) {
-    if (pl.lds > 48 * 1024) hipFuncSetAttribute((const void *)k_sac_fwd_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-    hipLaunchKernelGGL(k_sac_fwd_bwd<64>, dim3(2 * pl.n_tiles), dim3(256), pl.lds, st, A);
-  } else {
-    if (pl.lds > 48 * 1024) hipFuncSetAttribute((const void *)k_sac_fwd_bwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-    hipLaunchKernelGGL(k_sac_fwd_bwd<128>, dim3(2 * pl.n_tiles), dim3(512), pl.lds, st, A);
+  if (phase_mask & 1) {
+    if (pl.H == 64) {
+      rc = mbpo_ensure_lds<k_sac_fwd_bwd<64>>(pl.lds, "sac_grads");
+      if (rc != MBPO_OK) return rc;
+      hipLaunchKernelGGL(k_sac_fwd_bwd<64>, dim3(2 * pl.n_tiles), dim3(256), pl.lds, st, A);
+    } else {
+      rc = mbpo_ensure_lds<k_sac_fwd_bwd<128>>(pl.lds, "sac_grads");
+      if (rc != MBPO_OK) return rc;
+      hipLaunchKernelGGL(k_sac_fwd_bwd<128>, dim3(2 * pl.n_tiles), dim3(512), pl.lds, st, A);
+    }
+  }
+  if (!(phase_mask & 2)) {
+    MBPO_CHECK_LAUNCH("sac_grads");
+    return MBPO_OK;
   }
   SacReduceArgs R;
   R.slab_pi = A.slab_pi; R.slab_q = A.slab_q; R.slab_ex = A.slab_ex;
   R.n_tiles = pl.n_tiles; R.P = pl.P; R.Q2 = 2 * pl.Q; R.B = d->batch_size;
-  R.grads = d->grads; R.metrics = d->metrics; R.ss_part = d->workspace + pl.off_ss; R.step_count = d->step_count;
+  R.grads = d->grads; R.metrics = d->metrics; R.metrics_accum = d->metrics_accum; R.ss_part = d->workspace + pl.off_ss; R.step_count = d->step_count;
   hipLaunchKernelGGL(k_sac_reduce, dim3(pl.n_red), dim3(256), 0, st, R);
   MBPO_CHECK_LAUNCH("sac_grads");
   return MBPO_OK;
+}
+
+extern "C" int mbpo_sac_grads(const mbpo_sac_desc *d, void *stream) { return sac_grads_impl(d, 3, stream); }
+
+extern "C" int mbpo_sac_grads_phase(const mbpo_sac_desc *d, int32_t phase_mask, void *stream) {
+  MBPO_REQUIRE(phase_mask >= 1 && phase_mask <= 3, MBPO_ERR_ARG, "sac_grads_phase: phase_mask must be 1, 2 or 3");
+  return sac_grads_impl(d, phase_mask, stream);
 }
 
 extern "C" int mbpo_sac_grad_norms(const mbpo_sac_desc *d, void *stream) {
@@ -491,7 +512,7 @@ extern "C" int mbpo_sac_apply(const mbpo_sac_desc *d, void *stream) {
   if (rc != MBPO_OK) return rc;
   SacApplyArgs A;
   A.params = d->params; A.target_q = d->target_q; A.adam_m = d->adam_m; A.adam_v = d->adam_v; A.grads = d->grads;
-  A.metrics = d->metrics; A.step_count = d->step_count; A.ss_part = d->workspace + pl.off_ss;
+  A.metrics = d->metrics; A.metrics_accum = d->metrics_accum; A.step_count = d->step_count; A.ss_part = d->workspace + pl.off_ss;
   A.n_parts = pl.n_red; A.P = pl.P; A.Q2 = 2 * pl.Q;
   A.lr[0] = d->lr_policy; A.lr[1] = d->lr_q; A.lr[2] = d->lr_alpha;
   A.wd[0] = d->wd_policy; A.wd[1] = d->wd_q; A.wd[2] = d->wd_alpha;

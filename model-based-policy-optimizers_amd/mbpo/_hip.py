@@ -60,11 +60,13 @@ class RolloutDesc(C.Structure):
         ("deterministic", C.c_int32),
         ("ppo_extras", C.c_int32),
         ("env_major", C.c_int32),
+        ("actions", C.c_void_p),
         ("policy_noise", C.c_void_p),
         ("model_noise", C.c_void_p),
         ("member_idx", C.c_void_p),
         ("seed", C.c_uint64),
         ("offset", C.c_uint64),
+        ("offset_dev", C.c_void_p),
         ("obs", C.c_void_p),
         ("first_obs", C.c_void_p),
         ("steps", C.c_void_p),
@@ -82,7 +84,7 @@ class SacDesc(C.Structure):
         ("policy_activation", C.c_int32), ("q_activation", C.c_int32),
         ("params", C.c_void_p), ("target_q", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
         ("step_count", C.c_void_p), ("grads", C.c_void_p),
-        ("workspace", C.c_void_p), ("metrics", C.c_void_p),
+        ("workspace", C.c_void_p), ("metrics", C.c_void_p), ("metrics_accum", C.c_void_p),
         ("batch", C.c_void_p), ("batch_size", C.c_int32), ("row_len", C.c_int32),
         ("norm_mean", C.c_void_p), ("norm_std", C.c_void_p),
         ("noise_alpha", C.c_void_p), ("noise_critic", C.c_void_p), ("noise_actor", C.c_void_p),
@@ -131,7 +133,7 @@ def _bind_optional(lib: C.CDLL) -> None:
         # name: argtypes (see include/mbpo_hip.h)
         "mbpo_replay_insert": [vp, i64, i32, vp, vp, i64, vp],
         "mbpo_replay_gather": [vp, i64, i32, vp, vp, i64, vp, vp],
-        "mbpo_replay_sample": [vp, i64, i32, vp, u64, u64, i64, vp, vp, vp],
+        "mbpo_replay_sample": [vp, i64, i32, vp, u64, u64, vp, i64, vp, vp, vp],
         "mbpo_running_stats_reduce": [vp, i64, i32, i32, i32, vp, vp, vp, i32, vp],
         "mbpo_running_stats_apply": [vp, vp, i32, vp],
         "mbpo_gae_scan": [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp],
@@ -147,6 +149,10 @@ def _bind_optional(lib: C.CDLL) -> None:
         if fn is not None:
             fn.restype = C.c_int
             fn.argtypes = [C.POINTER(SacDesc), vp]
+    fn = getattr(lib, "mbpo_sac_grads_phase", None)
+    if fn is not None:
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(SacDesc), i32, vp]
     fn = getattr(lib, "mbpo_sac_workspace_floats", None)
     if fn is not None:
         fn.restype = C.c_int64

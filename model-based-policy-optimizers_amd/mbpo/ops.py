@@ -60,7 +60,8 @@ def transition_row_len(x_dim: int, u_dim: int, ppo_extras: bool = False) -> int:
     return 2 * x_dim + u_dim + 3 + ((1 + u_dim) if ppo_extras else 0)
 
 
-def model_rollout(*, policy_params: torch.Tensor, policy_spec: MlpSpec, x_dim: int, u_dim: int,
+def model_rollout(*, policy_params: Optional[torch.Tensor] = None, policy_spec: Optional[MlpSpec] = None, x_dim: int, u_dim: int,
+                  actions: Optional[torch.Tensor] = None,
                   obs: torch.Tensor, first_obs: torch.Tensor, steps: torch.Tensor, done: torch.Tensor,
                   n_steps: int, episode_length: int, action_repeat: int = 1,
                   system_kind: int = _hip.SYS_PENDULUM, dyn_params: Optional[torch.Tensor] = None,
@@ -72,7 +73,7 @@ def model_rollout(*, policy_params: torch.Tensor, policy_spec: MlpSpec, x_dim: i
                   deterministic: bool = False, ppo_extras: bool = False, env_major: bool = False,
                   policy_noise: Optional[torch.Tensor] = None, model_noise: Optional[torch.Tensor] = None,
                   member_idx: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  offset_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused S-step model rollout for N envs (R1-R8).  Updates obs/steps/done in place; returns rows [S*N, D]."""
     lib = load()
     n_envs = obs.shape[0]
@@ -90,7 +91,15 @@ def model_rollout(*, policy_params: torch.Tensor, policy_spec: MlpSpec, x_dim: i
         if out.shape != (n_steps * n_envs, D):
             raise ValueError(f"out must be [{n_steps * n_envs},{D}]")
     d = _hip.RolloutDesc()
-    d.policy = policy_spec.desc(policy_params)
+    if actions is None:
+        if policy_params is None or policy_spec is None:
+            raise ValueError("need either a policy (policy_params, policy_spec) or open-loop actions")
+        d.policy = policy_spec.desc(policy_params)
+    else:
+        _req(actions, "actions")
+        if actions.numel() != n_steps * n_envs * u_dim:
+            raise ValueError("actions must be [S,N,u]")
+        d.actions = actions.data_ptr()
     if system_kind == _hip.SYS_ENSEMBLE:
         if dyn_params is None or dyn_spec is None:
             raise ValueError("ensemble system needs dyn_params and dyn_spec")
@@ -119,6 +128,7 @@ def model_rollout(*, policy_params: torch.Tensor, policy_spec: MlpSpec, x_dim: i
             raise ValueError("member_idx must be [S,AR,N]")
     d.policy_noise, d.model_noise, d.member_idx = ptr(policy_noise), ptr(model_noise), ptr(member_idx)
     d.seed, d.offset = seed, offset
+    d.offset_dev = ptr(_req(offset_dev, "offset_dev")) if offset_dev is not None else None
     d.obs, d.first_obs, d.steps, d.done = obs.data_ptr(), first_obs.data_ptr(), steps.data_ptr(), done.data_ptr()
     d.transitions, d.row_len = out.data_ptr(), D
     check(lib.mbpo_model_rollout(C.byref(d), current_stream_ptr()), "mbpo_model_rollout")
@@ -147,15 +157,15 @@ def replay_gather(data: torch.Tensor, state: torch.Tensor, idx: torch.Tensor) ->
 
 
 def replay_sample(data: torch.Tensor, state: torch.Tensor, n: int, seed: int, offset: int, return_idx: bool = False,
-                  out: Optional[torch.Tensor] = None):
+                  out: Optional[torch.Tensor] = None, offset_dev: Optional[torch.Tensor] = None):
     """UniformSamplingQueue.sample: Philox randint in [sample_position, insert_position) + gather, one launch."""
     lib = load()
     _req(data, "data"); _req(state, "state", torch.int32)
     if out is None:
         out = torch.empty((n, data.shape[1]), device=data.device, dtype=torch.float32)
     idx = torch.empty((n,), device=data.device, dtype=torch.int32) if return_idx else None
-    check(lib.mbpo_replay_sample(data.data_ptr(), data.shape[0], data.shape[1], state.data_ptr(), seed, offset, n,
-                                 ptr(idx), out.data_ptr(), current_stream_ptr()), "mbpo_replay_sample")
+    check(lib.mbpo_replay_sample(data.data_ptr(), data.shape[0], data.shape[1], state.data_ptr(), seed, offset,
+                                 ptr(offset_dev), n, ptr(idx), out.data_ptr(), current_stream_ptr()), "mbpo_replay_sample")
     return (out, idx) if return_idx else out
 
 
@@ -178,13 +188,14 @@ def running_stats_reduce(rows: torch.Tensor, col_off: int, x_dim: int, stats: to
     return sums
 
 
-def running_stats_update(rows: torch.Tensor, col_off: int, x_dim: int, stats: torch.Tensor, all_reduce=None) -> None:
+def running_stats_update(rows: torch.Tensor, col_off: int, x_dim: int, stats: torch.Tensor, all_reduce=None,
+                         sums: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> None:
     """running_statistics.update(state, rows[:, col_off:col_off+x_dim]); `all_reduce(t)` sums `t` over ranks in place
     (the reference's psum under pmap_axis_name, sac/sac.py:298-301)."""
-    sums = running_stats_reduce(rows, col_off, x_dim, stats, 0)
+    sums = running_stats_reduce(rows, col_off, x_dim, stats, 0, sums=sums, workspace=workspace)
     if all_reduce is not None:
         all_reduce(sums)
-    running_stats_reduce(rows, col_off, x_dim, stats, 1, sums=sums)
+    running_stats_reduce(rows, col_off, x_dim, stats, 1, sums=sums, workspace=workspace)
     if all_reduce is not None:
         all_reduce(sums[1 + x_dim:])
     running_stats_apply(stats, sums, x_dim)
@@ -250,7 +261,7 @@ class SacUpdater:
         self.device = torch.device(device)
         f = lambda n: torch.zeros(n, device=self.device, dtype=torch.float32)
         self.params, self.target_q, self.adam_m, self.adam_v = f(self.NP), f(2 * self.Q), f(self.NP), f(self.NP)
-        self.step_count, self.grads, self.metrics = f(1), f(self.NP), f(4)
+        self.step_count, self.grads, self.metrics, self.metrics_accum = f(1), f(self.NP), f(4), f(5)
         self.all_reduce, self.world_size = all_reduce, world_size
         d = _hip.SacDesc()
         d.x_dim, d.u_dim = x_dim, u_dim
@@ -273,6 +284,7 @@ class SacUpdater:
         self.workspace = f(int(nws))
         d.params, d.target_q, d.adam_m, d.adam_v = (t.data_ptr() for t in (self.params, self.target_q, self.adam_m, self.adam_v))
         d.step_count, d.grads, d.workspace, d.metrics = (t.data_ptr() for t in (self.step_count, self.grads, self.workspace, self.metrics))
+        d.metrics_accum = self.metrics_accum.data_ptr()
         self.desc = d
 
     # views into the flat state

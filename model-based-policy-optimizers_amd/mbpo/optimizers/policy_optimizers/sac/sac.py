@@ -1,0 +1,458 @@
+"""SAC trainer — host-side mirror of mbpo/optimizers/policy_optimizers/sac/sac.py (same constructor arguments,
+derived quantities, method names, call order and metric keys); every numeric step runs in libmbpo_hip.so.
+
+Where the reference has                      this file issues
+  lax.scan of actor_step (:283-296)      ->  ONE mbpo_model_rollout launch per get_experience
+  running_statistics.update (:298-301)   ->  mbpo_running_stats_reduce x2 + _apply (two-pass, psum positions kept)
+  replay_buffer.insert / .sample (:303,318) -> mbpo_replay_insert / mbpo_replay_sample (device-resident positions)
+  lax.scan of sgd_step (:324)            ->  G x (mbpo_sac_grads [+ all-reduce] + mbpo_sac_apply)
+  jit(training_epoch) (:347-361)         ->  one captured hipGraph of a training_step, replayed per step
+
+Randomness: the reference splits a threefry key per call; here each epoch derives three integer seeds from the epoch
+key and the device-resident optimizer step count is added to the Philox offset inside the kernels, so a replayed graph
+draws fresh numbers every step (see utils/keys.py).
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+import time
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from mbpo import ops
+from mbpo.optimizers.policy_optimizers.brax_utils.base import State
+from mbpo.replay import ReplayBufferState, UniformSamplingQueue
+from mbpo.systems.brax_wrapper import BraxWrapper
+from mbpo.systems.ensemble_system import lecun_uniform_flat
+from mbpo.types import Transition
+from mbpo.utils import keys as K
+
+Metrics = Dict[str, Any]
+
+
+@dataclass
+class RunningStatisticsState:
+    """[3P] brax running_statistics.RunningStatisticsState as views into one device vector [count, mean, sv, std]."""
+    vec: torch.Tensor
+    x_dim: int
+
+    @property
+    def count(self):
+        return self.vec[0]
+
+    @property
+    def mean(self):
+        return self.vec[1:1 + self.x_dim]
+
+    @property
+    def summed_variance(self):
+        return self.vec[1 + self.x_dim:1 + 2 * self.x_dim]
+
+    @property
+    def std(self):
+        return self.vec[1 + 2 * self.x_dim:1 + 3 * self.x_dim]
+
+
+@dataclass
+class TrainingState:
+    """sac.py:39-54.  The tensors are views into the updater's flat device state (include/mbpo_hip.h)."""
+    policy_optimizer_state: Any
+    policy_params: torch.Tensor
+    q_optimizer_state: Any
+    q_params: torch.Tensor
+    target_q_params: torch.Tensor
+    gradient_steps: torch.Tensor
+    env_steps: int
+    alpha_optimizer_state: Any
+    alpha_params: torch.Tensor
+    normalizer_params: RunningStatisticsState
+
+    def get_policy_params(self):
+        return self.normalizer_params, self.policy_params
+
+    def replace(self, **kw):
+        return dataclasses.replace(self, **kw)
+
+
+class SAC:
+    def __init__(self,
+                 environment: BraxWrapper,
+                 num_timesteps: int,
+                 episode_length: int,
+                 action_repeat: int = 1,
+                 num_env_steps_between_updates: int = 2,
+                 num_envs: int = 1,
+                 num_eval_envs: int = 128,
+                 lr_alpha: float = 1e-4,
+                 lr_policy: float = 1e-4,
+                 lr_q: float = 1e-4,
+                 wd_alpha: float = 0.,
+                 wd_policy: float = 0.,
+                 wd_q: float = 0.,
+                 max_grad_norm: float = 1e5,
+                 discounting: float = 0.9,
+                 batch_size: int = 256,
+                 num_evals: int = 1,
+                 normalize_observations: bool = False,
+                 reward_scaling: float = 1.,
+                 tau: float = 0.005,
+                 min_replay_size: int = 0,
+                 max_replay_size: Optional[int] = None,
+                 grad_updates_per_step: int = 1,
+                 deterministic_eval: bool = True,
+                 init_log_alpha: float = 0.,
+                 target_entropy: Optional[float] = None,
+                 policy_hidden_layer_sizes: Sequence[int] = (64, 64, 64),
+                 policy_activation: str = "swish",
+                 critic_hidden_layer_sizes: Sequence[int] = (64, 64, 64),
+                 critic_activation: str = "swish",
+                 wandb_logging: bool = False,
+                 return_best_model: bool = False,
+                 eval_environment: Optional[BraxWrapper] = None,
+                 episode_length_eval: Optional[int] = None,
+                 eval_key_fixed: bool = False,
+                 non_equidistant_time: bool = False,
+                 continuous_discounting: float = 0,
+                 min_time_between_switches: float = 0,
+                 max_time_between_switches: float = 0,
+                 env_dt: float = 0,
+                 # --- MI355X-side knobs (not in the reference) ---
+                 use_graph: bool = True,
+                 process_group=None,
+                 ):
+        if min_replay_size >= num_timesteps:
+            raise ValueError('No training will happen because min_replay_size >= num_timesteps')     # sac.py:100-102
+        if non_equidistant_time:
+            raise NotImplementedError("non_equidistant_time (sac/losses.py:90-98) is a SURVEY §8f 'next' row (N1)")
+        if wandb_logging:
+            raise NotImplementedError("wandb is not available in this environment")
+        self.eval_key_fixed = eval_key_fixed
+        self.return_best_model = return_best_model
+        self.target_entropy = target_entropy
+        self.init_log_alpha = init_log_alpha
+        self.min_replay_size = min_replay_size
+        self.num_timesteps = num_timesteps
+        self.num_envs = num_envs
+        self.deterministic_eval = deterministic_eval
+        self.num_eval_envs = num_eval_envs
+        self.episode_length = episode_length
+        self.action_repeat = action_repeat
+        self.num_evals = num_evals
+        self.num_env_steps_between_updates = num_env_steps_between_updates
+        self.normalize_observations = normalize_observations
+        self.batch_size = batch_size
+        if max_replay_size is None:
+            max_replay_size = num_timesteps
+        self.max_replay_size = max_replay_size
+        # sac.py:119-134 — identical derived quantities
+        self.env_steps_per_actor_step = action_repeat * num_envs
+        self.num_prefill_actor_steps = math.ceil(min_replay_size / num_envs)
+        num_prefill_env_steps = self.num_prefill_actor_steps * self.env_steps_per_actor_step
+        assert num_timesteps - num_prefill_env_steps >= 0
+        self.num_evals_after_init = max(num_evals - 1, 1)
+        num_env_steps_in_one_train_step = self.num_evals_after_init * self.env_steps_per_actor_step
+        num_env_steps_in_one_train_step *= num_env_steps_between_updates
+        self.num_training_steps_per_epoch = math.ceil(
+            (num_timesteps - num_prefill_env_steps) / num_env_steps_in_one_train_step)
+        self.grad_updates_per_step = grad_updates_per_step
+        self.tau = tau
+        self.env = environment
+        if episode_length_eval is None:
+            episode_length_eval = episode_length
+        self.episode_length_eval = episode_length_eval
+        self.eval_env = environment if eval_environment is None else eval_environment
+        self.x_dim = self.env.observation_size
+        self.u_dim = self.env.action_size
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.policy_dims = [self.x_dim, *policy_hidden_layer_sizes, 2 * self.u_dim]
+        self.q_dims = [self.x_dim + self.u_dim, *critic_hidden_layer_sizes, 1]
+        self.policy_spec = ops.MlpSpec(self.policy_dims, policy_activation, 1)
+        # data-parallel ranks (the live form of _PMAP_AXIS_NAME, sac.py:188-189): one process per GPU
+        self.process_group = process_group
+        self.world_size = 1
+        all_reduce = None
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world_size = dist.get_world_size(process_group)
+            all_reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
+        self._all_reduce = all_reduce
+        self.updater = ops.SacUpdater(
+            x_dim=self.x_dim, u_dim=self.u_dim, policy_dims=self.policy_dims, q_dims=self.q_dims, batch_size=batch_size,
+            device=self.device, policy_activation=policy_activation, q_activation=critic_activation,
+            discounting=discounting, reward_scaling=reward_scaling, target_entropy=target_entropy, tau=tau,
+            lr_policy=lr_policy, lr_q=lr_q, lr_alpha=lr_alpha, wd_policy=wd_policy, wd_q=wd_q, wd_alpha=wd_alpha,
+            max_grad_norm=max_grad_norm, all_reduce=all_reduce, world_size=self.world_size)
+        # SAC's own buffer of model transitions (sac.py:191-205): rows carry state_extras.truncation
+        z = lambda n: torch.zeros(n, device=self.device)
+        dummy_transition = Transition(observation=z(self.x_dim), action=z(self.u_dim), reward=z(1), discount=z(1),
+                                      next_observation=z(self.x_dim),
+                                      extras={'state_extras': {'truncation': z(1)}, 'policy_extras': {}})
+        self.replay_buffer = UniformSamplingQueue(max_replay_size=max_replay_size, dummy_data_sample=dummy_transition,
+                                                  sample_batch_size=batch_size * grad_updates_per_step, device=self.device)
+        self.row_len = self.replay_buffer.row_len
+        # fixed device buffers (graph-replayable)
+        S, N = num_env_steps_between_updates, num_envs
+        self._rollout_rows = torch.empty(S * N, self.row_len, device=self.device)
+        self._batch_rows = torch.empty(batch_size * grad_updates_per_step, self.row_len, device=self.device)
+        self._stats_sums = torch.zeros(1 + 2 * self.x_dim, device=self.device)
+        self._stats_ws = torch.empty(64 * self.x_dim, device=self.device)
+        self._stats_vec = torch.zeros(1 + 3 * self.x_dim, device=self.device)
+        self.use_graph = use_graph
+        self._graph = None
+        self._graph_key = None
+        self._call_counter = 0     # host part of the Philox offset (high 32 bits)
+
+    # ------------------------------------------------------------------------------------------------ policy
+    def make_policy(self, params, deterministic: bool = False):
+        """make_inference_fn (sac_networks.py:58-73): policy(observations, key) -> (action, extras)."""
+        normalizer_params, policy_params = params
+        nm, ns = self._norm(normalizer_params)
+
+        def policy(observations: torch.Tensor, key_sample: int):
+            obs = observations.reshape(-1, self.x_dim).to(self.device, torch.float32).contiguous()
+            act = policy_act(policy_params, self.policy_spec, obs, nm, ns, deterministic, key_sample)
+            return (act[0] if observations.dim() == 1 else act), {}
+
+        return policy
+
+    def _norm(self, normalizer_params: RunningStatisticsState):
+        if not self.normalize_observations:
+            return None, None
+        return normalizer_params.mean.contiguous(), normalizer_params.std.contiguous()
+
+    # ------------------------------------------------------------------------------------------------ state
+    def init_training_state(self, key: int) -> TrainingState:
+        """sac.py:376-402: fresh lecun-uniform policy and twin critics, target = critics, log_alpha, normalizer init."""
+        key_policy, key_q = K.split(key)
+        gp = torch.Generator().manual_seed(key_policy % (2 ** 63))
+        gq = torch.Generator().manual_seed(key_q % (2 ** 63))
+        pol = lecun_uniform_flat(self.policy_dims, gp)
+        q = torch.cat([lecun_uniform_flat(self.q_dims, gq) for _ in range(2)])
+        params = torch.cat([pol, q, torch.tensor([self.init_log_alpha], dtype=torch.float32)]).to(self.device)
+        if self.process_group is not None:   # identical replicas: broadcast rank 0's initialisation
+            import torch.distributed as dist
+            dist.broadcast(params, src=0, group=self.process_group)
+        self.updater.load_state(params)
+        self._stats_vec.zero_()
+        self._stats_vec[1 + 2 * self.x_dim:] = 1.0      # running_statistics.init_state: std = 1
+        return self._training_state(env_steps=0)
+
+    def _training_state(self, env_steps: int) -> TrainingState:
+        u = self.updater
+        return TrainingState(policy_optimizer_state=(u.adam_m[:u.P], u.adam_v[:u.P]), policy_params=u.policy_params,
+                             q_optimizer_state=(u.adam_m[u.P:u.P + 2 * u.Q], u.adam_v[u.P:u.P + 2 * u.Q]),
+                             q_params=u.q_params, target_q_params=u.target_q, gradient_steps=u.step_count,
+                             env_steps=env_steps, alpha_optimizer_state=(u.adam_m[-1:], u.adam_v[-1:]),
+                             alpha_params=u.log_alpha, normalizer_params=RunningStatisticsState(self._stats_vec, self.x_dim))
+
+    # ------------------------------------------------------------------------------------------------ hot loops
+    def _next_offset(self) -> int:
+        self._call_counter += 1
+        return self._call_counter << 32
+
+    def get_experience(self, normalizer_params: RunningStatisticsState, policy_params: torch.Tensor, env_state: State,
+                       buffer_state: ReplayBufferState, key: int):
+        """sac.py:283-304."""
+        nm, ns = self._norm(normalizer_params)
+        spec = self.env.system.rollout_spec(env_state.system_params, self.device)
+        rows = ops.model_rollout(policy_params=policy_params, policy_spec=self.policy_spec, x_dim=self.x_dim, u_dim=self.u_dim,
+                                 obs=env_state.obs, first_obs=env_state.info['first_obs'], steps=env_state.info['steps'],
+                                 done=env_state.done, n_steps=self.num_env_steps_between_updates,
+                                 episode_length=self.episode_length, action_repeat=self.action_repeat, norm_mean=nm,
+                                 norm_std=ns, seed=key, offset=self._next_offset(), offset_dev=self.updater.step_count,
+                                 out=self._rollout_rows, **spec)
+        # running_statistics.update(normalizer_params, transitions.observation, pmap_axis_name)   (:298-301)
+        ops.running_stats_update(rows, 0, self.x_dim, normalizer_params.vec, all_reduce=self._all_reduce,
+                                 sums=self._stats_sums, workspace=self._stats_ws)
+        buffer_state = self.replay_buffer.insert_rows(buffer_state, rows)                       # :303
+        return normalizer_params, env_state, buffer_state
+
+    def sgd_step(self, transitions_rows: torch.Tensor, normalizer_params: RunningStatisticsState, key: int) -> None:
+        """sac.py:227-281 on one minibatch [B, D] (alpha, critic, actor updates at the old params + Polyak)."""
+        nm, ns = self._norm(normalizer_params)
+        self.updater.desc.seed = key
+        self.updater.sgd_step(transitions_rows, nm, ns, offset=self._call_counter << 32)
+
+    def training_step(self, training_state: TrainingState, env_state: State, buffer_state: ReplayBufferState, key: int):
+        """sac.py:306-327."""
+        experience_key, training_key = K.split(key)
+        normalizer_params, env_state, buffer_state = self.get_experience(
+            training_state.normalizer_params, training_state.policy_params, env_state, buffer_state, experience_key)
+        training_state = training_state.replace(
+            env_steps=training_state.env_steps + self.env_steps_per_actor_step * self.num_env_steps_between_updates)
+        buffer_state, rows = self.replay_buffer.sample_rows(buffer_state, out=self._batch_rows,
+                                                            offset_dev=self.updater.step_count)   # :318
+        B = self.batch_size
+        for g in range(self.grad_updates_per_step):                                                # scan :324
+            self.sgd_step(rows[g * B:(g + 1) * B], normalizer_params, training_key)
+        return training_state, env_state, buffer_state
+
+    def prefill_replay_buffer(self, training_state: TrainingState, env_state: State, buffer_state: ReplayBufferState, key: int):
+        """sac.py:329-345."""
+        for _ in range(self.num_prefill_actor_steps):
+            key, new_key = K.split(key)
+            _, env_state, buffer_state = self.get_experience(training_state.normalizer_params, training_state.policy_params,
+                                                             env_state, buffer_state, key)
+            training_state = training_state.replace(env_steps=training_state.env_steps + self.env_steps_per_actor_step)
+            key = new_key
+        return training_state, env_state, buffer_state, key
+
+    def training_epoch(self, training_state: TrainingState, env_state: State, buffer_state: ReplayBufferState, key: int):
+        """sac.py:347-361: num_training_steps_per_epoch training_steps; metrics averaged over the epoch.
+
+        With use_graph the first step of an epoch runs eagerly (it also warms every kernel up), the second is captured
+        into a hipGraph and the rest replay it — all launches read their positions / counters from device memory."""
+        self.updater.metrics_accum.zero_()
+        n = self.num_training_steps_per_epoch
+        env_steps_per = self.env_steps_per_actor_step * self.num_env_steps_between_updates
+        done_steps = 0
+        if self.use_graph and n >= 3 and self._all_reduce is None:
+            k1, k2 = K.split(key)
+            training_state, env_state, buffer_state = self.training_step(training_state, env_state, buffer_state, k1)
+            done_steps = 1
+            gkey = (id(env_state.obs), id(buffer_state.data))
+            if self._graph is None or self._graph_key != gkey:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self.training_step(training_state, env_state, buffer_state, k2)
+                self._graph, self._graph_key = graph, gkey
+            # capture does not execute: every step from here on is a replay
+            for _ in range(n - 1):
+                self._graph.replay()
+            done_steps = n
+            # host mirrors of the replay positions (same integer arithmetic as the device)
+            for _ in range(n - 1):
+                buffer_state = _advance_mirror(self.replay_buffer, buffer_state, self._rollout_rows.shape[0])
+            training_state = training_state.replace(env_steps=training_state.env_steps + (n - 1) * env_steps_per)
+        while done_steps < n:
+            key, k = K.split(key)
+            training_state, env_state, buffer_state = self.training_step(training_state, env_state, buffer_state, k)
+            done_steps += 1
+        acc = self.updater.metrics_accum.cpu()
+        cnt = max(float(acc[4]), 1.0)
+        metrics = {'critic_loss': float(acc[0]) / cnt, 'actor_loss': float(acc[1]) / cnt, 'alpha_loss': float(acc[2]) / cnt,
+                   'alpha': float(acc[3]) / cnt, 'buffer_current_size': float(self.replay_buffer.size(buffer_state))}
+        return training_state, env_state, buffer_state, metrics
+
+    def training_epoch_with_timing(self, training_state, env_state, buffer_state, key):
+        """sac.py:363-374 (note: like the reference, `sps` omits the num_env_steps_between_updates factor)."""
+        torch.cuda.synchronize()
+        t = time.time()
+        training_state, env_state, buffer_state, metrics = self.training_epoch(training_state, env_state, buffer_state, key)
+        torch.cuda.synchronize()
+        epoch_training_time = time.time() - t
+        sps = (self.env_steps_per_actor_step * self.num_training_steps_per_epoch) / epoch_training_time
+        metrics = {'training/sps': sps, **{f'training/{name}': value for name, value in metrics.items()}}
+        return training_state, env_state, buffer_state, metrics
+
+    # ------------------------------------------------------------------------------------------------ driver
+    def reset_envs(self, env: BraxWrapper, key: int, n: int) -> State:
+        return env.reset(K.split(key, n))
+
+    def run_training(self, key: int, progress_fn: Callable[[int, Metrics], None] = lambda *args: None):
+        """sac.py:404-494 — same order of key splits and phases."""
+        key, subkey = K.split(key)
+        training_state = self.init_training_state(subkey)
+        key, rb_key, env_key, eval_key = K.split(key, 4)
+        env_state = self.reset_envs(self.env, env_key, self.num_envs)
+        buffer_state = self.replay_buffer.init(rb_key)
+        evaluator = Evaluator(self, self.eval_env, num_eval_envs=self.num_eval_envs, episode_length=self.episode_length_eval,
+                              action_repeat=self.action_repeat, key=eval_key)
+        all_metrics: List[Metrics] = []
+        highest_eval_episode_reward = -float('inf')
+        best_params = self._snapshot(training_state)
+        if self.num_evals > 1:
+            metrics = evaluator.run_evaluation(training_state.get_policy_params(), training_metrics={})
+            if metrics['eval/episode_reward'] > highest_eval_episode_reward:
+                highest_eval_episode_reward = metrics['eval/episode_reward']
+                best_params = self._snapshot(training_state)
+            all_metrics.append(metrics)
+            progress_fn(0, metrics)
+        key, prefill_key = K.split(key)
+        training_state, env_state, buffer_state, _ = self.prefill_replay_buffer(training_state, env_state, buffer_state, prefill_key)
+        if self.eval_key_fixed:
+            key, eval_key = K.split(key)
+        for _ in range(self.num_evals_after_init):
+            key, epoch_key = K.split(key)
+            training_state, env_state, buffer_state, training_metrics = self.training_epoch_with_timing(
+                training_state, env_state, buffer_state, epoch_key)
+            if not self.eval_key_fixed:
+                key, eval_key = K.split(key)
+            metrics = evaluator.run_evaluation(training_state.get_policy_params(), training_metrics, unroll_key=eval_key)
+            if metrics['eval/episode_reward'] > highest_eval_episode_reward:
+                highest_eval_episode_reward = metrics['eval/episode_reward']
+                best_params = self._snapshot(training_state)
+            all_metrics.append(metrics)
+            progress_fn(training_state.env_steps, metrics)
+        last_params = self._snapshot(training_state)
+        params_to_return = best_params if self.return_best_model else last_params
+        return params_to_return, all_metrics
+
+    def _snapshot(self, training_state: TrainingState):
+        """(normalizer_params, policy_params) detached from the live flat state."""
+        return (RunningStatisticsState(training_state.normalizer_params.vec.clone(), self.x_dim),
+                training_state.policy_params.clone())
+
+
+def _advance_mirror(q: UniformSamplingQueue, bs: ReplayBufferState, n: int) -> ReplayBufferState:
+    mx = q.max_replay_size
+    roll = min(0, mx - bs.insert_position - n)
+    pos = bs.insert_position + roll
+    k, _ = K.split(bs.key)
+    return bs.replace(insert_position=(pos + n) % (mx + 1), sample_position=max(0, bs.sample_position + roll),
+                      head=(bs.head - roll) % mx, key=k, sample_count=bs.sample_count + 1)
+
+
+def policy_act(policy_params: torch.Tensor, policy_spec: ops.MlpSpec, obs: torch.Tensor, norm_mean, norm_std,
+               deterministic: bool, key: int) -> torch.Tensor:
+    """Policy inference for `act` (sac_networks.py:63-69): one MLP forward + NormalTanh mode/sample.
+    The MLP runs in mbpo_ensemble_mlp_forward; the distribution head is a few elementwise device ops (not a hot path)."""
+    x = obs if norm_mean is None else ((obs - norm_mean) / norm_std).contiguous()
+    logits = ops.ensemble_mlp_forward(policy_params, policy_spec, x)[0]
+    u = logits.shape[-1] // 2
+    loc, raw = logits[:, :u], logits[:, u:]
+    if deterministic:
+        return torch.tanh(loc)
+    scale = torch.nn.functional.softplus(raw) + 0.001
+    gen = torch.Generator(device=obs.device).manual_seed(int(key) % (2 ** 63))
+    eps = torch.randn(loc.shape, device=obs.device, generator=gen)
+    return torch.tanh(loc + scale * eps)
+
+
+class Evaluator:
+    """sac/acting.py:82-145 on the fused rollout: num_eval_envs episodes of `episode_length` steps from fresh resets,
+    deterministic (mode) or sampled actions; eval/episode_reward = mean over envs of the summed rewards."""
+
+    def __init__(self, trainer: SAC, eval_env: BraxWrapper, num_eval_envs: int, episode_length: int, action_repeat: int, key: int):
+        self.t, self.env = trainer, eval_env
+        self.num_eval_envs, self.episode_length, self.action_repeat = num_eval_envs, episode_length, action_repeat
+        self._key = key
+        self._eval_walltime = 0.0
+        self._steps_per_unroll = episode_length * num_eval_envs
+
+    def run_evaluation(self, policy_params, training_metrics: Metrics, unroll_key: Optional[int] = None) -> Metrics:
+        t = self.t
+        if unroll_key is None:
+            self._key, unroll_key = K.split(self._key)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        normalizer_params, pol = policy_params
+        nm, ns = t._norm(normalizer_params)
+        st = self.env.reset(K.split(unroll_key, self.num_eval_envs))
+        n_steps = self.episode_length // self.action_repeat
+        spec = self.env.system.rollout_spec(st.system_params, t.device)
+        rows = ops.model_rollout(policy_params=pol, policy_spec=t.policy_spec, x_dim=t.x_dim, u_dim=t.u_dim, obs=st.obs,
+                                 first_obs=st.info['first_obs'], steps=st.info['steps'], done=st.done, n_steps=n_steps,
+                                 episode_length=self.episode_length, action_repeat=self.action_repeat, norm_mean=nm,
+                                 norm_std=ns, deterministic=t.deterministic_eval, seed=unroll_key, offset=t._next_offset(), **spec)
+        rew = rows[:, t.x_dim + t.u_dim].reshape(n_steps, self.num_eval_envs).sum(dim=0)
+        episode_reward = float(rew.mean())
+        epoch_eval_time = time.time() - t0
+        self._eval_walltime += epoch_eval_time
+        return {'eval/walltime': self._eval_walltime, **training_metrics, 'eval/episode_reward': episode_reward,
+                'eval/avg_episode_length': float(self.episode_length), 'eval/epoch_eval_time': epoch_eval_time,
+                'eval/sps': self._steps_per_unroll / max(epoch_eval_time, 1e-9)}
