@@ -1,13 +1,14 @@
 // rollout.hip — R2 ensemble MLP forward and R1-R8 fused model rollout (see include/mbpo_hip.h).
 //
-// Decomposition (MI355X): one 4..16-wave workgroup owns a tile of 16 envs for ALL steps of the rollout and
-// ALL ensemble members, because every step ends in a reduction over members (mean / member pick) that feeds
-// the next step's input.  Waves split each Dense layer by (member, 16-column n-tile) items; activations
-// live in LDS, weights stream from L2 (flat params are ~0.2 MB and shared by every workgroup), the
-// transition row is assembled in LDS and written to HBM as one contiguous block per step.
+// Decomposition (MI355X): one workgroup owns a tile of 16 envs for ALL steps of the rollout and ALL ensemble
+// members, because every step ends in a reduction over members (mean / member pick) that feeds the next step's
+// input.  Each wave walks a whole (tile, network) chain (wave_mlp.hpp): wave 0 the policy, then waves 0..E-1 one
+// ensemble member each, with two workgroup barriers per step instead of one per layer.  Activations live in LDS,
+// weights stream from L2 (flat params are ~0.2 MB, shared by every workgroup), the transition row is assembled in
+// LDS and written to HBM as one contiguous block per step.
 // Per (env, step) HBM traffic is one row write (row_len*4 B) — the kernel is MFMA/latency bound by design.
 #include "common.hpp"
-#include "mlp_tile.hpp"
+#include "wave_mlp.hpp"
 #include <string.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -19,25 +20,26 @@ struct EnsFwdArgs {
   float *y;
   long long n_rows;
   int shared_input;
-  int ld_x, ld_h, ld_y;
+  int ld_x, ld_h, ld_y, n_chains;
 };
 
+// workgroup = n_chains waves; wave w walks member (round*n_chains + w)'s chain on the tile
 template <int H>
-__global__ void __launch_bounds__((H / 16) * 64) k_ensemble_forward(EnsFwdArgs A) {
+__global__ void __launch_bounds__(512) k_ensemble_forward(EnsFwdArgs A) {
   extern __shared__ __align__(16) float smem[];
-  constexpr int NW = H / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int HT = H / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const MlpDev &m = A.mlp;
   const int E = m.n_nets, din = m.dims[0], dout = m.dims[m.n_layers];
   const int n_in_nets = A.shared_input ? 1 : E;
+  const int T = 16 * A.ld_h;
   float *s_x = smem;                                // [n_in_nets][16][ld_x]
-  float *s_hA = s_x + n_in_nets * 16 * A.ld_x;      // [E][16][ld_h]
-  float *s_hB = s_hA + E * 16 * A.ld_h;             // [E][16][ld_h]
-  float *s_y = s_hB + E * 16 * A.ld_h;              // [E][16][ld_y]
+  float *s_pp = s_x + n_in_nets * 16 * A.ld_x;      // [n_chains][2] hidden tiles
+  float *s_y = s_pp + A.n_chains * 2 * T;           // [E][16][ld_y]
   const long long n_tiles = (A.n_rows + 15) >> 4;
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long row0 = tile * 16;
-    for (int idx = tid; idx < n_in_nets * 16 * din; idx += blockDim.x) {
+    for (int idx = tid; idx < n_in_nets * 16 * din; idx += nthreads) {
       int e = idx / (16 * din), rem = idx - e * 16 * din;
       int r = rem / din, c = rem - r * din;
       long long row = row0 + r;
@@ -46,9 +48,14 @@ __global__ void __launch_bounds__((H / 16) * 64) k_ensemble_forward(EnsFwdArgs A
       s_x[(e * 16 + r) * A.ld_x + c] = v;
     }
     __syncthreads();
-    mlp_forward_tile<H>(m, E, s_x, A.shared_input ? 0 : 16 * A.ld_x, A.ld_x, s_hA, s_hB, A.ld_h, s_y, A.ld_y, wave, NW,
-                        lane);
-    for (int idx = tid; idx < E * 16 * dout; idx += blockDim.x) {
+    for (int e0 = 0; e0 < E; e0 += A.n_chains) {
+      const int e = e0 + wave;
+      if (e < E)
+        wave_mlp_fwd<HT>(m, m.params + (long long)e * m.net_stride, s_x + (A.shared_input ? 0 : e * 16 * A.ld_x), A.ld_x,
+                         s_pp + wave * 2 * T, s_pp + wave * 2 * T + T, nullptr, nullptr, A.ld_h, s_y + e * 16 * A.ld_y, A.ld_y, lane);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < E * 16 * dout; idx += nthreads) {
       int e = idx / (16 * dout), rem = idx - e * 16 * dout;
       int r = rem / dout, c = rem - r * dout;
       long long row = row0 + r;
@@ -65,6 +72,17 @@ static int hidden_width(const MlpDev &m) {
   for (int l = 2; l < m.n_layers; ++l)
     if (m.dims[l] != H) return -1;
   return H;
+}
+
+static int up4(int v) { return (v + 3) & ~3; }
+
+// how many chains (waves) a workgroup runs side by side: one per member, capped at 8 waves (512 threads: two waves per
+// SIMD keep 256 VGPRs each) and by the LDS that the per-chain ping-pong tiles need next to `fixed_floats` of other
+// buffers; larger ensembles run in rounds of n_chains members
+static int pick_chains(int n_members, size_t fixed_floats, int ld_h) {
+  int c = n_members < 1 ? 1 : (n_members > 8 ? 8 : n_members);
+  while (c >= 1 && (fixed_floats + 2ull * c * 16 * ld_h) * sizeof(float) > 160 * 1024) --c;
+  return c;
 }
 
 static int num_cus() {
@@ -93,11 +111,14 @@ extern "C" int mbpo_ensemble_mlp_forward(const mbpo_mlp_desc *mlp, const float *
   A.y = y;
   A.n_rows = n_rows;
   A.shared_input = shared_input ? 1 : 0;
-  A.ld_x = A.mlp.dims[0] | 1;
-  A.ld_h = H + 1;
-  A.ld_y = A.mlp.dims[A.mlp.n_layers] | 1;
+  A.ld_x = up4(A.mlp.dims[0]) + 4;
+  A.ld_h = H + 4;
+  A.ld_y = up4(A.mlp.dims[A.mlp.n_layers]) + 4;
   const int E = A.mlp.n_nets;
-  size_t lds = sizeof(float) * ((size_t)(shared_input ? 1 : E) * 16 * A.ld_x + 2ull * E * 16 * A.ld_h + (size_t)E * 16 * A.ld_y);
+  const size_t fixed_f = (size_t)(shared_input ? 1 : E) * 16 * A.ld_x + (size_t)E * 16 * A.ld_y;
+  A.n_chains = pick_chains(E, fixed_f, A.ld_h);
+  MBPO_REQUIRE(A.n_chains >= 1, MBPO_ERR_UNSUPPORTED, "ensemble_mlp_forward: shapes do not fit 160 KiB of LDS");
+  size_t lds = sizeof(float) * (fixed_f + 2ull * A.n_chains * 16 * A.ld_h);
   long long n_tiles = (n_rows + 15) >> 4;
   int grid = (int)(n_tiles < 8LL * num_cus() ? n_tiles : 8LL * num_cus());
   hipStream_t st = (hipStream_t)stream;
@@ -105,7 +126,7 @@ extern "C" int mbpo_ensemble_mlp_forward(const mbpo_mlp_desc *mlp, const float *
   {                                                                             \
     rc = mbpo_ensure_lds<k_ensemble_forward<HH>>(lds, "ensemble_mlp_forward");          \
     if (rc != MBPO_OK) return rc;                                               \
-    hipLaunchKernelGGL(k_ensemble_forward<HH>, dim3(grid), dim3((HH / 16) * 64), lds, st, A); \
+    hipLaunchKernelGGL(k_ensemble_forward<HH>, dim3(grid), dim3(A.n_chains * 64), lds, st, A); \
   }
   if (H == 64) LAUNCH_ENS(64) else if (H == 128) LAUNCH_ENS(128) else LAUNCH_ENS(256)
 #undef LAUNCH_ENS
@@ -137,7 +158,7 @@ struct RolloutArgs {
   float *transitions;
   int row_len;
   // LDS geometry
-  int ld_x, ld_xu, ld_h, ld_y, n_slots;
+  int ld_x, ld_xu, ld_h, ld_y, n_chains, n_out;
 };
 
 // PendulumDynamics.next_state (dynamics/pendulum_dynamics.py:29-63), fp32, same operation order.
@@ -171,9 +192,9 @@ __device__ __forceinline__ float pendulum_reward(const float *x, float u, const 
 }
 
 template <int H>
-__global__ void __launch_bounds__((H / 16) * 64) k_model_rollout(RolloutArgs A) {
+__global__ void __launch_bounds__(512) k_model_rollout(RolloutArgs A) {
   extern __shared__ __align__(16) float smem[];
-  constexpr int NW = H / 16;
+  constexpr int HT = H / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int X = A.x_dim, U = A.u_dim, D = A.row_len;
   const int E = (A.system_kind == MBPO_SYS_ENSEMBLE) ? A.dyn.n_nets : 0;
@@ -185,11 +206,12 @@ __global__ void __launch_bounds__((H / 16) * 64) k_model_rollout(RolloutArgs A) 
   float *s_first = s_obs + 16 * A.ld_x;          // [16][ld_x]
   float *s_pin = s_first + 16 * A.ld_x;          // [16][ld_x]  normalised obs (policy input)
   float *s_xu = s_pin + 16 * A.ld_x;             // [16][ld_xu] dynamics input [x,u]
-  float *s_hA = s_xu + 16 * A.ld_xu;             // [n_slots][16][ld_h]
-  float *s_hB = s_hA + A.n_slots * 16 * A.ld_h;  // [n_slots][16][ld_h]
-  float *s_y = s_hB + A.n_slots * 16 * A.ld_h;   // [n_slots][16][ld_y]
-  float *s_row = s_y + A.n_slots * 16 * A.ld_y;  // [16][D]
-  float *s_steps = s_row + 16 * D;               // [16]
+  const int T = 16 * A.ld_h;
+  float *s_pp = s_xu + 16 * A.ld_xu;             // [n_chains][2] hidden tiles (ping-pong per chain)
+  float *s_hA = s_pp;                            // also scratch between chains
+  float *s_y = s_pp + A.n_chains * 2 * T;        // [n_out][16][ld_y]
+  float *s_row = s_y + A.n_out * 16 * A.ld_y;    // [16][D4]
+  float *s_steps = s_row + 16 * ((D + 3) & ~3);  // [16]
   float *s_done = s_steps + 16;                  // [16]
   float *s_rew = s_done + 16;                    // [16]
 
@@ -234,8 +256,9 @@ __global__ void __launch_bounds__((H / 16) * 64) k_model_rollout(RolloutArgs A) 
         s_pin[r * A.ld_x + c] = A.norm_mean ? (o - A.norm_mean[c]) / A.norm_std[c] : o;
       }
       __syncthreads();
-      // ---- policy MLP -> logits in s_y[0] ----
-      mlp_forward_tile<H>(A.policy, 1, s_pin, 0, A.ld_x, s_hA, s_hB, A.ld_h, s_y, A.ld_y, wave, NW, lane);
+      // ---- policy MLP -> logits in s_y[0] (one wave walks the whole chain) ----
+      if (wave == 0) wave_mlp_fwd<HT>(A.policy, A.policy.params, s_pin, A.ld_x, s_pp, s_pp + T, nullptr, nullptr, A.ld_h, s_y, A.ld_y, lane);
+      __syncthreads();
       // ---- NormalTanh sample (parametric_distribution.py:97-124) + AutoReset pre-step (training.py:119-124) ----
       for (int idx = tid; idx < 16 * U; idx += nthreads) {
         int r = idx / U, d = idx - r * U;
@@ -284,7 +307,14 @@ __global__ void __launch_bounds__((H / 16) * 64) k_model_rollout(RolloutArgs A) 
       // ---- EpisodeWrapper inner scan over action_repeat (training.py:91-97) ----
       for (int ar = 0; ar < AR; ++ar) {
         if (A.system_kind == MBPO_SYS_ENSEMBLE) {
-          mlp_forward_tile<H>(A.dyn, E, s_xu, 0, A.ld_xu, s_hA, s_hB, A.ld_h, s_y, A.ld_y, wave, NW, lane);
+          // one wave per ensemble member, n_chains members side by side
+          for (int e0 = 0; e0 < E; e0 += A.n_chains) {
+            const int e = e0 + wave;
+            if (e < E)
+              wave_mlp_fwd<HT>(A.dyn, A.dyn.params + (long long)e * A.dyn.net_stride, s_xu, A.ld_xu, s_pp + wave * 2 * T,
+                               s_pp + wave * 2 * T + T, nullptr, nullptr, A.ld_h, s_y + e * 16 * A.ld_y, A.ld_y, lane);
+          }
+          __syncthreads();
         }
         // reward uses the pre-step x and the action; next state from the system
         if (tid < 16) {
@@ -471,15 +501,16 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   A.seed = d->seed; A.offset = d->offset; A.offset_dev = d->offset_dev;
   A.obs = d->obs; A.first_obs = d->first_obs; A.steps = d->steps; A.done = d->done;
   A.transitions = d->transitions; A.row_len = d->row_len;
-  A.n_slots = E > 1 ? E : 1;
-  A.ld_x = X | 1;
-  A.ld_xu = (X + U) | 1;
-  A.ld_h = H + 1;
+  A.n_out = E > 1 ? E : 1;
+  A.ld_x = up4(X) + 4;
+  A.ld_xu = up4(X + U) + 4;
+  A.ld_h = H + 4;
   int ymax = 2 * U > dyn_out ? 2 * U : dyn_out;
-  A.ld_y = ymax | 1;
-  size_t lds_f = 3ull * 16 * A.ld_x + 16ull * A.ld_xu + 2ull * A.n_slots * 16 * A.ld_h + (size_t)A.n_slots * 16 * A.ld_y +
-                 16ull * d->row_len + 48;
-  size_t lds = lds_f * sizeof(float);
+  A.ld_y = up4(ymax) + 4;
+  const size_t fixed_f = 3ull * 16 * A.ld_x + 16ull * A.ld_xu + (size_t)A.n_out * 16 * A.ld_y + 16ull * up4(d->row_len) + 48;
+  A.n_chains = pick_chains(E, fixed_f, A.ld_h);
+  MBPO_REQUIRE(A.n_chains >= 1, MBPO_ERR_UNSUPPORTED, "model_rollout: shapes do not fit 160 KiB of LDS");
+  size_t lds = (fixed_f + 2ull * A.n_chains * 16 * A.ld_h) * sizeof(float);
   long long n_tiles = (d->n_envs + 15) >> 4;
   int grid = (int)(n_tiles < 4LL * num_cus() ? n_tiles : 4LL * num_cus());
   hipStream_t st = (hipStream_t)stream;
@@ -487,7 +518,7 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   {                                                                          \
     rc = mbpo_ensure_lds<k_model_rollout<HH>>(lds, "model_rollout");                 \
     if (rc != MBPO_OK) return rc;                                            \
-    hipLaunchKernelGGL(k_model_rollout<HH>, dim3(grid), dim3((HH / 16) * 64), lds, st, A); \
+    hipLaunchKernelGGL(k_model_rollout<HH>, dim3(grid), dim3(A.n_chains * 64), lds, st, A); \
   }
   if (H == 64) LAUNCH_RO(64) else if (H == 128) LAUNCH_RO(128) else LAUNCH_RO(256)
 #undef LAUNCH_RO

@@ -12,7 +12,7 @@
 // Algorithmic work per sample per sgd_step: 2*(5P + 12Q) FLOP — latency-bound at B=256, hence the
 // few fat launches and the slab scheme instead of a tree of small kernels.
 #include "common.hpp"
-#include "mlp_tile.hpp"
+#include "wave_mlp.hpp"
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
 #define LOG_2 0.69314718055994530942f
@@ -44,51 +44,65 @@ __device__ __forceinline__ ActSample normal_tanh_sample(float loc, float raw, fl
   return o;
 }
 
+// Workgroup = 4 waves = one 16-sample tile in one ROLE; each wave walks whole (tile, network) chains (wave_mlp.hpp).
+//   CRITIC role                                   ACTOR(+alpha) role
+//   P1  w0: pi(s') fwd   w1: Q1(s,a) fwd+store    P1  w0: pi(s) fwd+store
+//                        w2: Q2(s,a) fwd+store
+//   -- sample a', log pi'                         -- sample alpha/actor actions
+//   P2  w0: Qtgt1(s',a') w1: Qtgt2(s',a')         P2  w0: Q1(s,a~) fwd (z kept)  w1: Q2(s,a~)
+//   -- target y, errors, dL/dq                    -- min_q, dL/dq
+//   P3  per layer, one barrier each:              P3  w0: Q1 input-gradient chain   w1: Q2 chain
+//       w0/w1: Q1/Q2 dgrad   w2/w3: Q1/Q2 wgrad   -- dL/dlogits
+//                                                 P4  per layer: w0: pi dgrad   w1: pi wgrad
 template <int H>
-__global__ void __launch_bounds__((H / 16) * 64) k_sac_fwd_bwd(SacArgs A) {
+__global__ void __launch_bounds__(256) k_sac_fwd_bwd(SacArgs A) {
   extern __shared__ __align__(16) float smem[];
-  constexpr int NW = H / 16;
+  constexpr int HT = H / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int role = blockIdx.x & 1;  // 0 = critic, 1 = actor(+alpha)
   const int tile = blockIdx.x >> 1;
   const int X = A.X, U = A.U, D = A.D, B = A.B;
   const int row0 = tile * 16;
   const int ld_x = A.ld_x, ld_xu = A.ld_xu, ld_h = A.ld_h, ld_y = A.ld_y, LH = A.LH;
-  const int hns = 16 * ld_h;  // per-net stride of a hidden tile
+  const int T = 16 * ld_h;  // one hidden tile
 
-  // ---- LDS carve ----
-  float *s_row = smem;                      // [16][D]
-  float *s_sn = s_row + 16 * D;             // [16][ld_x]   normalised obs
+  // ---- LDS carve (every region a multiple of 4 floats: rows stay 16-byte aligned) ----
+  float *s_row = smem;                      // [16][D4]
+  const int D4 = (D + 3) & ~3;
+  float *s_sn = s_row + 16 * D4;            // [16][ld_x]   normalised obs
   float *s_sn2 = s_sn + 16 * ld_x;          // [16][ld_x]   normalised next obs
   float *s_qin = s_sn2 + 16 * ld_x;         // [16][ld_xu]  [sn, a]
   float *s_qin2 = s_qin + 16 * ld_xu;       // [16][ld_xu]  [s'n, a']
-  float *s_pp = s_qin2 + 16 * ld_xu;        // [2][2][16][ld_h]  ping-pong hidden / delta buffers (2 nets)
-  float *s_store = s_pp + 4 * hns;          // [LH*4][16][ld_h]  stored z / h (role dependent split)
-  float *s_y = s_store + LH * 4 * hns;      // [2][16][ld_y]
-  float *s_dy = s_y + 2 * 16 * ld_y;        // [2][16][ld_y]
-  float *s_dx = s_dy + 2 * 16 * ld_y;       // [2][16][ld_xu]
-  float *s_eps = s_dx + 2 * 16 * ld_xu;     // [16][U]
-  float *s_a = s_eps + 16 * U;              // [16][U]
-  float *s_sig = s_a + 16 * U;              // [16][U]
-  float *s_raw = s_sig + 16 * U;            // [16][U]
-  float *s_lp = s_raw + 16 * U;             // [16][U] per-dim log-prob (critic: next action; actor: actor-loss sample)
-  float *s_lpa = s_lp + 16 * U;             // [16][U] per-dim log-prob of the alpha-loss sample
-  float *s_scal = s_lpa + 16 * U;           // [4][16] per-row scalars
-  float *s_pp_a = s_pp, *s_pp_b = s_pp + 2 * hns;
+  float *s_pp = s_qin2 + 16 * ld_xu;        // 4 tiles: ping-pong hidden / delta tiles
+  float *s_store = s_pp + 4 * T;            // 4*LH tiles: stored z / h
+  float *s_y = s_store + 4 * LH * T;        // [3][16][ld_y]  network outputs
+  float *s_dy = s_y + 3 * 16 * ld_y;        // [2][16][ld_y]  output gradients
+  float *s_dx = s_dy + 2 * 16 * ld_y;       // [2][16][ld_xu] critic input gradients (actor role)
+  const int U4 = (16 * U + 3) & ~3;
+  float *s_eps = s_dx + 2 * 16 * ld_xu;     // [16][U] ...
+  float *s_a = s_eps + U4;
+  float *s_sig = s_a + U4;
+  float *s_raw = s_sig + U4;
+  float *s_lp = s_raw + U4;
+  float *s_lpa = s_lp + U4;
+  float *s_scal = s_lpa + U4;               // [4][16]
 
   const float alpha = expf(A.log_alpha[0]);
   const float invB = 1.0f / (float)B;
   const unsigned long long rng_off = A.offset + (unsigned long long)A.step_count[0];
+  const float *pi_p = A.pi.params, *q1_p = A.q.params, *q2_p = A.q.params + A.q.net_stride;
+  const float *t1_p = A.qt.params, *t2_p = A.qt.params + A.qt.net_stride;
+  const int QL = A.q.n_layers, PL = A.pi.n_layers;
 
   // ---- load the tile's transitions; normalise observations (q and policy both preprocess obs: sac/networks.py:76-78,96-98)
   for (int idx = tid; idx < 16 * D; idx += nthreads) {
     int r = idx / D, c = idx - r * D;
-    s_row[idx] = (row0 + r < B) ? A.batch[(long long)(row0 + r) * D + c] : 0.f;
+    s_row[r * D4 + c] = (row0 + r < B) ? A.batch[(long long)(row0 + r) * D + c] : 0.f;
   }
   __syncthreads();
   for (int idx = tid; idx < 16 * X; idx += nthreads) {
     int r = idx / X, c = idx - r * X;
-    float o = s_row[r * D + c], o2 = s_row[r * D + X + U + 2 + c];
+    float o = s_row[r * D4 + c], o2 = s_row[r * D4 + X + U + 2 + c];
     if (A.norm_mean) {
       o = (o - A.norm_mean[c]) / A.norm_std[c];
       o2 = (o2 - A.norm_mean[c]) / A.norm_std[c];
@@ -101,69 +115,92 @@ __global__ void __launch_bounds__((H / 16) * 64) k_sac_fwd_bwd(SacArgs A) {
   if (role == 0) {
     for (int idx = tid; idx < 16 * U; idx += nthreads) {
       int r = idx / U, d = idx - r * U;
-      s_qin[r * ld_xu + X + d] = s_row[r * D + X + d];  // transitions.action
+      s_qin[r * ld_xu + X + d] = s_row[r * D4 + X + d];  // transitions.action
     }
   }
   __syncthreads();
 
   if (role == 0) {
     // ============================== CRITIC (sac/losses.py:74-110) ==============================
-    // next_dist_params = policy(next_observation); next_action ~ ; next_log_prob          (:80-86)
-    mlp_forward_tile<H>(A.pi, 1, s_sn2, 0, ld_x, s_pp_a, s_pp_b, ld_h, s_y, ld_y, wave, NW, lane);
+    float *z1 = s_store, *h1 = s_store + LH * T, *z2 = s_store + 2 * LH * T, *h2 = s_store + 3 * LH * T;
+    float *y_pi = s_y, *y_q1 = s_y + 16 * ld_y, *y_q2 = s_y + 2 * 16 * ld_y;
+    // P1: next_dist_params = policy(next_observation) (:80-81)  ||  q_old_action = q(q_params, obs, action) (:78-79)
+    if (wave == 0) wave_mlp_fwd<HT>(A.pi, pi_p, s_sn2, ld_x, s_pp, s_pp + T, nullptr, nullptr, ld_h, y_pi, ld_y, lane);
+    else if (wave == 1) wave_mlp_fwd<HT>(A.q, q1_p, s_qin, ld_xu, nullptr, nullptr, z1, h1, ld_h, y_q1, ld_y, lane);
+    else if (wave == 2) wave_mlp_fwd<HT>(A.q, q2_p, s_qin, ld_xu, nullptr, nullptr, z2, h2, ld_h, y_q2, ld_y, lane);
+    __syncthreads();
+    // next_action ~ ; next_log_prob (:82-87)
     for (int idx = tid; idx < 16 * U; idx += nthreads) {
       int r = idx / U, d = idx - r * U;
       long long nidx = (long long)(row0 + r) * U + d;
       float eps = 0.f;
       if (row0 + r < B)
         eps = A.noise_critic ? A.noise_critic[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_CRITIC, (unsigned long long)nidx);
-      ActSample sm = normal_tanh_sample(s_y[r * ld_y + d], s_y[r * ld_y + U + d], eps);
-      s_qin2[r * ld_xu + X + d] = sm.a;  // postprocess(next_action)                              (:87)
+      ActSample sm = normal_tanh_sample(y_pi[r * ld_y + d], y_pi[r * ld_y + U + d], eps);
+      s_qin2[r * ld_xu + X + d] = sm.a;  // postprocess(next_action)
       s_lp[idx] = sm.lp;
     }
-    __syncthreads();
-    // next_q = q(target_q_params, next_observation, next_action)                                 (:88-89)
-    mlp_forward_tile<H>(A.qt, 2, s_qin2, 0, ld_xu, s_pp_a, s_pp_b, ld_h, s_y, ld_y, wave, NW, lane);
-    if (tid < 16) {
-      const int r = tid;
-      float nlp = 0.f;
-      for (int d = 0; d < U; ++d) nlp += s_lp[r * U + d];
-      const float nq = fminf(s_y[r * ld_y], s_y[(16 + r) * ld_y]);
-      const float next_v = nq - alpha * nlp;                                                   // :89
-      const float rew = s_row[r * D + X + U], disc = s_row[r * D + X + U + 1];
-      s_scal[r] = rew * A.reward_scaling + disc * A.discounting * next_v;                        // target_q :101-103
+    if (tid < 32) {  // keep q_old_action out of the way of P2's outputs
+      const int k = tid >> 4, r = tid & 15;
+      s_scal[32 + tid] = (k == 0 ? y_q1 : y_q2)[r * ld_y];
     }
     __syncthreads();
-    // q_old_action = q(q_params, observation, action)                                            (:78-79)
-    float *zq = s_store, *hq = s_store + LH * 2 * hns;
-    mlp_forward_tile_store<H>(A.q, 2, s_qin, 0, ld_xu, zq, hq, false, ld_h, s_y, ld_y, wave, NW, lane);
+    // P2: next_q = q(target_q_params, next_observation, next_action) (:88-89)
+    if (wave == 0) wave_mlp_fwd<HT>(A.qt, t1_p, s_qin2, ld_xu, s_pp, s_pp + T, nullptr, nullptr, ld_h, y_q1, ld_y, lane);
+    else if (wave == 1) wave_mlp_fwd<HT>(A.qt, t2_p, s_qin2, ld_xu, s_pp + 2 * T, s_pp + 3 * T, nullptr, nullptr, ld_h, y_q2, ld_y, lane);
+    __syncthreads();
     if (tid < 32) {
       const int k = tid >> 4, r = tid & 15;
       const bool ok = row0 + r < B;
-      const float trunc = s_row[r * D + D - 1];
-      const float err = ok ? (s_y[(k * 16 + r) * ld_y] - s_scal[r]) * (1.f - trunc) : 0.f;      // q_error :104-108
-      s_scal[16 + tid] = err * err;
+      float nlp = 0.f;
+      for (int d = 0; d < U; ++d) nlp += s_lp[r * U + d];
+      const float nq = fminf(y_q1[r * ld_y], y_q2[r * ld_y]);
+      const float next_v = nq - alpha * nlp;                                                   // :89
+      const float rew = s_row[r * D4 + X + U], disc = s_row[r * D4 + X + U + 1];
+      const float target = rew * A.reward_scaling + disc * A.discounting * next_v;             // :101-103
+      const float trunc = s_row[r * D4 + D - 1];
+      const float err = ok ? (s_scal[32 + tid] - target) * (1.f - trunc) : 0.f;               // q_error :104-108
+      s_scal[tid] = err * err;
       // loss = 0.5*mean(err^2) over [B,2]  ->  dL/dq = err*(1-trunc)/(2B)
       s_dy[(k * 16 + r) * ld_y] = err * (1.f - trunc) * (0.5f * invB);
     }
     __syncthreads();
+    // P3: backward through both critics, one layer per barrier: waves 0/1 push delta down, waves 2/3 form dW/db
     float *slab = A.slab_q + (long long)tile * (2 * A.q.n_params);
-    mlp_backward_tile<H>(A.q, 2, s_qin, 0, ld_xu, zq, hq, ld_h, s_dy, ld_y, s_pp_a, s_pp_b, slab, nullptr, wave, NW, lane,
-                         tid, nthreads);
+    {
+      const int net = wave & 1;
+      const float *qp = net ? q2_p : q1_p;
+      const float *zb = net ? z2 : z1, *hb = net ? h2 : h1;
+      float *d0 = s_pp + (2 * net) * T, *d1 = d0 + T;
+      const float *dcur = s_dy + net * 16 * ld_y;
+      int ldc = ld_y;
+      for (int l = QL - 1; l >= 0; --l) {
+        float *dn = (l & 1) ? d1 : d0;
+        if (wave < 2) wave_bwd_dgrad_step<HT>(A.q, qp, l, dcur, ldc, zb, ld_h, dn, nullptr, ld_xu, lane);
+        else wave_bwd_wgrad_step<HT>(A.q, l, s_qin, ld_xu, hb, ld_h, dcur, ldc, slab + (long long)net * A.q.net_stride, lane);
+        __syncthreads();
+        dcur = dn;
+        ldc = ld_h;
+      }
+    }
     if (tid == 0) {
       float acc = 0.f;
-      for (int i = 0; i < 32; ++i) acc += s_scal[16 + i];
+      for (int i = 0; i < 32; ++i) acc += s_scal[i];
       A.slab_ex[tile * 4 + 0] = acc;
     }
   } else {
     // ============================== ACTOR + ALPHA (sac/losses.py:61-72, 112-125) ==============================
-    float *zp = s_store, *hp = s_store + LH * hns;            // policy: z, h   [LH][1][16][ld_h] each
-    float *zq = s_store + 2 * LH * hns;                       // critics: z only [LH][2][16][ld_h]
-    mlp_forward_tile_store<H>(A.pi, 1, s_sn, 0, ld_x, zp, hp, false, ld_h, s_y, ld_y, wave, NW, lane);
+    float *zp = s_store, *hp = s_store + LH * T;               // policy: z, h
+    float *zq1 = s_store + 2 * LH * T, *zq2 = s_store + 3 * LH * T;   // critics: z only
+    float *y_pi = s_y, *y_q1 = s_y + 16 * ld_y, *y_q2 = s_y + 2 * 16 * ld_y;
+    // P1: dist_params = policy(observation)
+    if (wave == 0) wave_mlp_fwd<HT>(A.pi, pi_p, s_sn, ld_x, nullptr, nullptr, zp, hp, ld_h, y_pi, ld_y, lane);
+    __syncthreads();
     for (int idx = tid; idx < 16 * U; idx += nthreads) {
       int r = idx / U, d = idx - r * U;
       long long nidx = (long long)(row0 + r) * U + d;
       const bool ok = row0 + r < B;
-      const float loc = s_y[r * ld_y + d], raw = s_y[r * ld_y + U + d];
+      const float loc = y_pi[r * ld_y + d], raw = y_pi[r * ld_y + U + d];
       float e_al = 0.f, e_ac = 0.f;
       if (ok) {
         e_al = A.noise_alpha ? A.noise_alpha[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ALPHA, (unsigned long long)nidx);
@@ -180,8 +217,11 @@ __global__ void __launch_bounds__((H / 16) * 64) k_sac_fwd_bwd(SacArgs A) {
       s_qin[r * ld_xu + X + d] = sac.a;  // postprocess(action) (:120)
     }
     __syncthreads();
-    if (tid < 16) {
-      const int r = tid;
+    // P2: q_action = q(q_params, observation, action) with the OLD q_params (sac.py:253)   (:121-122)
+    if (wave == 0) wave_mlp_fwd<HT>(A.q, q1_p, s_qin, ld_xu, s_pp, s_pp + T, zq1, nullptr, ld_h, y_q1, ld_y, lane);
+    else if (wave == 1) wave_mlp_fwd<HT>(A.q, q2_p, s_qin, ld_xu, s_pp + 2 * T, s_pp + 3 * T, zq2, nullptr, ld_h, y_q2, ld_y, lane);
+    else if (wave == 2 && lane < 16) {
+      const int r = lane;
       const bool ok = row0 + r < B;
       float lp_al = 0.f, lp_ac = 0.f;
       for (int d = 0; d < U; ++d) {
@@ -193,12 +233,10 @@ __global__ void __launch_bounds__((H / 16) * 64) k_sac_fwd_bwd(SacArgs A) {
       s_scal[16 + r] = ok ? lp_ac : 0.f;
     }
     __syncthreads();
-    // q_action = q(q_params, observation, action)  with the OLD q_params (sac.py:253)              (:121-122)
-    mlp_forward_tile_store<H>(A.q, 2, s_qin, 0, ld_xu, zq, s_pp, true, ld_h, s_y, ld_y, wave, NW, lane);
     if (tid < 16) {
       const int r = tid;
       const bool ok = row0 + r < B;
-      const float q0 = s_y[r * ld_y], q1 = s_y[(16 + r) * ld_y];
+      const float q0 = y_q1[r * ld_y], q1 = y_q2[r * ld_y];
       const float mq = fminf(q0, q1);
       s_scal[32 + r] = ok ? (alpha * s_scal[16 + r] - mq) : 0.f;   // actor_loss = alpha*log_prob - min_q   (:123-124)
       // d(mean(-min_q))/dq_k: -1/B on the arg-min critic (ties split evenly, as jnp.min's gradient does)
@@ -212,9 +250,10 @@ __global__ void __launch_bounds__((H / 16) * 64) k_sac_fwd_bwd(SacArgs A) {
       s_dy[(16 + r) * ld_y] = g1;
     }
     __syncthreads();
-    // backward through the critics: input gradient only (no weight gradients: q_params are not the actor's variables)
-    mlp_backward_tile<H>(A.q, 2, s_qin, 0, ld_xu, zq, nullptr, ld_h, s_dy, ld_y, s_pp_a, s_pp_b, nullptr, s_dx, wave, NW,
-                         lane, tid, nthreads);
+    // P3: backward through the critics: input gradient only (q_params are not the actor's variables)
+    if (wave == 0) wave_mlp_bwd_input<HT>(A.q, q1_p, zq1, ld_h, s_dy, ld_y, s_pp, s_pp + T, s_dx, ld_xu, lane);
+    else if (wave == 1) wave_mlp_bwd_input<HT>(A.q, q2_p, zq2, ld_h, s_dy + 16 * ld_y, ld_y, s_pp + 2 * T, s_pp + 3 * T, s_dx + 16 * ld_xu, ld_xu, lane);
+    __syncthreads();
     for (int idx = tid; idx < 16 * U; idx += nthreads) {
       int r = idx / U, d = idx - r * U;
       const bool ok = row0 + r < B;
@@ -227,9 +266,21 @@ __global__ void __launch_bounds__((H / 16) * 64) k_sac_fwd_bwd(SacArgs A) {
       s_dy[r * ld_y + U + d] = ok ? gsig * sigmoid_f(raw) : 0.f;       // d/draw = d/dsigma * softplus'(raw)
     }
     __syncthreads();
+    // P4: backward through the policy, one layer per barrier: wave 0 pushes delta down, wave 1 forms dW/db
     float *slab = A.slab_pi + (long long)tile * A.pi.n_params;
-    mlp_backward_tile<H>(A.pi, 1, s_sn, 0, ld_x, zp, hp, ld_h, s_dy, ld_y, s_pp_a, s_pp_b, slab, nullptr, wave, NW, lane, tid,
-                         nthreads);
+    {
+      float *d0 = s_pp, *d1 = s_pp + T;
+      const float *dcur = s_dy;
+      int ldc = ld_y;
+      for (int l = PL - 1; l >= 0; --l) {
+        float *dn = (l & 1) ? d1 : d0;
+        if (wave == 0) wave_bwd_dgrad_step<HT>(A.pi, pi_p, l, dcur, ldc, zp, ld_h, dn, nullptr, ld_x, lane);
+        else if (wave == 1) wave_bwd_wgrad_step<HT>(A.pi, l, s_sn, ld_x, hp, ld_h, dcur, ldc, slab, lane);
+        __syncthreads();
+        dcur = dn;
+        ldc = ld_h;
+      }
+    }
     if (tid == 0) {
       float al = 0.f, ac = 0.f;
       for (int i = 0; i < 16; ++i) {
@@ -322,12 +373,16 @@ struct SacApplyArgs {
 __global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
   __shared__ float s_scale[3];
   const int tid = threadIdx.x;
-  if (tid < 3) {
-    float ss = 0.f;
-    for (int p = 0; p < A.n_parts; ++p) ss += A.ss_part[p * 3 + tid];
-    // [3P optax.clip_by_global_norm] g_norm = sqrt(sum g^2); g <- g if g_norm < max_norm else (g / g_norm) * max_norm
-    const float gnorm = sqrtf(ss) * A.grad_scale;
-    s_scale[tid] = gnorm;
+  {
+    // wave w < 3 reduces optimizer group w's sum-of-squares partials (fixed shuffle tree -> deterministic)
+    const int w = tid >> 6, lane = tid & 63;
+    if (w < 3) {
+      float ss = 0.f;
+      for (int p = lane; p < A.n_parts; p += 64) ss += A.ss_part[p * 3 + w];
+      ss = wave_sum64(ss);
+      // [3P optax.clip_by_global_norm] g_norm = sqrt(sum g^2); g <- g if g_norm < max_norm else (g / g_norm) * max_norm
+      if (lane == 0) s_scale[w] = sqrtf(ss) * A.grad_scale;
+    }
   }
   __syncthreads();
   const int NP = A.P + A.Q2 + 1;
@@ -421,13 +476,14 @@ static int sac_plan(const mbpo_sac_desc *d, SacPlan *pl, bool need_ptrs) {
   pl->LH = lhp > lhq ? lhp : lhq;
   pl->n_tiles = (d->batch_size + 15) / 16;
   pl->n_red = (pl->NP + 255) / 256;
-  pl->ld_x = d->x_dim | 1;
-  pl->ld_xu = (d->x_dim + d->u_dim) | 1;
-  pl->ld_h = Hp + 1;
-  pl->ld_y = (2 * d->u_dim) | 1;
+  auto up4 = [](int v) { return (v + 3) & ~3; };
+  pl->ld_x = up4(d->x_dim) + 4;
+  pl->ld_xu = up4(d->x_dim + d->u_dim) + 4;
+  pl->ld_h = Hp + 4;
+  pl->ld_y = up4(2 * d->u_dim) + 4;
   const int U = d->u_dim;
-  size_t f = 16ull * d->row_len + 2ull * 16 * pl->ld_x + 2ull * 16 * pl->ld_xu + 4ull * 16 * pl->ld_h +
-             (size_t)pl->LH * 4 * 16 * pl->ld_h + 4ull * 16 * pl->ld_y + 2ull * 16 * pl->ld_xu + 6ull * 16 * U + 64;
+  size_t f = 16ull * up4(d->row_len) + 2ull * 16 * pl->ld_x + 2ull * 16 * pl->ld_xu + 4ull * 16 * pl->ld_h +
+             (size_t)pl->LH * 4 * 16 * pl->ld_h + 5ull * 16 * pl->ld_y + 2ull * 16 * pl->ld_xu + 6ull * up4(16 * U) + 64;
   pl->lds = f * sizeof(float);
   pl->off_slab_pi = 0;
   pl->off_slab_q = pl->off_slab_pi + (long long)pl->n_tiles * pl->P;
@@ -473,7 +529,7 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream) 
     } else {
       rc = mbpo_ensure_lds<k_sac_fwd_bwd<128>>(pl.lds, "sac_grads");
       if (rc != MBPO_OK) return rc;
-      hipLaunchKernelGGL(k_sac_fwd_bwd<128>, dim3(2 * pl.n_tiles), dim3(512), pl.lds, st, A);
+      hipLaunchKernelGGL(k_sac_fwd_bwd<128>, dim3(2 * pl.n_tiles), dim3(256), pl.lds, st, A);
     }
   }
   if (!(phase_mask & 2)) {
