@@ -256,9 +256,14 @@ __global__ void __launch_bounds__(512) k_model_rollout(RolloutArgs A) {
         s_pin[r * A.ld_x + c] = A.norm_mean ? (o - A.norm_mean[c]) / A.norm_std[c] : o;
       }
       __syncthreads();
-      // ---- policy MLP -> logits in s_y[0] (one wave walks the whole chain) ----
-      if (wave == 0) wave_mlp_fwd<HT>(A.policy, A.policy.params, s_pin, A.ld_x, s_pp, s_pp + T, nullptr, nullptr, A.ld_h, s_y, A.ld_y, lane);
-      __syncthreads();
+      // ---- policy MLP -> logits in s_y[0]: waves 0..3 share the chain (column slices), one barrier per layer ----
+      {
+        FwdChain fc{&A.policy, A.policy.params, s_pin, A.ld_x, s_pp, s_pp + T, nullptr, nullptr, s_y};
+        for (int l = 0; l < A.policy.n_layers; ++l) {
+          if (wave < 4) group_fwd_step<HT, 4>(fc, l, A.ld_h, A.ld_y, wave, lane);
+          __syncthreads();
+        }
+      }
       // ---- NormalTanh sample (parametric_distribution.py:97-124) + AutoReset pre-step (training.py:119-124) ----
       for (int idx = tid; idx < 16 * U; idx += nthreads) {
         int r = idx / U, d = idx - r * U;
@@ -307,10 +312,10 @@ __global__ void __launch_bounds__(512) k_model_rollout(RolloutArgs A) {
       // ---- EpisodeWrapper inner scan over action_repeat (training.py:91-97) ----
       for (int ar = 0; ar < AR; ++ar) {
         if (A.system_kind == MBPO_SYS_ENSEMBLE) {
-          // one wave per ensemble member, n_chains members side by side
+          // one wave per ensemble member chain (no barrier inside a chain), n_chains members side by side
           for (int e0 = 0; e0 < E; e0 += A.n_chains) {
             const int e = e0 + wave;
-            if (e < E)
+            if (wave < A.n_chains && e < E)
               wave_mlp_fwd<HT>(A.dyn, A.dyn.params + (long long)e * A.dyn.net_stride, s_xu, A.ld_xu, s_pp + wave * 2 * T,
                                s_pp + wave * 2 * T + T, nullptr, nullptr, A.ld_h, s_y + e * 16 * A.ld_y, A.ld_y, lane);
           }
@@ -511,6 +516,7 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   A.n_chains = pick_chains(E, fixed_f, A.ld_h);
   MBPO_REQUIRE(A.n_chains >= 1, MBPO_ERR_UNSUPPORTED, "model_rollout: shapes do not fit 160 KiB of LDS");
   size_t lds = (fixed_f + 2ull * A.n_chains * 16 * A.ld_h) * sizeof(float);
+  const int n_waves = A.n_chains > 4 ? A.n_chains : 4;  // the policy chain is shared by waves 0..3
   long long n_tiles = (d->n_envs + 15) >> 4;
   int grid = (int)(n_tiles < 4LL * num_cus() ? n_tiles : 4LL * num_cus());
   hipStream_t st = (hipStream_t)stream;
@@ -518,7 +524,7 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   {                                                                          \
     rc = mbpo_ensure_lds<k_model_rollout<HH>>(lds, "model_rollout");                 \
     if (rc != MBPO_OK) return rc;                                            \
-    hipLaunchKernelGGL(k_model_rollout<HH>, dim3(grid), dim3(A.n_chains * 64), lds, st, A); \
+    hipLaunchKernelGGL(k_model_rollout<HH>, dim3(grid), dim3(n_waves * 64), lds, st, A); \
   }
   if (H == 64) LAUNCH_RO(64) else if (H == 128) LAUNCH_RO(128) else LAUNCH_RO(256)
 #undef LAUNCH_RO

@@ -44,21 +44,26 @@ __device__ __forceinline__ ActSample normal_tanh_sample(float loc, float raw, fl
   return o;
 }
 
-// Workgroup = 4 waves = one 16-sample tile in one ROLE; each wave walks whole (tile, network) chains (wave_mlp.hpp).
-//   CRITIC role                                   ACTOR(+alpha) role
-//   P1  w0: pi(s') fwd   w1: Q1(s,a) fwd+store    P1  w0: pi(s) fwd+store
-//                        w2: Q2(s,a) fwd+store
-//   -- sample a', log pi'                         -- sample alpha/actor actions
-//   P2  w0: Qtgt1(s',a') w1: Qtgt2(s',a')         P2  w0: Q1(s,a~) fwd (z kept)  w1: Q2(s,a~)
-//   -- target y, errors, dL/dq                    -- min_q, dL/dq
-//   P3  per layer, one barrier each:              P3  w0: Q1 input-gradient chain   w1: Q2 chain
-//       w0/w1: Q1/Q2 dgrad   w2/w3: Q1/Q2 wgrad   -- dL/dlogits
-//                                                 P4  per layer: w0: pi dgrad   w1: pi wgrad
+// Workgroup = 8 waves = one 16-sample tile in one ROLE.  Wave w = (chain c = w/2, sub = w%2): each network chain is
+// shared by 2 waves (column slices of H/2), chains advance side by side in lockstep, one workgroup barrier per layer
+// (wave_mlp.hpp "Lockstep groups").  The per-sgd_step critical path is ~16 layer-steps of ~32 MFMAs per wave.
+// (16 waves x 4 per chain halves the MFMAs per step again but caps a wave at 128 VGPRs: hipcc spilled ~850 registers.)
+//   CRITIC role                                     ACTOR(+alpha) role
+//   P1  c0: pi(s') fwd  c1: Q1(s,a) fwd+store       P1  c0: pi(s) fwd+store
+//                       c2: Q2(s,a) fwd+store
+//   -- sample a', log pi'                           -- sample alpha/actor actions
+//   P2  c0: Qtgt1(s',a')  c1: Qtgt2(s',a')          P2  c0: Q1(s,a~) fwd (z kept)  c1: Q2(s,a~)
+//   -- target y, errors, dL/dq                      -- min_q, dL/dq
+//   P3  per layer: c0/c1: Q1/Q2 dgrad               P3  per layer: c0/c1: Q1/Q2 input-gradient
+//                  c2/c3: Q1/Q2 wgrad               -- dL/dlogits
+//                                                   P4  per layer: c0: pi dgrad   c1: pi wgrad
 template <int H>
-__global__ void __launch_bounds__(256) k_sac_fwd_bwd(SacArgs A) {
+__global__ void __launch_bounds__(512) k_sac_fwd_bwd(SacArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
+  constexpr int SP = 2;   // waves per chain: 4 chains x 2 waves = 8 waves (512 threads keep 256 VGPRs per wave)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int chain = wave / SP, sub = wave % SP;
   const int role = blockIdx.x & 1;  // 0 = critic, 1 = actor(+alpha)
   const int tile = blockIdx.x >> 1;
   const int X = A.X, U = A.U, D = A.D, B = A.B;
@@ -93,6 +98,8 @@ __global__ void __launch_bounds__(256) k_sac_fwd_bwd(SacArgs A) {
   const float *pi_p = A.pi.params, *q1_p = A.q.params, *q2_p = A.q.params + A.q.net_stride;
   const float *t1_p = A.qt.params, *t2_p = A.qt.params + A.qt.net_stride;
   const int QL = A.q.n_layers, PL = A.pi.n_layers;
+  const int Lmax = QL > PL ? QL : PL;
+  float *y_pi = s_y, *y_q1 = s_y + 16 * ld_y, *y_q2 = s_y + 2 * 16 * ld_y;
 
   // ---- load the tile's transitions; normalise observations (q and policy both preprocess obs: sac/networks.py:76-78,96-98)
   for (int idx = tid; idx < 16 * D; idx += nthreads) {
@@ -123,12 +130,17 @@ __global__ void __launch_bounds__(256) k_sac_fwd_bwd(SacArgs A) {
   if (role == 0) {
     // ============================== CRITIC (sac/losses.py:74-110) ==============================
     float *z1 = s_store, *h1 = s_store + LH * T, *z2 = s_store + 2 * LH * T, *h2 = s_store + 3 * LH * T;
-    float *y_pi = s_y, *y_q1 = s_y + 16 * ld_y, *y_q2 = s_y + 2 * 16 * ld_y;
     // P1: next_dist_params = policy(next_observation) (:80-81)  ||  q_old_action = q(q_params, obs, action) (:78-79)
-    if (wave == 0) wave_mlp_fwd<HT>(A.pi, pi_p, s_sn2, ld_x, s_pp, s_pp + T, nullptr, nullptr, ld_h, y_pi, ld_y, lane);
-    else if (wave == 1) wave_mlp_fwd<HT>(A.q, q1_p, s_qin, ld_xu, nullptr, nullptr, z1, h1, ld_h, y_q1, ld_y, lane);
-    else if (wave == 2) wave_mlp_fwd<HT>(A.q, q2_p, s_qin, ld_xu, nullptr, nullptr, z2, h2, ld_h, y_q2, ld_y, lane);
-    __syncthreads();
+    {
+      FwdChain fc;
+      if (chain == 0) fc = FwdChain{&A.pi, pi_p, s_sn2, ld_x, s_pp, s_pp + T, nullptr, nullptr, y_pi};
+      else if (chain == 1) fc = FwdChain{&A.q, q1_p, s_qin, ld_xu, nullptr, nullptr, z1, h1, y_q1};
+      else fc = FwdChain{&A.q, q2_p, s_qin, ld_xu, nullptr, nullptr, z2, h2, y_q2};
+      for (int l = 0; l < Lmax; ++l) {
+        if (chain < 3) group_fwd_step<HT, SP>(fc, l, ld_h, ld_y, sub, lane);
+        __syncthreads();
+      }
+    }
     // next_action ~ ; next_log_prob (:82-87)
     for (int idx = tid; idx < 16 * U; idx += nthreads) {
       int r = idx / U, d = idx - r * U;
@@ -146,9 +158,15 @@ __global__ void __launch_bounds__(256) k_sac_fwd_bwd(SacArgs A) {
     }
     __syncthreads();
     // P2: next_q = q(target_q_params, next_observation, next_action) (:88-89)
-    if (wave == 0) wave_mlp_fwd<HT>(A.qt, t1_p, s_qin2, ld_xu, s_pp, s_pp + T, nullptr, nullptr, ld_h, y_q1, ld_y, lane);
-    else if (wave == 1) wave_mlp_fwd<HT>(A.qt, t2_p, s_qin2, ld_xu, s_pp + 2 * T, s_pp + 3 * T, nullptr, nullptr, ld_h, y_q2, ld_y, lane);
-    __syncthreads();
+    {
+      FwdChain fc;
+      if (chain == 0) fc = FwdChain{&A.qt, t1_p, s_qin2, ld_xu, s_pp, s_pp + T, nullptr, nullptr, y_q1};
+      else fc = FwdChain{&A.qt, t2_p, s_qin2, ld_xu, s_pp + 2 * T, s_pp + 3 * T, nullptr, nullptr, y_q2};
+      for (int l = 0; l < QL; ++l) {
+        if (chain < 2) group_fwd_step<HT, SP>(fc, l, ld_h, ld_y, sub, lane);
+        __syncthreads();
+      }
+    }
     if (tid < 32) {
       const int k = tid >> 4, r = tid & 15;
       const bool ok = row0 + r < B;
@@ -165,10 +183,10 @@ __global__ void __launch_bounds__(256) k_sac_fwd_bwd(SacArgs A) {
       s_dy[(k * 16 + r) * ld_y] = err * (1.f - trunc) * (0.5f * invB);
     }
     __syncthreads();
-    // P3: backward through both critics, one layer per barrier: waves 0/1 push delta down, waves 2/3 form dW/db
+    // P3: backward through both critics, one layer per barrier: chains 0/1 push delta down, chains 2/3 form dW/db
     float *slab = A.slab_q + (long long)tile * (2 * A.q.n_params);
     {
-      const int net = wave & 1;
+      const int net = chain & 1;
       const float *qp = net ? q2_p : q1_p;
       const float *zb = net ? z2 : z1, *hb = net ? h2 : h1;
       float *d0 = s_pp + (2 * net) * T, *d1 = d0 + T;
@@ -176,8 +194,8 @@ __global__ void __launch_bounds__(256) k_sac_fwd_bwd(SacArgs A) {
       int ldc = ld_y;
       for (int l = QL - 1; l >= 0; --l) {
         float *dn = (l & 1) ? d1 : d0;
-        if (wave < 2) wave_bwd_dgrad_step<HT>(A.q, qp, l, dcur, ldc, zb, ld_h, dn, nullptr, ld_xu, lane);
-        else wave_bwd_wgrad_step<HT>(A.q, l, s_qin, ld_xu, hb, ld_h, dcur, ldc, slab + (long long)net * A.q.net_stride, lane);
+        if (chain < 2) group_bwd_dgrad_layer<HT, SP>(A.q, qp, l, dcur, ldc, zb, ld_h, dn, nullptr, ld_xu, sub, lane);
+        else group_bwd_wgrad_layer<HT, SP>(A.q, l, s_qin, ld_xu, hb, ld_h, dcur, ldc, slab + (long long)net * A.q.net_stride, sub, lane);
         __syncthreads();
         dcur = dn;
         ldc = ld_h;
@@ -192,10 +210,14 @@ __global__ void __launch_bounds__(256) k_sac_fwd_bwd(SacArgs A) {
     // ============================== ACTOR + ALPHA (sac/losses.py:61-72, 112-125) ==============================
     float *zp = s_store, *hp = s_store + LH * T;               // policy: z, h
     float *zq1 = s_store + 2 * LH * T, *zq2 = s_store + 3 * LH * T;   // critics: z only
-    float *y_pi = s_y, *y_q1 = s_y + 16 * ld_y, *y_q2 = s_y + 2 * 16 * ld_y;
     // P1: dist_params = policy(observation)
-    if (wave == 0) wave_mlp_fwd<HT>(A.pi, pi_p, s_sn, ld_x, nullptr, nullptr, zp, hp, ld_h, y_pi, ld_y, lane);
-    __syncthreads();
+    {
+      FwdChain fc{&A.pi, pi_p, s_sn, ld_x, nullptr, nullptr, zp, hp, y_pi};
+      for (int l = 0; l < PL; ++l) {
+        if (chain == 0) group_fwd_step<HT, SP>(fc, l, ld_h, ld_y, sub, lane);
+        __syncthreads();
+      }
+    }
     for (int idx = tid; idx < 16 * U; idx += nthreads) {
       int r = idx / U, d = idx - r * U;
       long long nidx = (long long)(row0 + r) * U + d;
@@ -218,21 +240,27 @@ __global__ void __launch_bounds__(256) k_sac_fwd_bwd(SacArgs A) {
     }
     __syncthreads();
     // P2: q_action = q(q_params, observation, action) with the OLD q_params (sac.py:253)   (:121-122)
-    if (wave == 0) wave_mlp_fwd<HT>(A.q, q1_p, s_qin, ld_xu, s_pp, s_pp + T, zq1, nullptr, ld_h, y_q1, ld_y, lane);
-    else if (wave == 1) wave_mlp_fwd<HT>(A.q, q2_p, s_qin, ld_xu, s_pp + 2 * T, s_pp + 3 * T, zq2, nullptr, ld_h, y_q2, ld_y, lane);
-    else if (wave == 2 && lane < 16) {
-      const int r = lane;
-      const bool ok = row0 + r < B;
-      float lp_al = 0.f, lp_ac = 0.f;
-      for (int d = 0; d < U; ++d) {
-        lp_al += s_lpa[r * U + d];
-        lp_ac += s_lp[r * U + d];
+    {
+      FwdChain fc;
+      if (chain == 0) fc = FwdChain{&A.q, q1_p, s_qin, ld_xu, s_pp, s_pp + T, zq1, nullptr, y_q1};
+      else fc = FwdChain{&A.q, q2_p, s_qin, ld_xu, s_pp + 2 * T, s_pp + 3 * T, zq2, nullptr, y_q2};
+      if (wave == 4 && lane < 16) {
+        const int r = lane;
+        const bool ok = row0 + r < B;
+        float lp_al = 0.f, lp_ac = 0.f;
+        for (int d = 0; d < U; ++d) {
+          lp_al += s_lpa[r * U + d];
+          lp_ac += s_lp[r * U + d];
+        }
+        // alpha_loss = alpha * stop_gradient(-log_prob - target_entropy); d/dlog_alpha = the same value   (:70-72)
+        s_scal[r] = ok ? alpha * (-lp_al - A.target_entropy) : 0.f;
+        s_scal[16 + r] = ok ? lp_ac : 0.f;
       }
-      // alpha_loss = alpha * stop_gradient(-log_prob - target_entropy); d/dlog_alpha = the same value   (:70-72)
-      s_scal[r] = ok ? alpha * (-lp_al - A.target_entropy) : 0.f;
-      s_scal[16 + r] = ok ? lp_ac : 0.f;
+      for (int l = 0; l < QL; ++l) {
+        if (chain < 2) group_fwd_step<HT, SP>(fc, l, ld_h, ld_y, sub, lane);
+        __syncthreads();
+      }
     }
-    __syncthreads();
     if (tid < 16) {
       const int r = tid;
       const bool ok = row0 + r < B;
@@ -251,9 +279,21 @@ __global__ void __launch_bounds__(256) k_sac_fwd_bwd(SacArgs A) {
     }
     __syncthreads();
     // P3: backward through the critics: input gradient only (q_params are not the actor's variables)
-    if (wave == 0) wave_mlp_bwd_input<HT>(A.q, q1_p, zq1, ld_h, s_dy, ld_y, s_pp, s_pp + T, s_dx, ld_xu, lane);
-    else if (wave == 1) wave_mlp_bwd_input<HT>(A.q, q2_p, zq2, ld_h, s_dy + 16 * ld_y, ld_y, s_pp + 2 * T, s_pp + 3 * T, s_dx + 16 * ld_xu, ld_xu, lane);
-    __syncthreads();
+    {
+      const int net = chain & 1;
+      const float *qp = net ? q2_p : q1_p;
+      const float *zb = net ? zq2 : zq1;
+      float *d0 = s_pp + (2 * net) * T, *d1 = d0 + T;
+      const float *dcur = s_dy + net * 16 * ld_y;
+      int ldc = ld_y;
+      for (int l = QL - 1; l >= 0; --l) {
+        float *dn = (l & 1) ? d1 : d0;
+        if (chain < 2) group_bwd_dgrad_layer<HT, SP>(A.q, qp, l, dcur, ldc, zb, ld_h, dn, s_dx + net * 16 * ld_xu, ld_xu, sub, lane);
+        __syncthreads();
+        dcur = dn;
+        ldc = ld_h;
+      }
+    }
     for (int idx = tid; idx < 16 * U; idx += nthreads) {
       int r = idx / U, d = idx - r * U;
       const bool ok = row0 + r < B;
@@ -266,7 +306,7 @@ __global__ void __launch_bounds__(256) k_sac_fwd_bwd(SacArgs A) {
       s_dy[r * ld_y + U + d] = ok ? gsig * sigmoid_f(raw) : 0.f;       // d/draw = d/dsigma * softplus'(raw)
     }
     __syncthreads();
-    // P4: backward through the policy, one layer per barrier: wave 0 pushes delta down, wave 1 forms dW/db
+    // P4: backward through the policy, one layer per barrier: chain 0 pushes delta down, chain 1 forms dW/db
     float *slab = A.slab_pi + (long long)tile * A.pi.n_params;
     {
       float *d0 = s_pp, *d1 = s_pp + T;
@@ -274,8 +314,8 @@ __global__ void __launch_bounds__(256) k_sac_fwd_bwd(SacArgs A) {
       int ldc = ld_y;
       for (int l = PL - 1; l >= 0; --l) {
         float *dn = (l & 1) ? d1 : d0;
-        if (wave == 0) wave_bwd_dgrad_step<HT>(A.pi, pi_p, l, dcur, ldc, zp, ld_h, dn, nullptr, ld_x, lane);
-        else if (wave == 1) wave_bwd_wgrad_step<HT>(A.pi, l, s_sn, ld_x, hp, ld_h, dcur, ldc, slab, lane);
+        if (chain == 0) group_bwd_dgrad_layer<HT, SP>(A.pi, pi_p, l, dcur, ldc, zp, ld_h, dn, nullptr, ld_x, sub, lane);
+        else if (chain == 1) group_bwd_wgrad_layer<HT, SP>(A.pi, l, s_sn, ld_x, hp, ld_h, dcur, ldc, slab, sub, lane);
         __syncthreads();
         dcur = dn;
         ldc = ld_h;
@@ -525,11 +565,11 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream) 
     if (pl.H == 64) {
       rc = mbpo_ensure_lds<k_sac_fwd_bwd<64>>(pl.lds, "sac_grads");
       if (rc != MBPO_OK) return rc;
-      hipLaunchKernelGGL(k_sac_fwd_bwd<64>, dim3(2 * pl.n_tiles), dim3(256), pl.lds, st, A);
+      hipLaunchKernelGGL(k_sac_fwd_bwd<64>, dim3(2 * pl.n_tiles), dim3(512), pl.lds, st, A);
     } else {
       rc = mbpo_ensure_lds<k_sac_fwd_bwd<128>>(pl.lds, "sac_grads");
       if (rc != MBPO_OK) return rc;
-      hipLaunchKernelGGL(k_sac_fwd_bwd<128>, dim3(2 * pl.n_tiles), dim3(256), pl.lds, st, A);
+      hipLaunchKernelGGL(k_sac_fwd_bwd<128>, dim3(2 * pl.n_tiles), dim3(512), pl.lds, st, A);
     }
   }
   if (!(phase_mask & 2)) {

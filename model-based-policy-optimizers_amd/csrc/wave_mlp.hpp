@@ -90,8 +90,10 @@ __device__ __forceinline__ void store_vec_global(float *p, const float (&v)[NV])
 //   KS == 0 : K <= 32 (the network input layer): 8 unrolled k-steps, out-of-range steps get a = 0 and a clamped B row.
 //   otherwise a generic runtime loop (not used by the shapes this library dispatches).
 // Columns beyond N are handled by clamping the B column and dropping the result.
+// Slicing: W / bias / h_out / z_out may point at a column offset of the full layer; `ldw` is the row stride of W (the
+// full layer width) and N the number of columns this call produces — that is how several waves share one layer.
 template <int NT, int KS = 0>
-__device__ __forceinline__ void wave_dense_fwd(const float *x, int ldx, int K, const float *__restrict__ W,
+__device__ __forceinline__ void wave_dense_fwd(const float *x, int ldx, int K, const float *__restrict__ W, int ldw,
                                                const float *__restrict__ bias, int N, float *h_out, float *z_out, int ldo,
                                                int act, int lane) {
   const int r = lane & 15, g = lane >> 4;
@@ -109,12 +111,12 @@ __device__ __forceinline__ void wave_dense_fwd(const float *x, int ldx, int K, c
     constexpr int KSS = KS > 0 ? KS : 8;
     constexpr int KB = 8;  // k-steps per register bank
     constexpr int NB = KSS / KB;
-    const float *wr = W + (long long)(g * KSS) * N;
+    const float *wr = W + (g * KSS) * ldw;
     float bv[2][KB][NT];
     auto load_bank = [&](int blk, float (&bank)[KB][NT]) {
 #pragma unroll
       for (int u = 0; u < KB; ++u) {
-        const float *row = wr + (long long)(blk * KB + u) * N;
+        const float *row = wr + (blk * KB + u) * ldw;
         if (full_n) {
           load_vec_global<NT>(row + NT * r, bank[u]);
         } else {
@@ -147,7 +149,7 @@ __device__ __forceinline__ void wave_dense_fwd(const float *x, int ldx, int K, c
       const int kk = ok ? k : 0;
       av[s] = x[r * ldx + kk];
       av[s] = ok ? av[s] : 0.f;
-      const float *row = W + (long long)kk * N;
+      const float *row = W + kk * ldw;
       if (full_n) {
         load_vec_global<NT>(row + NT * r, bv[s]);
       } else {
@@ -167,7 +169,7 @@ __device__ __forceinline__ void wave_dense_fwd(const float *x, int ldx, int K, c
       float a = x[r * ldx + kk];
       a = kin ? a : 0.f;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, W[(long long)kk * N + ncol[t]], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, W[kk * ldw + ncol[t]], acc[t], 0, 0, 0);
     }
   }
   // epilogue: lane holds y[row = 4g+i][n = NT*r + t]
@@ -221,21 +223,21 @@ __device__ __forceinline__ void wave_mlp_fwd(const MlpDev &m, const float *param
     if (last) {
       // output layer: K is the hidden width (static path) unless the MLP has no hidden layer at all
       if (K == 16 * HT) {
-        if (N <= 16) wave_dense_fwd<1, 4 * HT>(cur, ldc, K, W, b, N, y, nullptr, ldy, -1, lane);
-        else if (N <= 32) wave_dense_fwd<2, 4 * HT>(cur, ldc, K, W, b, N, y, nullptr, ldy, -1, lane);
-        else if (N <= 64) wave_dense_fwd<4, 4 * HT>(cur, ldc, K, W, b, N, y, nullptr, ldy, -1, lane);
-        else wave_dense_fwd<8, 4 * HT>(cur, ldc, K, W, b, N, y, nullptr, ldy, -1, lane);
+        if (N <= 16) wave_dense_fwd<1, 4 * HT>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+        else if (N <= 32) wave_dense_fwd<2, 4 * HT>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+        else if (N <= 64) wave_dense_fwd<4, 4 * HT>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+        else wave_dense_fwd<8, 4 * HT>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
       } else {
-        if (N <= 16) wave_dense_fwd<1>(cur, ldc, K, W, b, N, y, nullptr, ldy, -1, lane);
-        else if (N <= 32) wave_dense_fwd<2>(cur, ldc, K, W, b, N, y, nullptr, ldy, -1, lane);
-        else if (N <= 64) wave_dense_fwd<4>(cur, ldc, K, W, b, N, y, nullptr, ldy, -1, lane);
-        else wave_dense_fwd<8>(cur, ldc, K, W, b, N, y, nullptr, ldy, -1, lane);
+        if (N <= 16) wave_dense_fwd<1>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+        else if (N <= 32) wave_dense_fwd<2>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+        else if (N <= 64) wave_dense_fwd<4>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+        else wave_dense_fwd<8>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
       }
     } else {
       float *ho = hbuf ? hbuf + l * tile : ((l & 1) ? pp1 : pp0);
       float *zo = zbuf ? zbuf + l * tile : nullptr;
-      if (K == 16 * HT) wave_dense_fwd<HT, 4 * HT>(cur, ldc, K, W, b, N, ho, zo, ldh, m.act, lane);
-      else wave_dense_fwd<HT>(cur, ldc, K, W, b, N, ho, zo, ldh, m.act, lane);
+      if (K == 16 * HT) wave_dense_fwd<HT, 4 * HT>(cur, ldc, K, W, N, b, N, ho, zo, ldh, m.act, lane);
+      else wave_dense_fwd<HT>(cur, ldc, K, W, N, b, N, ho, zo, ldh, m.act, lane);
       cur = ho;
       ldc = ldh;
     }
@@ -246,9 +248,11 @@ __device__ __forceinline__ void wave_mlp_fwd(const MlpDev &m, const float *param
 // ------------------------------------------------------------------------------------------------ backward pieces
 // dW[K][N] = x^T[K][16] . delta[16][N], written to `gW` (global, row-major [K][N]); the MFMA k runs over the 16 rows.
 // Tiles (kt, nt) in chunks of KTC x NTC accumulators; row map k = KT*rho + kt, column map n = NT*j + t.
+// Slicing: x / delta / gW may point at a column offset; `ldw` is the row stride of gW (full layer width), K and N the
+// extents of the block this call produces.
 template <int KT, int NT>
 __device__ __forceinline__ void wave_dense_wgrad(const float *x, int ldx, int K, const float *delta, int ldd, int N,
-                                                 float *__restrict__ gW, int lane) {
+                                                 float *__restrict__ gW, int ldw, int lane) {
   const int r = lane & 15, g = lane >> 4;
   constexpr int KTC = KT > 4 ? 4 : KT, NTC = NT > 4 ? 4 : NT;
   const bool full = (K == 16 * KT) && (N == 16 * NT);
@@ -293,12 +297,12 @@ __device__ __forceinline__ void wave_dense_wgrad(const float *x, int ldx, int K,
             float ov[NTC];
 #pragma unroll
             for (int b = 0; b < NTC; ++b) ov[b] = acc[a][b][i];
-            store_vec_global<NTC>(gW + (long long)k * N + NT * r + nt0, ov);
+            store_vec_global<NTC>(gW + k * ldw + NT * r + nt0, ov);
           } else if (k < K) {
 #pragma unroll
             for (int b = 0; b < NTC; ++b) {
               const int n = NT * r + nt0 + b;
-              if (n < N) gW[(long long)k * N + n] = acc[a][b][i];
+              if (n < N) gW[k * ldw + n] = acc[a][b][i];
             }
           }
         }
@@ -321,9 +325,11 @@ __device__ __forceinline__ void wave_dense_bgrad(const float *delta, int ldd, in
 // The MFMA sums over n: lane group g takes n in [g*nc, (g+1)*nc); output column map k = KT*j + kt (K <= 16*KT).
 //   NS > 0 : N == 4*NS known at compile time (delta of a hidden layer): W fetched block-wise into two register banks;
 //   NS == 0: N <= 32 (delta of the output layer): 8 unrolled n-steps with clamped addresses.
+// Slicing: W may point at a ROW offset (W + k0*ldw) with z_prev / dx at the matching column offset k0; K is then the
+// number of output columns of this call.  `ldw` = row stride of W.
 template <int KT, int NS = 0>
-__device__ __forceinline__ void wave_dense_dgrad(const float *delta, int ldd, int N, const float *__restrict__ W, int K,
-                                                 const float *z_prev, int ldz, int act, float *dx, int ldx, int lane) {
+__device__ __forceinline__ void wave_dense_dgrad(const float *delta, int ldd, int N, const float *__restrict__ W, int ldw,
+                                                 int K, const float *z_prev, int ldz, int act, float *dx, int ldx, int lane) {
   const int r = lane & 15, g = lane >> 4;
   const int nc = (N + 3) >> 2;
   const bool full_k = (K == 16 * KT);
@@ -333,7 +339,7 @@ __device__ __forceinline__ void wave_dense_dgrad(const float *delta, int ldd, in
   // W rows of this lane's KT outputs (B[k_mfma = n][j -> k = KT*r + t] = W[k][n]); clamped for partial tiles
   const float *wrow[KT];
 #pragma unroll
-  for (int t = 0; t < KT; ++t) wrow[t] = W + (long long)((KT * r + t < K) ? KT * r + t : 0) * N;
+  for (int t = 0; t < KT; ++t) wrow[t] = W + ((KT * r + t < K) ? KT * r + t : 0) * ldw;
   if (NS > 0 && N == 4 * NS) {
     constexpr int NSS = NS > 0 ? NS : 8;
     constexpr int NBK = 8;  // n-steps per bank
@@ -424,18 +430,18 @@ __device__ __forceinline__ void wave_bwd_dgrad_step(const MlpDev &m, const float
   const float *W = params + m.w_off[l];
   if (l > 0) {
     const float *zp = zbuf + (l - 1) * 16 * ldh;
-    if (N == 16 * HT) wave_dense_dgrad<HT, 4 * HT>(delta, ldd, N, W, K, zp, ldh, m.act, dprev, ldh, lane);
-    else wave_dense_dgrad<HT>(delta, ldd, N, W, K, zp, ldh, m.act, dprev, ldh, lane);
+    if (N == 16 * HT) wave_dense_dgrad<HT, 4 * HT>(delta, ldd, N, W, N, K, zp, ldh, m.act, dprev, ldh, lane);
+    else wave_dense_dgrad<HT>(delta, ldd, N, W, N, K, zp, ldh, m.act, dprev, ldh, lane);
   } else if (dX) {
     // network input: K = dims[0] is small (<= 16*IT columns); N is the hidden width (static) when a hidden layer exists
     if (N == 16 * HT) {
-      if (K <= 16) wave_dense_dgrad<1, 4 * HT>(delta, ldd, N, W, K, nullptr, 0, 0, dX, ldx_in, lane);
-      else if (K <= 32) wave_dense_dgrad<2, 4 * HT>(delta, ldd, N, W, K, nullptr, 0, 0, dX, ldx_in, lane);
-      else wave_dense_dgrad<4, 4 * HT>(delta, ldd, N, W, K, nullptr, 0, 0, dX, ldx_in, lane);
+      if (K <= 16) wave_dense_dgrad<1, 4 * HT>(delta, ldd, N, W, N, K, nullptr, 0, 0, dX, ldx_in, lane);
+      else if (K <= 32) wave_dense_dgrad<2, 4 * HT>(delta, ldd, N, W, N, K, nullptr, 0, 0, dX, ldx_in, lane);
+      else wave_dense_dgrad<4, 4 * HT>(delta, ldd, N, W, N, K, nullptr, 0, 0, dX, ldx_in, lane);
     } else {
-      if (K <= 16) wave_dense_dgrad<1>(delta, ldd, N, W, K, nullptr, 0, 0, dX, ldx_in, lane);
-      else if (K <= 32) wave_dense_dgrad<2>(delta, ldd, N, W, K, nullptr, 0, 0, dX, ldx_in, lane);
-      else wave_dense_dgrad<4>(delta, ldd, N, W, K, nullptr, 0, 0, dX, ldx_in, lane);
+      if (K <= 16) wave_dense_dgrad<1>(delta, ldd, N, W, N, K, nullptr, 0, 0, dX, ldx_in, lane);
+      else if (K <= 32) wave_dense_dgrad<2>(delta, ldd, N, W, N, K, nullptr, 0, 0, dX, ldx_in, lane);
+      else wave_dense_dgrad<4>(delta, ldd, N, W, N, K, nullptr, 0, 0, dX, ldx_in, lane);
     }
   }
   WAVE_FENCE();
@@ -451,15 +457,15 @@ __device__ __forceinline__ void wave_bwd_wgrad_step(const MlpDev &m, int l, cons
   const bool last = (l == m.n_layers - 1);
   if (l == 0) {
     // K small (network input), N = hidden width
-    if (K <= 16) wave_dense_wgrad<1, HT>(hp, ldp, K, delta, ldd, N, gW, lane);
-    else if (K <= 32) wave_dense_wgrad<2, HT>(hp, ldp, K, delta, ldd, N, gW, lane);
-    else wave_dense_wgrad<4, HT>(hp, ldp, K, delta, ldd, N, gW, lane);
+    if (K <= 16) wave_dense_wgrad<1, HT>(hp, ldp, K, delta, ldd, N, gW, N, lane);
+    else if (K <= 32) wave_dense_wgrad<2, HT>(hp, ldp, K, delta, ldd, N, gW, N, lane);
+    else wave_dense_wgrad<4, HT>(hp, ldp, K, delta, ldd, N, gW, N, lane);
   } else if (last) {
-    if (N <= 16) wave_dense_wgrad<HT, 1>(hp, ldp, K, delta, ldd, N, gW, lane);
-    else if (N <= 32) wave_dense_wgrad<HT, 2>(hp, ldp, K, delta, ldd, N, gW, lane);
-    else wave_dense_wgrad<HT, 4>(hp, ldp, K, delta, ldd, N, gW, lane);
+    if (N <= 16) wave_dense_wgrad<HT, 1>(hp, ldp, K, delta, ldd, N, gW, N, lane);
+    else if (N <= 32) wave_dense_wgrad<HT, 2>(hp, ldp, K, delta, ldd, N, gW, N, lane);
+    else wave_dense_wgrad<HT, 4>(hp, ldp, K, delta, ldd, N, gW, N, lane);
   } else {
-    wave_dense_wgrad<HT, HT>(hp, ldp, K, delta, ldd, N, gW, lane);
+    wave_dense_wgrad<HT, HT>(hp, ldp, K, delta, ldd, N, gW, N, lane);
   }
   wave_dense_bgrad(delta, ldd, N, gb, lane);
 }
@@ -477,5 +483,122 @@ __device__ __forceinline__ void wave_mlp_bwd_input(const MlpDev &m, const float 
     wave_bwd_dgrad_step<HT>(m, params, l, dcur, ldc, zbuf, ldh, dn, dX, ldx_in, lane);
     dcur = dn;
     ldc = ldh;
+  }
+}
+
+// =================================================================================================
+// Lockstep groups: SP waves share one chain, each producing a slice of H/SP columns of every hidden layer.  The caller
+// walks the layers and places ONE workgroup barrier per layer; several chains (nets) advance side by side, so the
+// barrier count is the depth of one net, not the sum over nets.  HT = H/16, CT = HT/SP n-tiles per wave.
+// =================================================================================================
+
+// forward layer l of one chain; `cur` is the layer input, ho/zo the layer's hidden output tiles (zo optional), y the
+// output-layer tile.  Wave `sub` of the chain's SP waves.
+template <int HT, int SP>
+__device__ __forceinline__ void group_fwd_layer(const MlpDev &m, const float *params, int l, const float *cur, int ldc,
+                                                float *ho, float *zo, int ldh, float *y, int ldy, int sub, int lane) {
+  constexpr int CT = HT / SP;
+  const int K = m.dims[l], N = m.dims[l + 1];
+  const float *W = params + m.w_off[l], *b = params + m.b_off[l];
+  if (l < m.n_layers - 1) {
+    const int c0 = sub * 16 * CT;
+    if (K == 16 * HT) wave_dense_fwd<CT, 4 * HT>(cur, ldc, K, W + c0, N, b + c0, 16 * CT, ho + c0, zo ? zo + c0 : nullptr, ldh, m.act, lane);
+    else wave_dense_fwd<CT>(cur, ldc, K, W + c0, N, b + c0, 16 * CT, ho + c0, zo ? zo + c0 : nullptr, ldh, m.act, lane);
+  } else if (sub == 0) {
+    if (K == 16 * HT) {
+      if (N <= 16) wave_dense_fwd<1, 4 * HT>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+      else if (N <= 32) wave_dense_fwd<2, 4 * HT>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+      else if (N <= 64) wave_dense_fwd<4, 4 * HT>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+      else wave_dense_fwd<8, 4 * HT>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+    } else {
+      if (N <= 16) wave_dense_fwd<1>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+      else if (N <= 32) wave_dense_fwd<2>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+      else if (N <= 64) wave_dense_fwd<4>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+      else wave_dense_fwd<8>(cur, ldc, K, W, N, b, N, y, nullptr, ldy, -1, lane);
+    }
+  }
+}
+
+// Bookkeeping of a forward chain walked layer by layer (which tile is the current input / output).
+struct FwdChain {
+  const MlpDev *m;
+  const float *params;
+  const float *x;   // network input tile
+  int ldx;
+  float *pp0, *pp1; // ping-pong hidden tiles (used when hbuf == nullptr)
+  float *zbuf, *hbuf;  // optional per-layer stores (layer l at + l*tile)
+  float *y;         // output tile
+};
+
+template <int HT, int SP>
+__device__ __forceinline__ void group_fwd_step(const FwdChain &c, int l, int ldh, int ldy, int sub, int lane) {
+  if (l >= c.m->n_layers) return;
+  const int tile = 16 * ldh;
+  const float *cur;
+  int ldc;
+  if (l == 0) {
+    cur = c.x;
+    ldc = c.ldx;
+  } else {
+    cur = c.hbuf ? c.hbuf + (l - 1) * tile : (((l - 1) & 1) ? c.pp1 : c.pp0);
+    ldc = ldh;
+  }
+  float *ho = c.hbuf ? c.hbuf + l * tile : ((l & 1) ? c.pp1 : c.pp0);
+  float *zo = c.zbuf ? c.zbuf + l * tile : nullptr;
+  group_fwd_layer<HT, SP>(*c.m, c.params, l, cur, ldc, ho, zo, ldh, c.y, ldy, sub, lane);
+}
+
+// backward layer l, dgrad half of one chain: delta_{l-1}[:, slice] (l > 0) or dX (l == 0, wave 0 only).
+template <int HT, int SP>
+__device__ __forceinline__ void group_bwd_dgrad_layer(const MlpDev &m, const float *params, int l, const float *delta, int ldd,
+                                                      const float *zbuf, int ldh, float *dprev, float *dX, int ldx_in,
+                                                      int sub, int lane) {
+  constexpr int CT = HT / SP;
+  const int K = m.dims[l], N = m.dims[l + 1];
+  const float *W = params + m.w_off[l];
+  if (l > 0) {
+    const int k0 = sub * 16 * CT;  // K == 16*HT: this wave's slice of the previous hidden layer
+    const float *zp = zbuf + (l - 1) * 16 * ldh + k0;
+    if (N == 16 * HT) wave_dense_dgrad<CT, 4 * HT>(delta, ldd, N, W + k0 * N, N, 16 * CT, zp, ldh, m.act, dprev + k0, ldh, lane);
+    else wave_dense_dgrad<CT>(delta, ldd, N, W + k0 * N, N, 16 * CT, zp, ldh, m.act, dprev + k0, ldh, lane);
+  } else if (dX && sub == 0) {
+    if (N == 16 * HT) {
+      if (K <= 16) wave_dense_dgrad<1, 4 * HT>(delta, ldd, N, W, N, K, nullptr, 0, 0, dX, ldx_in, lane);
+      else if (K <= 32) wave_dense_dgrad<2, 4 * HT>(delta, ldd, N, W, N, K, nullptr, 0, 0, dX, ldx_in, lane);
+      else wave_dense_dgrad<4, 4 * HT>(delta, ldd, N, W, N, K, nullptr, 0, 0, dX, ldx_in, lane);
+    } else {
+      if (K <= 16) wave_dense_dgrad<1>(delta, ldd, N, W, N, K, nullptr, 0, 0, dX, ldx_in, lane);
+      else if (K <= 32) wave_dense_dgrad<2>(delta, ldd, N, W, N, K, nullptr, 0, 0, dX, ldx_in, lane);
+      else wave_dense_dgrad<4>(delta, ldd, N, W, N, K, nullptr, 0, 0, dX, ldx_in, lane);
+    }
+  }
+}
+
+// backward layer l, wgrad half of one chain: dW_l[:, slice], db_l[slice] from (h_{l-1} | x, delta_l).
+template <int HT, int SP>
+__device__ __forceinline__ void group_bwd_wgrad_layer(const MlpDev &m, int l, const float *x_in, int ldx_in, const float *hbuf,
+                                                      int ldh, const float *delta, int ldd, float *slab, int sub, int lane) {
+  constexpr int CT = HT / SP;
+  const int K = m.dims[l], N = m.dims[l + 1];
+  const float *hp = (l == 0) ? x_in : hbuf + (l - 1) * 16 * ldh;
+  const int ldp = (l == 0) ? ldx_in : ldh;
+  float *gW = slab + m.w_off[l], *gb = slab + m.b_off[l];
+  if (l == m.n_layers - 1) {
+    // output layer: N small.  Split the K rows of dW over the SP waves instead (K == 16*HT).
+    const int k0 = sub * 16 * CT;
+    if (N <= 16) wave_dense_wgrad<CT, 1>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, lane);
+    else if (N <= 32) wave_dense_wgrad<CT, 2>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, lane);
+    else wave_dense_wgrad<CT, 4>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, lane);
+    if (sub == 0) wave_dense_bgrad(delta, ldd, N, gb, lane);
+  } else {
+    const int c0 = sub * 16 * CT;  // N == 16*HT: column slice
+    if (l == 0) {
+      if (K <= 16) wave_dense_wgrad<1, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane);
+      else if (K <= 32) wave_dense_wgrad<2, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane);
+      else wave_dense_wgrad<4, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane);
+    } else {
+      wave_dense_wgrad<HT, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane);
+    }
+    wave_dense_bgrad(delta + c0, ldd, 16 * CT, gb + c0, lane);
   }
 }
