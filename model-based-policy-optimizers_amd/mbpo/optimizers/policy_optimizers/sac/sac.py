@@ -24,6 +24,7 @@ import torch
 
 from mbpo import ops
 from mbpo.optimizers.policy_optimizers.brax_utils.base import State
+from mbpo.parallel import DataParallel
 from mbpo.replay import ReplayBufferState, UniformSamplingQueue
 from mbpo.systems.brax_wrapper import BraxWrapper
 from mbpo.systems.ensemble_system import lecun_uniform_flat
@@ -172,12 +173,9 @@ class SAC:
         self.policy_spec = ops.MlpSpec(self.policy_dims, policy_activation, 1)
         # data-parallel ranks (the live form of _PMAP_AXIS_NAME, sac.py:188-189): one process per GPU
         self.process_group = process_group
-        self.world_size = 1
-        all_reduce = None
-        if process_group is not None:
-            import torch.distributed as dist
-            self.world_size = dist.get_world_size(process_group)
-            all_reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
+        self.dp = DataParallel(process_group)
+        self.world_size = self.dp.world_size
+        all_reduce = self.dp.all_reduce_fn()
         self._all_reduce = all_reduce
         self.updater = ops.SacUpdater(
             x_dim=self.x_dim, u_dim=self.u_dim, policy_dims=self.policy_dims, q_dims=self.q_dims, batch_size=batch_size,
@@ -232,9 +230,7 @@ class SAC:
         pol = lecun_uniform_flat(self.policy_dims, gp)
         q = torch.cat([lecun_uniform_flat(self.q_dims, gq) for _ in range(2)])
         params = torch.cat([pol, q, torch.tensor([self.init_log_alpha], dtype=torch.float32)]).to(self.device)
-        if self.process_group is not None:   # identical replicas: broadcast rank 0's initialisation
-            import torch.distributed as dist
-            dist.broadcast(params, src=0, group=self.process_group)
+        self.dp.broadcast(params, src=0)     # identical replicas: rank 0's initialisation everywhere
         self.updater.load_state(params)
         self._stats_vec.zero_()
         self._stats_vec[1 + 2 * self.x_dim:] = 1.0      # running_statistics.init_state: std = 1

@@ -1,0 +1,89 @@
+"""GPU, world_size 2: two ranks share the one MI355X of the box (gloo moves the CUDA tensors), each runs the HIP SAC
+sgd_step on HALF of a global minibatch with the flat-gradient all-reduce in between; the result must equal the
+single-process HIP step on the whole minibatch.  Also a world_size-1 "nccl" (RCCL) group through the same code path."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _setup_paths():
+    for p in (str(ROOT), str(ROOT / "model-based-policy-optimizers_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _make(world, B):
+    from oracle import sac as osac
+    X, U = 4, 1
+    g = torch.Generator().manual_seed(0)
+    cfg = osac.SacConfig(X, U, [X, 64, 64, 64, 2 * U], [X + U, 64, 64, 64, 1], lr_policy=1e-3, lr_q=1e-3, lr_alpha=1e-3,
+                         max_grad_norm=0.05)
+    st = osac.init_state(cfg, g)
+    D = 2 * X + U + 3
+    batch = torch.randn(world * B, D, generator=g)
+    batch[:, X + U + 1] = 1.0
+    batch[:, D - 1] = (torch.rand(world * B, generator=g) < 0.2).float()
+    noise = [torch.randn(world * B, U, generator=g) for _ in range(3)]
+    return cfg, st, batch, noise
+
+
+def _updater(cfg, B, dev, **kw):
+    from mbpo import ops
+    return ops.SacUpdater(x_dim=cfg.x_dim, u_dim=cfg.u_dim, policy_dims=cfg.policy_dims, q_dims=cfg.q_dims, batch_size=B,
+                          device=dev, lr_policy=cfg.lr_policy, lr_q=cfg.lr_q, lr_alpha=cfg.lr_alpha,
+                          max_grad_norm=cfg.max_grad_norm, **kw)
+
+
+def _worker(rank, world, port, backend, tmpdir):
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from mbpo.parallel import DataParallel
+        dp = DataParallel(dist.group.WORLD)
+        B = 32
+        cfg, st, batch, noise = _make(world, B)
+        sl = slice(rank * B, (rank + 1) * B)
+        up = _updater(cfg, B, dev, all_reduce=dp.all_reduce_fn(), world_size=world)
+        params = st.params.to(dev)
+        dp.broadcast(params)
+        up.load_state(params)
+        up.sgd_step(batch[sl].to(dev), None, None, *[n[sl].to(dev) for n in noise])
+        torch.cuda.synchronize()
+        # single-process reference on the GLOBAL minibatch, same HIP path
+        ref = _updater(cfg, world * B, dev)
+        ref.load_state(st.params.to(dev))
+        ref.sgd_step(batch.to(dev), None, None, *[n.to(dev) for n in noise])
+        torch.cuda.synchronize()
+        torch.testing.assert_close(up.grads * (1.0 / world), ref.grads, atol=1e-6, rtol=1e-4)
+        torch.testing.assert_close(up.params, ref.params, atol=2e-6, rtol=0)
+        torch.testing.assert_close(up.target_q, ref.target_q, atol=2e-6, rtol=0)
+        (Path(tmpdir) / f"ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_gloo(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, "gloo", str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_single_rank_rccl_group(tmp_path):
+    """world_size 1 over backend 'nccl' (= RCCL): the same all-reduce + grad-norm + apply sequence the 8-GPU run uses."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(1, port, "nccl", str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok0").exists()
