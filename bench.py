@@ -156,6 +156,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Libraries (RCCL's version banner) write to fd 1; the contract is ONE JSON line on stdout, so fd 1 points at stderr
+    # until the result is printed.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,10 +173,15 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    force_pg = os.environ.get("MBPO_BENCH_FORCE_PG") == "1"      # exercise the RCCL path on a single rank
+    if world > 1 or force_pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if force_pg and world == 1:
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
         pg = dist.group.WORLD
 
     log(f"building trainer on {device} (world={world})")
@@ -183,7 +194,7 @@ def main():
     torch.cuda.synchronize()
     log("prefill done")
 
-    use_graph = trainer.use_graph and world == 1
+    use_graph = trainer.use_graph
     key = 23 + rank
 
     def one_step():
@@ -198,16 +209,25 @@ def main():
     torch.cuda.synchronize()
     log(f"{max(args.warmup, 1)} eager warm-up steps done")
     if use_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            trainer.training_step(ts, env_state, buffer_state, 29)
-        log("graph captured")
-        graph.replay()   # one untimed replay
-        torch.cuda.synchronize()
-        log("graph replayed once")
+        # With ranks > 1 the captured step contains the RCCL all-reduces; if this RCCL/torch build cannot capture them
+        # every rank falls back to eager launches together (the capture fails identically on all ranks).
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                trainer.training_step(ts, env_state, buffer_state, 29)
+            log("graph captured")
+            graph.replay()   # one untimed replay
+            torch.cuda.synchronize()
+            log("graph replayed once")
+        except Exception as e:  # noqa: BLE001
+            if pg is None:
+                raise
+            log(f"hipGraph capture with collectives failed ({type(e).__name__}: {e}); running eagerly")
+            graph = None
+            torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if pg is not None:
             import torch.distributed as dist
             dist.barrier()
 
@@ -222,7 +242,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if pg is not None:
         import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -268,8 +288,11 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
             log("cpu baseline done")
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    if pg is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 

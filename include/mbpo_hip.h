@@ -218,6 +218,42 @@ int mbpo_sac_grads_phase(const mbpo_sac_desc *d, int32_t phase_mask, void *strea
 int mbpo_sac_grad_norms(const mbpo_sac_desc *d, void *stream);
 int mbpo_sac_apply(const mbpo_sac_desc *d, void *stream);
 
+/* ---- P1-P3: PPO minibatch update (ppo/ppo.py:142-156, ppo/losses.py:56-126) -----------------------
+ * replaces: PPO.minibatch_step = value_and_grad(PPOLoss.loss) + optax.adamw(lr, wd) over {policy, value} (ppo.py:128,139-140;
+ *           no gradient clipping in this variant).  Inside the loss: policy logits and value baseline on [B,T] samples,
+ *           bootstrap value, compute_gae (stop-gradient), advantage normalisation over the whole minibatch
+ *           (losses.py:101-102), clipped surrogate, 0.5*MSE value loss, entropy bonus with a fresh NormalTanh sample.
+ * Flat state: params [P+V] = [ policy | value ]; adam_m/adam_v [P+V]; step_count [1]; grads [P+V].
+ *   mbpo_ppo_grads : grads, metrics[0..3] = total_loss, policy_loss, v_loss, entropy_loss (losses.py:121-126); bumps step_count
+ *   mbpo_ppo_apply : grads *= grad_scale; AdamW.   All-reduce `grads` in between for N>1 ranks (ppo.py:149-154's pmean).
+ * data: one minibatch [batch_size, unroll_length, row_len] of PPO rows (row_len = 2x+2u+4), i.e. the rollout kernel's
+ *       env_major output after the permutation gather.  entropy_noise [B,T,u] or NULL -> Philox(seed, offset+step_count, stream 9).
+ */
+typedef struct mbpo_ppo_desc {
+  int32_t x_dim, u_dim;
+  int32_t policy_layers;
+  int32_t policy_dims[MBPO_MAX_LAYERS + 1];  /* [x_dim, hidden..., 2*u_dim] */
+  int32_t value_layers;
+  int32_t value_dims[MBPO_MAX_LAYERS + 1];   /* [x_dim, hidden..., 1] */
+  int32_t policy_activation, value_activation;
+  float *params, *adam_m, *adam_v, *step_count, *grads;
+  float *workspace;                          /* >= mbpo_ppo_workspace_floats() floats */
+  float *metrics;                            /* [4] */
+  float *metrics_accum;                      /* optional [5]: running sums of the four metrics + count */
+  const float *data;
+  int32_t batch_size, unroll_length, row_len;
+  const float *norm_mean, *norm_std;         /* [x_dim] or NULL */
+  const float *entropy_noise;                /* [B,T,u] or NULL */
+  uint64_t seed, offset;
+  float entropy_cost, discounting, reward_scaling, gae_lambda, clipping_epsilon;
+  int32_t normalize_advantage;
+  float lr, wd, grad_scale;
+} mbpo_ppo_desc;
+
+int64_t mbpo_ppo_workspace_floats(const mbpo_ppo_desc *d);
+int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream);
+int mbpo_ppo_apply(const mbpo_ppo_desc *d, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

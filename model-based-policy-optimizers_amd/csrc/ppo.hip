@@ -1,0 +1,498 @@
+// ppo.hip — P1-P3: one PPO minibatch update (see include/mbpo_hip.h).
+//
+//   k_ppo_values    V(obs) on all B*T samples + the bootstrap V(next_obs[:, T-1]); also splits the row columns the
+//                   GAE scan needs (truncation, termination, scaled reward) into [B,T] arrays.            [fp32 MFMA]
+//   mbpo_gae_scan   vs, advantages (scan.hip; batch-major, wavefront-shuffle scan)                         [HBM]
+//   k_moments_*     mean / population std of the advantages over the whole minibatch (two passes)         [HBM]
+//   k_ppo_fwd_bwd   policy and value forward + hand-written backward of the clipped-surrogate / value / entropy losses;
+//                   a workgroup walks many 16-sample tiles and ACCUMULATES its weight gradients into its own slab
+//                   (8 waves: policy and value chains, 2 waves each; backward: dgrad + wgrad chains side by side).  [fp32 MFMA]
+//   k_ppo_reduce    grads = fixed-order sum of the slabs; loss metrics.                                    [HBM]
+//   k_ppo_apply     optax.adamw(lr, wd) (no clipping in this variant, ppo.py:128).                         [HBM]
+// Algorithmic work per sample: 3*(2P + 2V) FLOP fwd+bwd (+2V for the value pre-pass), 4*(2x+2u+4) B of row data.
+#include "common.hpp"
+#include "wave_mlp.hpp"
+
+#define LOG_SQRT_2PI 0.91893853320467274178f
+#define LOG_2 0.69314718055994530942f
+#define PPO_MOM_WGS 64
+
+struct PpoArgs {
+  MlpDev pi, v;
+  int X, U, B, T, D;
+  const float *data, *norm_mean, *norm_std, *ent_noise;
+  unsigned long long seed, offset;
+  const float *step_count;
+  float entropy_cost, discounting, reward_scaling, gae_lambda, clip_eps;
+  int normalize_advantage;
+  // workspace pieces
+  float *baseline, *boot, *trunc, *term, *rew, *vs, *adv, *mom, *slabs, *extras;
+  int n_slabs;
+  int ld_x, ld_h, ld_y, LH;
+};
+
+// ------------------------------------------------------------------------------------------------ values pre-pass
+template <int H>
+__global__ void __launch_bounds__(256) k_ppo_values(PpoArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int HT = H / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int X = A.X, U = A.U, D = A.D, T = A.T;
+  const long long M = (long long)A.B * T, rows = M + A.B;     // samples, then one bootstrap row per trajectory
+  float *s_x = smem;                         // [16][ld_x]
+  float *s_pp = s_x + 16 * A.ld_x;           // 2 hidden tiles
+  float *s_y = s_pp + 2 * 16 * A.ld_h;       // [16][ld_y]
+  const long long n_tiles = (rows + 15) >> 4;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long r0 = tile * 16;
+    for (int idx = tid; idx < 16 * X; idx += blockDim.x) {
+      const int r = idx / X, c = idx - r * X;
+      const long long i = r0 + r;
+      float o = 0.f;
+      if (i < M) o = A.data[i * D + c];                                                   // observation
+      else if (i < rows) o = A.data[((i - M) * T + (T - 1)) * D + X + U + 2 + c];         // next_observation[-1]  (losses.py:84-85)
+      if (A.norm_mean) o = (o - A.norm_mean[c]) / A.norm_std[c];
+      s_x[r * A.ld_x + c] = o;
+    }
+    if (tid < 16) {
+      const long long i = r0 + tid;
+      if (i < M) {
+        const float *row = A.data + i * D;
+        const float tr = row[D - 1], disc = row[X + U + 1];
+        A.trunc[i] = tr;
+        A.term[i] = (1.f - disc) * (1.f - tr);                 // termination = (1 - discount) * (1 - truncation)   (:89)
+        A.rew[i] = row[X + U] * A.reward_scaling;              // rewards = data.reward * reward_scaling             (:87)
+      }
+    }
+    __syncthreads();
+    FwdChain fc{&A.v, A.v.params, s_x, A.ld_x, s_pp, s_pp + 16 * A.ld_h, nullptr, nullptr, s_y};
+    for (int l = 0; l < A.v.n_layers; ++l) {
+      group_fwd_step<HT, 4>(fc, l, A.ld_h, A.ld_y, wave, lane);
+      __syncthreads();
+    }
+    if (tid < 16) {
+      const long long i = r0 + tid;
+      if (i < M) A.baseline[i] = s_y[tid * A.ld_y];
+      else if (i < rows) A.boot[i - M] = s_y[tid * A.ld_y];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ moments (two passes)
+__device__ __forceinline__ float ppo_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// PASS 0: partial[g] = sum x ; PASS 1: partial[g] = sum (x - mean)^2
+template <int PASS>
+__global__ void __launch_bounds__(256) k_moments_partial(const float *x, long long n, const float *mom, float *partial) {
+  __shared__ float s_w[4];
+  const float mean = PASS ? mom[0] : 0.f;
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float d = x[i] - mean;
+    acc += PASS ? d * d : d;
+  }
+  acc = ppo_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+template <int PASS>
+__global__ void k_moments_final(const float *partial, int n_parts, long long n, float *mom) {
+  if (threadIdx.x == 0) {
+    float acc = 0.f;
+    for (int g = 0; g < n_parts; ++g) acc += partial[g];
+    if (PASS == 0) mom[0] = acc / (float)n;                // mean
+    else mom[1] = sqrtf(acc / (float)n);                   // population std (jnp.std)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ loss fwd/bwd
+template <int H>
+__global__ void __launch_bounds__(512) k_ppo_fwd_bwd(PpoArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int HT = H / 16;
+  constexpr int SP = 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int chain = wave / SP, sub = wave % SP;
+  const int X = A.X, U = A.U, D = A.D;
+  const long long M = (long long)A.B * A.T;
+  const int ld_x = A.ld_x, ld_h = A.ld_h, ld_y = A.ld_y, LH = A.LH;
+  const int TT = 16 * ld_h;
+  const int D4 = (D + 3) & ~3;
+  float *s_row = smem;                       // [16][D4]
+  float *s_x = s_row + 16 * D4;              // [16][ld_x]   normalised obs
+  float *s_store = s_x + 16 * ld_x;          // 4*LH tiles: policy z,h | value z,h
+  float *s_pp = s_store + 4 * LH * TT;       // 4 tiles: delta ping-pong (policy, value)
+  float *s_y = s_pp + 4 * TT;                // [2][16][ld_y]  logits | value
+  float *s_dy = s_y + 2 * 16 * ld_y;         // [2][16][ld_y]
+  float *s_scal = s_dy + 2 * 16 * ld_y;      // [4][16]
+  float *zp = s_store, *hp = s_store + LH * TT, *zv = s_store + 2 * LH * TT, *hv = s_store + 3 * LH * TT;
+  float *y_pi = s_y, *y_v = s_y + 16 * ld_y;
+  const int PL = A.pi.n_layers, VL = A.v.n_layers;
+  const int Lmax = PL > VL ? PL : VL;
+  const float invM = 1.0f / (float)M;
+  const float adv_mean = A.normalize_advantage ? A.mom[0] : 0.f;
+  const float adv_istd = A.normalize_advantage ? 1.0f / (A.mom[1] + 1e-8f) : 1.f;          // losses.py:101-102
+  const unsigned long long rng_off = A.offset + (unsigned long long)A.step_count[0];
+  float *slab = A.slabs + (long long)blockIdx.x * (A.pi.n_params + A.v.n_params);
+  float *slab_pi = slab, *slab_v = slab + A.pi.n_params;
+  float loss_pol = 0.f, loss_v = 0.f, loss_ent = 0.f;     // thread 0..15 partials, reduced at the end
+  const long long n_tiles = (M + 15) >> 4;
+  bool first = true;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, first = false) {
+    const long long r0 = tile * 16;
+    for (int idx = tid; idx < 16 * D; idx += nthreads) {
+      const int r = idx / D, c = idx - r * D;
+      s_row[r * D4 + c] = (r0 + r < M) ? A.data[(r0 + r) * D + c] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 16 * X; idx += nthreads) {
+      const int r = idx / X, c = idx - r * X;
+      float o = s_row[r * D4 + c];
+      if (A.norm_mean) o = (o - A.norm_mean[c]) / A.norm_std[c];
+      s_x[r * ld_x + c] = o;
+    }
+    __syncthreads();
+    // ---- forward: policy logits (:80) and value baseline (:82), both stored for the backward
+    {
+      FwdChain fc;
+      if (chain == 0) fc = FwdChain{&A.pi, A.pi.params, s_x, ld_x, nullptr, nullptr, zp, hp, y_pi};
+      else fc = FwdChain{&A.v, A.v.params, s_x, ld_x, nullptr, nullptr, zv, hv, y_v};
+      for (int l = 0; l < Lmax; ++l) {
+        if (chain < 2) group_fwd_step<HT, SP>(fc, l, ld_h, ld_y, sub, lane);
+        __syncthreads();
+      }
+    }
+    // ---- per-sample loss terms and output gradients
+    if (tid < 16) {
+      const int r = tid;
+      const long long i = r0 + r;
+      const bool ok = i < M;
+      const float *row = s_row + r * D4;
+      const float lp_b = row[2 * X + U + 2];                       // behaviour log-prob (policy_extras.log_prob)
+      const float adv = ok ? (A.adv[i] - adv_mean) * adv_istd : 0.f;
+      const float vs = ok ? A.vs[i] : 0.f;
+      float lp_t = 0.f, ent = 0.f;
+      for (int d = 0; d < U; ++d) {
+        const float loc = y_pi[r * ld_y + d], raw = y_pi[r * ld_y + U + d];
+        const float sg = softplus_f(raw) + 0.001f;
+        const float z = row[2 * X + U + 3 + d];                    // raw_action
+        const float q = (z - loc) / sg;
+        lp_t += -0.5f * q * q - logf(sg) - LOG_SQRT_2PI - 2.0f * (LOG_2 - z - softplus_f(-2.0f * z));   // log_prob (:91-92)
+        float eps = 0.f;
+        if (ok) {
+          const long long nidx = i * U + d;
+          eps = A.ent_noise ? A.ent_noise[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_ENTROPY, (unsigned long long)nidx);
+        }
+        const float zf = loc + sg * eps;
+        ent += 0.5f + LOG_SQRT_2PI + logf(sg) + 2.0f * (LOG_2 - zf - softplus_f(-2.0f * zf));           // entropy (:117)
+      }
+      const float rho = expf(lp_t - lp_b);                                                                // :103
+      const float lo = 1.f - A.clip_eps, hi = 1.f + A.clip_eps;
+      const float s1 = rho * adv, s2 = fminf(fmaxf(rho, lo), hi) * adv;
+      // d min(s1,s2)/d rho: inside the clip range s1 == s2 (tie, both branches carry adv); outside only s1 can carry it
+      const bool inside = (rho >= lo) && (rho <= hi);
+      const float w = inside ? 1.f : (s1 < s2 ? 1.f : 0.f);
+      const float g_lp = ok ? -invM * rho * adv * w : 0.f;          // d policy_loss / d lp_t
+      const float g_ent = ok ? -A.entropy_cost * invM : 0.f;        // d entropy_loss / d entropy_i
+      const float v = y_v[r * ld_y];
+      if (ok) {
+        loss_pol += -fminf(s1, s2);
+        loss_v += 0.5f * (vs - v) * (vs - v);
+        loss_ent += ent;
+      }
+      s_dy[(16 + r) * ld_y] = ok ? -(vs - v) * invM : 0.f;          // d (0.5*mean((vs-V)^2)) / dV   (:112-114)
+      for (int d = 0; d < U; ++d) {
+        const float loc = y_pi[r * ld_y + d], raw = y_pi[r * ld_y + U + d];
+        const float sg = softplus_f(raw) + 0.001f;
+        const float z = row[2 * X + U + 3 + d];
+        const float q = (z - loc) / sg;
+        float eps = 0.f;
+        if (ok) {
+          const long long nidx = i * U + d;
+          eps = A.ent_noise ? A.ent_noise[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_ENTROPY, (unsigned long long)nidx);
+        }
+        const float th = tanhf(loc + sg * eps);
+        // lp_t: d/dloc = q/sg, d/dsigma = (q*q - 1)/sg ; entropy: d/dloc = -2 tanh(zf), d/dsigma = 1/sg - 2 tanh(zf) eps
+        const float g_loc = g_lp * (q / sg) + g_ent * (-2.f * th);
+        const float g_sig = g_lp * ((q * q - 1.f) / sg) + g_ent * (1.f / sg - 2.f * th * eps);
+        s_dy[r * ld_y + d] = g_loc;
+        s_dy[r * ld_y + U + d] = g_sig * sigmoid_f(raw);
+      }
+    }
+    __syncthreads();
+    // ---- backward: chains 0/1 push delta down (policy / value), chains 2/3 accumulate dW/db into this WG's slab
+    {
+      const int net = chain & 1;
+      const MlpDev &m = net ? A.v : A.pi;
+      const float *zb = net ? zv : zp, *hb = net ? hv : hp;
+      float *d0 = s_pp + (2 * net) * TT, *d1 = d0 + TT;
+      const float *dcur = s_dy + net * 16 * ld_y;
+      int ldc = ld_y;
+      for (int l = Lmax - 1; l >= 0; --l) {
+        float *dn = (l & 1) ? d1 : d0;
+        if (l < m.n_layers) {
+          if (chain < 2) group_bwd_dgrad_layer<HT, SP>(m, m.params, l, dcur, ldc, zb, ld_h, dn, nullptr, ld_x, sub, lane);
+          else group_bwd_wgrad_layer<HT, SP>(m, l, s_x, ld_x, hb, ld_h, dcur, ldc, net ? slab_v : slab_pi, sub, lane, !first);
+        }
+        __syncthreads();
+        if (l < m.n_layers) {
+          dcur = dn;
+          ldc = ld_h;
+        }
+      }
+    }
+  }
+  // ---- loss partials of this workgroup (fixed order)
+  if (tid < 16) {
+    s_scal[tid] = loss_pol;
+    s_scal[16 + tid] = loss_v;
+    s_scal[32 + tid] = loss_ent;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      a += s_scal[i];
+      b += s_scal[16 + i];
+      c += s_scal[32 + i];
+    }
+    A.extras[blockIdx.x * 4 + 0] = a;
+    A.extras[blockIdx.x * 4 + 1] = b;
+    A.extras[blockIdx.x * 4 + 2] = c;
+  }
+}
+
+struct PpoReduceArgs {
+  const float *slabs, *extras;
+  int n_slabs, NPV;
+  long long M;
+  float entropy_cost;
+  float *grads, *metrics, *metrics_accum, *step_count;
+};
+
+__global__ void __launch_bounds__(256) k_ppo_reduce(PpoReduceArgs A) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < A.NPV) {
+    float g = 0.f;
+    for (int s = 0; s < A.n_slabs; ++s) g += A.slabs[(long long)s * A.NPV + i];
+    A.grads[i] = g;
+  }
+  if (i == 0) {
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int s = 0; s < A.n_slabs; ++s) {
+      a += A.extras[s * 4 + 0];
+      b += A.extras[s * 4 + 1];
+      c += A.extras[s * 4 + 2];
+    }
+    const float invM = 1.0f / (float)A.M;
+    const float pl = a * invM, vl = b * invM, el = A.entropy_cost * -(c * invM);
+    A.metrics[0] = pl + vl + el;   // total_loss
+    A.metrics[1] = pl;
+    A.metrics[2] = vl;
+    A.metrics[3] = el;
+    if (A.metrics_accum) {
+      for (int k = 0; k < 4; ++k) A.metrics_accum[k] += A.metrics[k];
+      A.metrics_accum[4] += 1.0f;
+    }
+    A.step_count[0] = A.step_count[0] + 1.0f;
+  }
+}
+
+struct PpoApplyArgs {
+  float *params, *adam_m, *adam_v;
+  const float *grads, *step_count;
+  int NPV;
+  float lr, wd, grad_scale;
+};
+
+__global__ void __launch_bounds__(256) k_ppo_apply(PpoApplyArgs A) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.NPV) return;
+  // [3P optax.adamw] (constants as optax forms them: f32(0.1), f32(0.001) — see sac.hip)
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+  const float count = A.step_count[0];
+  const float g = A.grads[i] * A.grad_scale;
+  const float mu = b1 * A.adam_m[i] + 0.1f * g;
+  const float nu = b2 * A.adam_v[i] + 0.001f * (g * g);
+  A.adam_m[i] = mu;
+  A.adam_v[i] = nu;
+  const float mu_hat = mu / (1.f - powf(b1, count));
+  const float nu_hat = nu / (1.f - powf(b2, count));
+  const float p = A.params[i];
+  const float upd = mu_hat / (sqrtf(nu_hat) + eps) + A.wd * p;
+  A.params[i] = p + (-A.lr) * upd;
+}
+
+// ------------------------------------------------------------------------------------------------ host
+struct PpoPlan {
+  MlpDev pi, v;
+  int P, V, NPV, H, LH, n_slabs;
+  long long M;
+  int ld_x, ld_h, ld_y;
+  size_t lds_values, lds_fb;
+  long long off_baseline, off_boot, off_trunc, off_term, off_rew, off_vs, off_adv, off_mom, off_part, off_slabs, off_extras, total;
+};
+
+static int ppo_same_hidden(const int *dims, int n_layers) {
+  if (n_layers < 2) return -1;
+  for (int l = 2; l < n_layers; ++l)
+    if (dims[l] != dims[1]) return -1;
+  return dims[1];
+}
+
+static int ppo_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+static int ppo_plan(const mbpo_ppo_desc *d, PpoPlan *pl, bool need_ptrs) {
+  MBPO_REQUIRE(d, MBPO_ERR_ARG, "ppo: null descriptor");
+  MBPO_REQUIRE(d->x_dim > 0 && d->u_dim > 0 && d->batch_size > 0 && d->unroll_length > 0, MBPO_ERR_ARG, "ppo: bad sizes");
+  MBPO_REQUIRE(d->row_len == 2 * d->x_dim + 2 * d->u_dim + 4, MBPO_ERR_ARG, "ppo: row_len %d != 2x+2u+4", d->row_len);
+  MBPO_REQUIRE(d->policy_layers >= 2 && d->policy_layers <= MBPO_MAX_LAYERS && d->value_layers >= 2 && d->value_layers <= MBPO_MAX_LAYERS,
+               MBPO_ERR_ARG, "ppo: networks need at least one hidden layer");
+  MBPO_REQUIRE(d->policy_dims[0] == d->x_dim && d->policy_dims[d->policy_layers] == 2 * d->u_dim, MBPO_ERR_ARG,
+               "ppo: policy must map [x_dim] -> [2*u_dim]");
+  MBPO_REQUIRE(d->value_dims[0] == d->x_dim && d->value_dims[d->value_layers] == 1, MBPO_ERR_ARG, "ppo: value net must map [x_dim] -> [1]");
+  const int Hp = ppo_same_hidden(d->policy_dims, d->policy_layers), Hv = ppo_same_hidden(d->value_dims, d->value_layers);
+  MBPO_REQUIRE(Hp == Hv && (Hp == 64 || Hp == 128), MBPO_ERR_UNSUPPORTED,
+               "ppo: policy and value hidden layers must share one width in {64,128} (got %d, %d)", Hp, Hv);
+  mbpo_mlp_desc md;
+  md.net_stride = 0;
+  md.n_nets = 1;
+  md.params = d->params ? d->params : (const float *)16;
+  md.n_layers = d->policy_layers;
+  for (int l = 0; l <= d->policy_layers; ++l) md.dims[l] = d->policy_dims[l];
+  md.activation = d->policy_activation;
+  int rc = mbpo_make_mlp_dev(&md, &pl->pi, "ppo.policy");
+  if (rc != MBPO_OK) return rc;
+  pl->P = pl->pi.n_params;
+  md.n_layers = d->value_layers;
+  for (int l = 0; l <= d->value_layers; ++l) md.dims[l] = d->value_dims[l];
+  md.activation = d->value_activation;
+  rc = mbpo_make_mlp_dev(&md, &pl->v, "ppo.value");
+  if (rc != MBPO_OK) return rc;
+  pl->V = pl->v.n_params;
+  pl->v.params = d->params ? d->params + pl->P : nullptr;
+  pl->NPV = pl->P + pl->V;
+  pl->H = Hp;
+  const int lhp = d->policy_layers - 1, lhv = d->value_layers - 1;
+  pl->LH = lhp > lhv ? lhp : lhv;
+  pl->M = (long long)d->batch_size * d->unroll_length;
+  auto up4 = [](int v) { return (v + 3) & ~3; };
+  pl->ld_x = up4(d->x_dim) + 4;
+  pl->ld_h = Hp + 4;
+  pl->ld_y = up4(2 * d->u_dim) + 4;
+  pl->lds_values = sizeof(float) * (16ull * pl->ld_x + 2ull * 16 * pl->ld_h + 16ull * pl->ld_y);
+  pl->lds_fb = sizeof(float) * (16ull * up4(d->row_len) + 16ull * pl->ld_x + (size_t)pl->LH * 4 * 16 * pl->ld_h + 4ull * 16 * pl->ld_h +
+                                4ull * 16 * pl->ld_y + 64);
+  long long tiles = (pl->M + 15) / 16;
+  long long cap = 2LL * ppo_num_cus();
+  pl->n_slabs = (int)(tiles < cap ? tiles : cap);
+  long long o = 0;
+  auto take = [&](long long n) { long long at = o; o += (n + 3) & ~3LL; return at; };
+  pl->off_baseline = take(pl->M); pl->off_boot = take(d->batch_size); pl->off_trunc = take(pl->M); pl->off_term = take(pl->M);
+  pl->off_rew = take(pl->M); pl->off_vs = take(pl->M); pl->off_adv = take(pl->M); pl->off_mom = take(4); pl->off_part = take(PPO_MOM_WGS);
+  pl->off_slabs = take((long long)pl->n_slabs * pl->NPV); pl->off_extras = take((long long)pl->n_slabs * 4);
+  pl->total = o;
+  if (need_ptrs)
+    MBPO_REQUIRE(d->params && d->adam_m && d->adam_v && d->step_count && d->grads && d->workspace && d->metrics, MBPO_ERR_ARG,
+                 "ppo: null state pointer");
+  return MBPO_OK;
+}
+
+extern "C" int64_t mbpo_ppo_workspace_floats(const mbpo_ppo_desc *d) {
+  PpoPlan pl;
+  int rc = ppo_plan(d, &pl, false);
+  if (rc != MBPO_OK) return rc;
+  return pl.total;
+}
+
+extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
+  PpoPlan pl;
+  int rc = ppo_plan(d, &pl, true);
+  if (rc != MBPO_OK) return rc;
+  MBPO_REQUIRE(d->data, MBPO_ERR_ARG, "ppo_grads: null data");
+  MBPO_REQUIRE((d->norm_mean == nullptr) == (d->norm_std == nullptr), MBPO_ERR_ARG, "ppo_grads: norm_mean/norm_std mismatch");
+  float *ws = d->workspace;
+  PpoArgs A;
+  A.pi = pl.pi; A.v = pl.v;
+  A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.T = d->unroll_length; A.D = d->row_len;
+  A.data = d->data; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std; A.ent_noise = d->entropy_noise;
+  A.seed = d->seed; A.offset = d->offset; A.step_count = d->step_count;
+  A.entropy_cost = d->entropy_cost; A.discounting = d->discounting; A.reward_scaling = d->reward_scaling;
+  A.gae_lambda = d->gae_lambda; A.clip_eps = d->clipping_epsilon; A.normalize_advantage = d->normalize_advantage;
+  A.baseline = ws + pl.off_baseline; A.boot = ws + pl.off_boot; A.trunc = ws + pl.off_trunc; A.term = ws + pl.off_term;
+  A.rew = ws + pl.off_rew; A.vs = ws + pl.off_vs; A.adv = ws + pl.off_adv; A.mom = ws + pl.off_mom;
+  A.slabs = ws + pl.off_slabs; A.extras = ws + pl.off_extras; A.n_slabs = pl.n_slabs;
+  A.ld_x = pl.ld_x; A.ld_h = pl.ld_h; A.ld_y = pl.ld_y; A.LH = pl.LH;
+  hipStream_t st = (hipStream_t)stream;
+  // 1. values pre-pass
+  long long vt = (pl.M + d->batch_size + 15) / 16;
+  int vgrid = (int)(vt < 4LL * ppo_num_cus() ? vt : 4LL * ppo_num_cus());
+  if (pl.H == 64) {
+    rc = mbpo_ensure_lds<k_ppo_values<64>>(pl.lds_values, "ppo_grads");
+    if (rc != MBPO_OK) return rc;
+    hipLaunchKernelGGL(k_ppo_values<64>, dim3(vgrid), dim3(256), pl.lds_values, st, A);
+  } else {
+    rc = mbpo_ensure_lds<k_ppo_values<128>>(pl.lds_values, "ppo_grads");
+    if (rc != MBPO_OK) return rc;
+    hipLaunchKernelGGL(k_ppo_values<128>, dim3(vgrid), dim3(256), pl.lds_values, st, A);
+  }
+  // 2. GAE on [B,T] (batch-major: the data's native layout, no transpose)   losses.py:94-99,128-184
+  rc = mbpo_gae_scan(A.trunc, A.term, A.rew, A.baseline, A.boot, A.vs, A.adv, d->batch_size, d->unroll_length, d->discounting,
+                     d->gae_lambda, 0, stream);
+  if (rc != MBPO_OK) return rc;
+  // 3. advantage moments over the whole minibatch
+  if (d->normalize_advantage) {
+    float *part = ws + pl.off_part;
+    long long blocks = (pl.M + 255) / 256;
+    int g = (int)(blocks < PPO_MOM_WGS ? blocks : PPO_MOM_WGS);
+    hipLaunchKernelGGL(k_moments_partial<0>, dim3(g), dim3(256), 0, st, (const float *)A.adv, pl.M, (const float *)A.mom, part);
+    hipLaunchKernelGGL(k_moments_final<0>, dim3(1), dim3(64), 0, st, (const float *)part, g, pl.M, A.mom);
+    hipLaunchKernelGGL(k_moments_partial<1>, dim3(g), dim3(256), 0, st, (const float *)A.adv, pl.M, (const float *)A.mom, part);
+    hipLaunchKernelGGL(k_moments_final<1>, dim3(1), dim3(64), 0, st, (const float *)part, g, pl.M, A.mom);
+  }
+  // 4. loss forward/backward
+  if (pl.H == 64) {
+    rc = mbpo_ensure_lds<k_ppo_fwd_bwd<64>>(pl.lds_fb, "ppo_grads");
+    if (rc != MBPO_OK) return rc;
+    hipLaunchKernelGGL(k_ppo_fwd_bwd<64>, dim3(pl.n_slabs), dim3(512), pl.lds_fb, st, A);
+  } else {
+    rc = mbpo_ensure_lds<k_ppo_fwd_bwd<128>>(pl.lds_fb, "ppo_grads");
+    if (rc != MBPO_OK) return rc;
+    hipLaunchKernelGGL(k_ppo_fwd_bwd<128>, dim3(pl.n_slabs), dim3(512), pl.lds_fb, st, A);
+  }
+  // 5. reduce
+  PpoReduceArgs R;
+  R.slabs = A.slabs; R.extras = A.extras; R.n_slabs = pl.n_slabs; R.NPV = pl.NPV; R.M = pl.M; R.entropy_cost = d->entropy_cost;
+  R.grads = d->grads; R.metrics = d->metrics; R.metrics_accum = d->metrics_accum; R.step_count = d->step_count;
+  hipLaunchKernelGGL(k_ppo_reduce, dim3((pl.NPV + 255) / 256), dim3(256), 0, st, R);
+  MBPO_CHECK_LAUNCH("ppo_grads");
+  return MBPO_OK;
+}
+
+extern "C" int mbpo_ppo_apply(const mbpo_ppo_desc *d, void *stream) {
+  PpoPlan pl;
+  int rc = ppo_plan(d, &pl, true);
+  if (rc != MBPO_OK) return rc;
+  PpoApplyArgs A;
+  A.params = d->params; A.adam_m = d->adam_m; A.adam_v = d->adam_v; A.grads = d->grads; A.step_count = d->step_count;
+  A.NPV = pl.NPV; A.lr = d->lr; A.wd = d->wd; A.grad_scale = d->grad_scale;
+  hipLaunchKernelGGL(k_ppo_apply, dim3((pl.NPV + 255) / 256), dim3(256), 0, (hipStream_t)stream, A);
+  MBPO_CHECK_LAUNCH("ppo_apply");
+  return MBPO_OK;
+}

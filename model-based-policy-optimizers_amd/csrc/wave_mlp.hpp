@@ -250,9 +250,10 @@ __device__ __forceinline__ void wave_mlp_fwd(const MlpDev &m, const float *param
 // Tiles (kt, nt) in chunks of KTC x NTC accumulators; row map k = KT*rho + kt, column map n = NT*j + t.
 // Slicing: x / delta / gW may point at a column offset; `ldw` is the row stride of gW (full layer width), K and N the
 // extents of the block this call produces.
+// accumulate: gW += (the slab belongs to this workgroup alone, so a plain read-modify-write is race-free).
 template <int KT, int NT>
 __device__ __forceinline__ void wave_dense_wgrad(const float *x, int ldx, int K, const float *delta, int ldd, int N,
-                                                 float *__restrict__ gW, int ldw, int lane) {
+                                                 float *__restrict__ gW, int ldw, int lane, bool accumulate = false) {
   const int r = lane & 15, g = lane >> 4;
   constexpr int KTC = KT > 4 ? 4 : KT, NTC = NT > 4 ? 4 : NT;
   const bool full = (K == 16 * KT) && (N == 16 * NT);
@@ -297,12 +298,19 @@ __device__ __forceinline__ void wave_dense_wgrad(const float *x, int ldx, int K,
             float ov[NTC];
 #pragma unroll
             for (int b = 0; b < NTC; ++b) ov[b] = acc[a][b][i];
-            store_vec_global<NTC>(gW + k * ldw + NT * r + nt0, ov);
+            float *dst = gW + k * ldw + NT * r + nt0;
+            if (accumulate) {
+              float old[NTC];
+              load_vec_global<NTC>(dst, old);
+#pragma unroll
+              for (int b = 0; b < NTC; ++b) ov[b] += old[b];
+            }
+            store_vec_global<NTC>(dst, ov);
           } else if (k < K) {
 #pragma unroll
             for (int b = 0; b < NTC; ++b) {
               const int n = NT * r + nt0 + b;
-              if (n < N) gW[k * ldw + n] = acc[a][b][i];
+              if (n < N) gW[k * ldw + n] = accumulate ? gW[k * ldw + n] + acc[a][b][i] : acc[a][b][i];
             }
           }
         }
@@ -312,12 +320,13 @@ __device__ __forceinline__ void wave_dense_wgrad(const float *x, int ldx, int K,
 }
 
 // db[n] = sum_rows delta[row][n]
-__device__ __forceinline__ void wave_dense_bgrad(const float *delta, int ldd, int N, float *__restrict__ gb, int lane) {
+__device__ __forceinline__ void wave_dense_bgrad(const float *delta, int ldd, int N, float *__restrict__ gb, int lane,
+                                                 bool accumulate = false) {
   for (int n = lane; n < N; n += 64) {
     float acc = 0.f;
 #pragma unroll
     for (int row = 0; row < 16; ++row) acc += delta[row * ldd + n];
-    gb[n] = acc;
+    gb[n] = accumulate ? gb[n] + acc : acc;
   }
 }
 
@@ -577,7 +586,8 @@ __device__ __forceinline__ void group_bwd_dgrad_layer(const MlpDev &m, const flo
 // backward layer l, wgrad half of one chain: dW_l[:, slice], db_l[slice] from (h_{l-1} | x, delta_l).
 template <int HT, int SP>
 __device__ __forceinline__ void group_bwd_wgrad_layer(const MlpDev &m, int l, const float *x_in, int ldx_in, const float *hbuf,
-                                                      int ldh, const float *delta, int ldd, float *slab, int sub, int lane) {
+                                                      int ldh, const float *delta, int ldd, float *slab, int sub, int lane,
+                                                      bool accumulate = false) {
   constexpr int CT = HT / SP;
   const int K = m.dims[l], N = m.dims[l + 1];
   const float *hp = (l == 0) ? x_in : hbuf + (l - 1) * 16 * ldh;
@@ -586,19 +596,19 @@ __device__ __forceinline__ void group_bwd_wgrad_layer(const MlpDev &m, int l, co
   if (l == m.n_layers - 1) {
     // output layer: N small.  Split the K rows of dW over the SP waves instead (K == 16*HT).
     const int k0 = sub * 16 * CT;
-    if (N <= 16) wave_dense_wgrad<CT, 1>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, lane);
-    else if (N <= 32) wave_dense_wgrad<CT, 2>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, lane);
-    else wave_dense_wgrad<CT, 4>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, lane);
-    if (sub == 0) wave_dense_bgrad(delta, ldd, N, gb, lane);
+    if (N <= 16) wave_dense_wgrad<CT, 1>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, lane, accumulate);
+    else if (N <= 32) wave_dense_wgrad<CT, 2>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, lane, accumulate);
+    else wave_dense_wgrad<CT, 4>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, lane, accumulate);
+    if (sub == 0) wave_dense_bgrad(delta, ldd, N, gb, lane, accumulate);
   } else {
     const int c0 = sub * 16 * CT;  // N == 16*HT: column slice
     if (l == 0) {
-      if (K <= 16) wave_dense_wgrad<1, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane);
-      else if (K <= 32) wave_dense_wgrad<2, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane);
-      else wave_dense_wgrad<4, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane);
+      if (K <= 16) wave_dense_wgrad<1, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane, accumulate);
+      else if (K <= 32) wave_dense_wgrad<2, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane, accumulate);
+      else wave_dense_wgrad<4, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane, accumulate);
     } else {
-      wave_dense_wgrad<HT, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane);
+      wave_dense_wgrad<HT, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane, accumulate);
     }
-    wave_dense_bgrad(delta + c0, ldd, 16 * CT, gb + c0, lane);
+    wave_dense_bgrad(delta + c0, ldd, 16 * CT, gb + c0, lane, accumulate);
   }
 }

@@ -96,6 +96,23 @@ class SacDesc(C.Structure):
     ]
 
 
+class PpoDesc(C.Structure):
+    _fields_ = [
+        ("x_dim", C.c_int32), ("u_dim", C.c_int32),
+        ("policy_layers", C.c_int32), ("policy_dims", C.c_int32 * (MBPO_MAX_LAYERS + 1)),
+        ("value_layers", C.c_int32), ("value_dims", C.c_int32 * (MBPO_MAX_LAYERS + 1)),
+        ("policy_activation", C.c_int32), ("value_activation", C.c_int32),
+        ("params", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("step_count", C.c_void_p), ("grads", C.c_void_p),
+        ("workspace", C.c_void_p), ("metrics", C.c_void_p), ("metrics_accum", C.c_void_p),
+        ("data", C.c_void_p), ("batch_size", C.c_int32), ("unroll_length", C.c_int32), ("row_len", C.c_int32),
+        ("norm_mean", C.c_void_p), ("norm_std", C.c_void_p), ("entropy_noise", C.c_void_p),
+        ("seed", C.c_uint64), ("offset", C.c_uint64),
+        ("entropy_cost", C.c_float), ("discounting", C.c_float), ("reward_scaling", C.c_float), ("gae_lambda", C.c_float),
+        ("clipping_epsilon", C.c_float), ("normalize_advantage", C.c_int32),
+        ("lr", C.c_float), ("wd", C.c_float), ("grad_scale", C.c_float),
+    ]
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -149,6 +166,15 @@ def _bind_optional(lib: C.CDLL) -> None:
         if fn is not None:
             fn.restype = C.c_int
             fn.argtypes = [C.POINTER(SacDesc), vp]
+    for name in ("mbpo_ppo_grads", "mbpo_ppo_apply"):
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = C.c_int
+            fn.argtypes = [C.POINTER(PpoDesc), vp]
+    fn = getattr(lib, "mbpo_ppo_workspace_floats", None)
+    if fn is not None:
+        fn.restype = C.c_int64
+        fn.argtypes = [C.POINTER(PpoDesc)]
     fn = getattr(lib, "mbpo_sac_grads_phase", None)
     if fn is not None:
         fn.restype = C.c_int

@@ -329,3 +329,80 @@ class SacUpdater:
             self.all_reduce(self.grads)
             check(self.lib.mbpo_sac_grad_norms(C.byref(d), st), "mbpo_sac_grad_norms")
         check(self.lib.mbpo_sac_apply(C.byref(d), st), "mbpo_sac_apply")
+
+
+# ------------------------------------------------------------------------------------------------ PPO minibatch update (P1-P3)
+class PpoUpdater:
+    """Owns the flat PPO train state ([policy | value] params, Adam moments, step count) on one GPU and drives
+    mbpo_ppo_grads / mbpo_ppo_apply.  `all_reduce(t)` (SUM over ranks, in place) sits at ppo.py:149-154's pmean position."""
+
+    def __init__(self, *, x_dim: int, u_dim: int, policy_dims: Sequence[int], value_dims: Sequence[int], batch_size: int,
+                 unroll_length: int, device, policy_activation: str = "swish", value_activation: str = "swish",
+                 entropy_cost: float = 1e-4, discounting: float = 0.9, reward_scaling: float = 1.0, gae_lambda: float = 0.95,
+                 clipping_epsilon: float = 0.3, normalize_advantage: bool = True, lr: float = 1e-4, wd: float = 1e-5,
+                 seed: int = 0, all_reduce=None, world_size: int = 1):
+        self.lib = load()
+        self.x_dim, self.u_dim, self.batch_size, self.unroll_length = x_dim, u_dim, batch_size, unroll_length
+        self.policy_spec = MlpSpec(list(policy_dims), policy_activation, 1)
+        self.value_spec = MlpSpec(list(value_dims), value_activation, 1)
+        self.P, self.V = self.policy_spec.n_params, self.value_spec.n_params
+        self.NPV = self.P + self.V
+        self.device = torch.device(device)
+        f = lambda n: torch.zeros(n, device=self.device, dtype=torch.float32)
+        self.params, self.adam_m, self.adam_v, self.grads = f(self.NPV), f(self.NPV), f(self.NPV), f(self.NPV)
+        self.step_count, self.metrics, self.metrics_accum = f(1), f(4), f(5)
+        self.all_reduce, self.world_size = all_reduce, world_size
+        d = _hip.PpoDesc()
+        d.x_dim, d.u_dim = x_dim, u_dim
+        d.policy_layers, d.value_layers = len(policy_dims) - 1, len(value_dims) - 1
+        for i, v in enumerate(policy_dims):
+            d.policy_dims[i] = int(v)
+        for i, v in enumerate(value_dims):
+            d.value_dims[i] = int(v)
+        d.policy_activation, d.value_activation = _hip.ACT_IDS[policy_activation], _hip.ACT_IDS[value_activation]
+        d.batch_size, d.unroll_length, d.row_len = batch_size, unroll_length, transition_row_len(x_dim, u_dim, True)
+        d.entropy_cost, d.discounting, d.reward_scaling = entropy_cost, discounting, reward_scaling
+        d.gae_lambda, d.clipping_epsilon, d.normalize_advantage = gae_lambda, clipping_epsilon, int(normalize_advantage)
+        d.lr, d.wd, d.grad_scale = lr, wd, 1.0 / world_size
+        d.seed, d.offset = seed, 0
+        nws = self.lib.mbpo_ppo_workspace_floats(C.byref(d))
+        if nws < 0:
+            check(int(nws), "mbpo_ppo_workspace_floats")
+        self.workspace = f(int(nws))
+        d.params, d.adam_m, d.adam_v, d.step_count, d.grads = (t.data_ptr() for t in (self.params, self.adam_m, self.adam_v, self.step_count, self.grads))
+        d.workspace, d.metrics, d.metrics_accum = self.workspace.data_ptr(), self.metrics.data_ptr(), self.metrics_accum.data_ptr()
+        self.desc = d
+
+    @property
+    def policy_params(self) -> torch.Tensor:
+        return self.params[:self.P]
+
+    @property
+    def value_params(self) -> torch.Tensor:
+        return self.params[self.P:]
+
+    def load_state(self, params, adam_m=None, adam_v=None, count: float = 0.0):
+        self.params.copy_(params)
+        self.adam_m.zero_() if adam_m is None else self.adam_m.copy_(adam_m)
+        self.adam_v.zero_() if adam_v is None else self.adam_v.copy_(adam_v)
+        self.step_count.fill_(count)
+
+    def minibatch_step(self, data: torch.Tensor, norm_mean=None, norm_std=None, entropy_noise=None, offset: int = 0) -> None:
+        """One PPO.minibatch_step (ppo.py:142-156) on data [B, T, 2x+2u+4]."""
+        _req(data, "data")
+        if tuple(data.shape) != (self.batch_size, self.unroll_length, self.desc.row_len):
+            raise ValueError(f"data must be [{self.batch_size},{self.unroll_length},{self.desc.row_len}], got {tuple(data.shape)}")
+        d = self.desc
+        d.data = data.data_ptr()
+        d.norm_mean, d.norm_std = ptr(norm_mean), ptr(norm_std)
+        if entropy_noise is not None:
+            _req(entropy_noise, "entropy_noise")
+            if entropy_noise.numel() != self.batch_size * self.unroll_length * self.u_dim:
+                raise ValueError("entropy_noise must be [B,T,u]")
+        d.entropy_noise = ptr(entropy_noise)
+        d.offset = offset
+        st = current_stream_ptr()
+        check(self.lib.mbpo_ppo_grads(C.byref(d), st), "mbpo_ppo_grads")
+        if self.all_reduce is not None:
+            self.all_reduce(self.grads)
+        check(self.lib.mbpo_ppo_apply(C.byref(d), st), "mbpo_ppo_apply")

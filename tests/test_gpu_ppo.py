@@ -1,0 +1,105 @@
+"""GPU parity: PPO minibatch update (P1-P3) — HIP value pre-pass + GAE + advantage normalisation + hand-written
+loss backward + AdamW, vs the torch-autograd oracle (oracle/ppo.py).
+
+Tolerances (fp32): vs / advantages 2e-5; flat gradients atol 2e-6 + rtol 5e-4 vs the fp32 oracle and rtol 2e-4 vs fp64
+(advantage normalisation divides by a minibatch std, which amplifies rounding slightly more than in SAC);
+loss terms 1e-5; optimizer step 1e-7/1e-6 GIVEN the device gradient (see tests/test_gpu_sac.py for why).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as onets
+from oracle import ppo as oppo
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(X, U, hidden, B, T, seed, normalize, **kw):
+    g = torch.Generator().manual_seed(seed)
+    cfg = oppo.PpoConfig(x_dim=X, u_dim=U, policy_dims=[X, *hidden, 2 * U], value_dims=[X, *hidden, 1], **kw)
+    st = oppo.init_state(cfg, g)
+    st.params = st.params + 0.03 * torch.randn(st.params.shape, generator=g)
+    D = 2 * X + 2 * U + 4
+    data = torch.randn(B, T, D, generator=g)
+    o = X + U
+    data[..., X:o] = torch.tanh(data[..., o + 3 + X:o + 3 + X + U])                 # action = tanh(raw_action)
+    data[..., o + 1] = (torch.rand(B, T, generator=g) > 0.1).float()                # discount
+    data[..., D - 1] = (torch.rand(B, T, generator=g) < 0.15).float()               # truncation
+    data[..., o + 2 + X] = -1.0 + 0.5 * torch.randn(B, T, generator=g)              # behaviour log-prob
+    noise = torch.randn(B, T, U, generator=g)
+    nm = torch.randn(X, generator=g) * 0.3 if normalize else None
+    ns = torch.rand(X, generator=g) + 0.5 if normalize else None
+    return cfg, st, data, noise, nm, ns
+
+
+def _updater(dev, cfg, B, T, **kw):
+    from mbpo import ops
+    return ops.PpoUpdater(x_dim=cfg.x_dim, u_dim=cfg.u_dim, policy_dims=cfg.policy_dims, value_dims=cfg.value_dims,
+                          batch_size=B, unroll_length=T, device=dev, entropy_cost=cfg.entropy_cost, discounting=cfg.discounting,
+                          reward_scaling=cfg.reward_scaling, gae_lambda=cfg.gae_lambda, clipping_epsilon=cfg.clipping_epsilon,
+                          normalize_advantage=cfg.normalize_advantage, lr=cfg.lr, wd=cfg.wd, **kw)
+
+
+@pytest.mark.parametrize("X,U,hidden,B,T,normalize,norm_adv", [
+    (3, 1, (64, 64), 128, 40, True, True),        # reference test config (tests/test_ppo.py:30-56)
+    (3, 1, (64, 64, 64), 32, 5, False, True),     # defaults (ppo.py:69-72), horizon-5 rollouts
+    (4, 1, (64, 64, 64), 16, 10, True, False),    # no advantage normalisation
+    (4, 2, (128, 128), 24, 7, True, True),        # 128-wide, ragged M = 168 (not a multiple of 16), u=2
+    (17, 6, (64, 64), 8, 3, False, True),
+])
+def test_ppo_gradients_and_step(dev, X, U, hidden, B, T, normalize, norm_adv):
+    cfg, st, data, noise, nm, ns = _make(X, U, hidden, B, T, 0, normalize, entropy_cost=1e-2, discounting=0.99,
+                                          reward_scaling=0.5, gae_lambda=0.95, clipping_epsilon=0.3,
+                                          normalize_advantage=norm_adv, lr=3e-4, wd=1e-5)
+    g_ref, terms, vs_ref, adv_ref = oppo.grads(cfg, st.params, data, noise, nm, ns)
+    d64 = lambda t: None if t is None else t.double()
+    g_ref64, terms64, vs64, adv64 = oppo.grads(cfg, st.params.double(), data.double(), noise.double(), d64(nm), d64(ns))
+    up = _updater(dev, cfg, B, T)
+    up.load_state(st.params.to(dev))
+    dd = lambda t: None if t is None else t.to(dev)
+    up.minibatch_step(data.to(dev), dd(nm), dd(ns), noise.to(dev))
+    torch.cuda.synchronize()
+    g = up.grads.cpu()
+    torch.testing.assert_close(g, g_ref, atol=2e-6, rtol=5e-4)
+    torch.testing.assert_close(g.double(), g_ref64, atol=2e-6, rtol=2e-4)
+    m = up.metrics.cpu().tolist()
+    np.testing.assert_allclose(m, [terms64["total_loss"], terms64["policy_loss"], terms64["v_loss"], terms64["entropy_loss"]],
+                               rtol=2e-5, atol=1e-5)
+    st_new, _, _ = oppo.minibatch_step(cfg, st, data, noise, nm, ns, grad_override=g)
+    torch.testing.assert_close(up.params.cpu(), st_new.params, atol=1e-7, rtol=1e-6)
+    torch.testing.assert_close(up.adam_m.cpu(), st_new.adam_m, atol=1e-9, rtol=1e-5)
+    torch.testing.assert_close(up.adam_v.cpu(), st_new.adam_v, atol=1e-12, rtol=1e-5)
+    assert float(up.step_count.cpu()) == 1.0
+
+
+def test_ppo_clip_branches(dev):
+    """Behaviour log-probs far from the target ones push rho outside [1-eps, 1+eps] on both sides: the clipped branch
+    (zero gradient) and the unclipped-but-smaller branch must both match autograd."""
+    cfg, st, data, noise, nm, ns = _make(3, 1, (64, 64), 32, 8, 3, False, clipping_epsilon=0.1)
+    X, U = 3, 1
+    data[..., X + U + 2 + X] += torch.randn(32, 8, generator=torch.Generator().manual_seed(1)) * 1.5
+    g_ref, _, _, _ = oppo.grads(cfg, st.params, data, noise)
+    up = _updater(dev, cfg, 32, 8)
+    up.load_state(st.params.to(dev))
+    up.minibatch_step(data.to(dev), None, None, noise.to(dev))
+    torch.testing.assert_close(up.grads.cpu(), g_ref, atol=2e-6, rtol=5e-4)
+
+
+def test_ppo_chained_minibatches(dev):
+    cfg, st, _, _, _, _ = _make(3, 1, (64, 64), 32, 10, 5, False, lr=1e-3, entropy_cost=1e-3)
+    up = _updater(dev, cfg, 32, 10)
+    up.load_state(st.params.to(dev))
+    for k in range(10):
+        _, _, data, noise, _, _ = _make(3, 1, (64, 64), 32, 10, 100 + k, False)
+        st, terms, _ = oppo.minibatch_step(cfg, st, data, noise)
+        up.minibatch_step(data.to(dev), None, None, noise.to(dev))
+        np.testing.assert_allclose(up.metrics.cpu().tolist()[0], terms["total_loss"], rtol=2e-3, atol=2e-3)
+    rel = float((up.params.cpu() - st.params).norm() / st.params.norm())
+    assert rel < 1e-3 and float(up.step_count.cpu()) == 10.0
+
+
+def test_ppo_bad_args(dev):
+    from mbpo import ops, _hip
+    with pytest.raises(_hip.MbpoHipError):
+        ops.PpoUpdater(x_dim=3, u_dim=1, policy_dims=[3, 64, 128, 2], value_dims=[3, 64, 64, 1], batch_size=8, unroll_length=4, device=dev)
