@@ -1,0 +1,263 @@
+"""PPO trainer — host-side mirror of mbpo/optimizers/policy_optimizers/ppo/ppo.py (same constructor arguments, derived
+quantities, method names, call order, metric keys); every numeric step runs in libmbpo_hip.so.
+
+Where the reference has                               this file issues
+  scan of brax acting.generate_unroll (:194-208)  ->  K x mbpo_model_rollout (ppo_extras, env_major): rows land as
+                                                      data[B*M, T, D] directly — no swapaxes/reshape (:210-213)
+  running_statistics.update (:216-219)            ->  mbpo_running_stats_reduce x2 + _apply
+  jr.permutation + reshape (:166-171)             ->  device permutation + mbpo_replay_gather on [B*M] rows of T*D floats
+  scan of minibatch_step (:172-176)               ->  M x (mbpo_ppo_grads [+ all-reduce] + mbpo_ppo_apply)
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+import time
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from mbpo import ops
+from mbpo.optimizers.policy_optimizers.brax_utils.base import State
+from mbpo.optimizers.policy_optimizers.sac.sac import Evaluator, RunningStatisticsState, policy_act
+from mbpo.parallel import DataParallel
+from mbpo.systems.brax_wrapper import BraxWrapper
+from mbpo.systems.ensemble_system import lecun_uniform_flat
+from mbpo.utils import keys as K
+
+Metrics = Dict[str, Any]
+
+
+@dataclass
+class PPONetworkParams:
+    """ppo/losses.py:19-23."""
+    policy: torch.Tensor
+    value: torch.Tensor
+
+
+@dataclass
+class TrainingState:
+    """ppo.py:36-44; tensors are views into the updater's flat device state."""
+    optimizer_state: Any
+    params: PPONetworkParams
+    normalizer_params: RunningStatisticsState
+    env_steps: int
+
+    def get_policy_params(self):
+        return self.normalizer_params, self.params.policy
+
+    def replace(self, **kw):
+        return dataclasses.replace(self, **kw)
+
+
+class PPO:
+    def __init__(self,
+                 environment: BraxWrapper,
+                 num_timesteps: int,
+                 episode_length: int,
+                 action_repeat: int = 1,
+                 num_envs: int = 1,
+                 num_eval_envs: int = 128,
+                 lr: float = 1e-4,
+                 wd: float = 1e-5,
+                 entropy_cost: float = 1e-4,
+                 discounting: float = 0.9,
+                 seed: int = 0,
+                 unroll_length: int = 10,
+                 batch_size: int = 32,
+                 num_minibatches: int = 16,
+                 num_updates_per_batch: int = 2,
+                 num_evals: int = 1,
+                 normalize_observations: bool = False,
+                 reward_scaling: float = 1.,
+                 clipping_epsilon: float = .3,
+                 gae_lambda: float = .95,
+                 deterministic_eval: bool = False,
+                 normalize_advantage: bool = True,
+                 policy_hidden_layer_sizes: Sequence[int] = (64, 64, 64),
+                 policy_activation: str = "swish",
+                 critic_hidden_layer_sizes: Sequence[int] = (64, 64, 64),
+                 critic_activation: str = "swish",
+                 wandb_logging: bool = False,
+                 # --- MI355X-side knob (not in the reference) ---
+                 process_group=None,
+                 ):
+        if wandb_logging:
+            raise NotImplementedError("wandb is not available in this environment")
+        self.episode_length = episode_length
+        self.action_repeat = action_repeat
+        self.num_timesteps = num_timesteps
+        self.deterministic_eval = deterministic_eval
+        self.normalize_observations = normalize_observations
+        self.num_evals = num_evals
+        self.num_updates_per_batch = num_updates_per_batch
+        self.num_minibatches = num_minibatches
+        self.batch_size = batch_size
+        self.unroll_length = unroll_length
+        self.num_eval_envs = num_eval_envs
+        self.num_envs = num_envs
+        assert batch_size * num_minibatches % num_envs == 0                                   # ppo.py:99
+        self.env_step_per_training_step = batch_size * unroll_length * num_minibatches * action_repeat
+        self.num_evals_after_init = max(num_evals - 1, 1)
+        self.num_training_steps_per_epoch = math.ceil(num_timesteps / (self.num_evals_after_init * self.env_step_per_training_step))
+        self.key = K.PRNGKey(seed)
+        self.env = environment
+        self.x_dim, self.u_dim = self.env.observation_size, self.env.action_size
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.policy_dims = [self.x_dim, *policy_hidden_layer_sizes, 2 * self.u_dim]
+        self.value_dims = [self.x_dim, *critic_hidden_layer_sizes, 1]
+        self.policy_spec = ops.MlpSpec(self.policy_dims, policy_activation, 1)
+        self.dp = DataParallel(process_group)
+        self._all_reduce = self.dp.all_reduce_fn()
+        self.updater = ops.PpoUpdater(
+            x_dim=self.x_dim, u_dim=self.u_dim, policy_dims=self.policy_dims, value_dims=self.value_dims, batch_size=batch_size,
+            unroll_length=unroll_length, device=self.device, policy_activation=policy_activation,
+            value_activation=critic_activation, entropy_cost=entropy_cost, discounting=discounting,
+            reward_scaling=reward_scaling, gae_lambda=gae_lambda, clipping_epsilon=clipping_epsilon,
+            normalize_advantage=normalize_advantage, lr=lr, wd=wd, all_reduce=self._all_reduce, world_size=self.dp.world_size)
+        self.row_len = ops.transition_row_len(self.x_dim, self.u_dim, True)
+        n_traj = batch_size * num_minibatches
+        self._data = torch.empty(n_traj, unroll_length, self.row_len, device=self.device)       # [B*M, T, D]
+        self._shuffled = torch.empty_like(self._data)
+        self._ring_state = torch.zeros(4, dtype=torch.int32, device=self.device)                # head = 0: plain row gather
+        self._stats_vec = torch.zeros(1 + 3 * self.x_dim, device=self.device)
+        self._stats_sums = torch.zeros(1 + 2 * self.x_dim, device=self.device)
+        self._stats_ws = torch.empty(64 * self.x_dim, device=self.device)
+        self._call_counter = 0
+
+    # ------------------------------------------------------------------------------------------------ policy / state
+    def _norm(self, normalizer_params: RunningStatisticsState):
+        if not self.normalize_observations:
+            return None, None
+        return normalizer_params.mean.contiguous(), normalizer_params.std.contiguous()
+
+    def _next_offset(self) -> int:
+        self._call_counter += 1
+        return self._call_counter << 32
+
+    def make_policy(self, params, deterministic: bool = False):
+        """make_inference_fn (ppo_network.py:59-84)."""
+        normalizer_params, policy_params = params
+        nm, ns = self._norm(normalizer_params)
+
+        def policy(observations: torch.Tensor, key_sample: int):
+            obs = observations.reshape(-1, self.x_dim).to(self.device, torch.float32).contiguous()
+            act = policy_act(policy_params, self.policy_spec, obs, nm, ns, deterministic, key_sample)
+            return (act[0] if observations.dim() == 1 else act), {}
+
+        return policy
+
+    def init_training_state(self, key: int) -> TrainingState:
+        """ppo.py:265-277."""
+        k0, k1 = K.split(key)
+        pol = lecun_uniform_flat(self.policy_dims, torch.Generator().manual_seed(k0 % (2 ** 63)))
+        val = lecun_uniform_flat(self.value_dims, torch.Generator().manual_seed(k1 % (2 ** 63)))
+        params = torch.cat([pol, val]).to(self.device)
+        self.dp.broadcast(params, src=0)
+        self.updater.load_state(params)
+        self._stats_vec.zero_()
+        self._stats_vec[1 + 2 * self.x_dim:] = 1.0
+        return self._training_state(0)
+
+    def _training_state(self, env_steps: int) -> TrainingState:
+        u = self.updater
+        return TrainingState(optimizer_state=(u.adam_m, u.adam_v, u.step_count),
+                             params=PPONetworkParams(policy=u.policy_params, value=u.value_params),
+                             normalizer_params=RunningStatisticsState(self._stats_vec, self.x_dim), env_steps=env_steps)
+
+    # ------------------------------------------------------------------------------------------------ hot loops
+    def minibatch_step(self, data: torch.Tensor, normalizer_params: RunningStatisticsState, key: int) -> None:
+        """ppo.py:142-156 on one minibatch [B, T, D]."""
+        nm, ns = self._norm(normalizer_params)
+        self.updater.desc.seed = key
+        self.updater.minibatch_step(data, nm, ns, offset=self._call_counter << 32)
+
+    def sgd_step(self, data: torch.Tensor, normalizer_params: RunningStatisticsState, key: int) -> None:
+        """ppo.py:158-177: one shared permutation of the B*M trajectories, then M minibatch updates."""
+        key, key_perm, key_grad = K.split(key, 3)
+        n = data.shape[0]
+        gen = torch.Generator(device=self.device).manual_seed(key_perm % (2 ** 63))
+        perm = torch.randperm(n, device=self.device, generator=gen, dtype=torch.int64).to(torch.int32)
+        # every leaf is permuted with the SAME key (ppo.py:166-169) == one row gather of whole trajectories
+        flat = data.reshape(n, -1)
+        shuffled = ops.replay_gather(flat, self._ring_state, perm).reshape(self.num_minibatches, self.batch_size,
+                                                                            self.unroll_length, self.row_len)
+        for m in range(self.num_minibatches):
+            self.minibatch_step(shuffled[m], normalizer_params, key_grad)
+
+    def training_step(self, training_state: TrainingState, state: State, key: int):
+        """ppo.py:179-233."""
+        key_sgd, key_generate_unroll, new_key = K.split(key, 3)
+        nm, ns = self._norm(training_state.normalizer_params)
+        spec = self.env.system.rollout_spec(state.system_params, self.device)
+        n_unrolls = self.batch_size * self.num_minibatches // self.num_envs
+        N, T = self.num_envs, self.unroll_length
+        cur_key = key_generate_unroll
+        for k in range(n_unrolls):                                                               # scan :194-208
+            cur_key, next_key = K.split(cur_key)
+            ops.model_rollout(policy_params=training_state.params.policy, policy_spec=self.policy_spec, x_dim=self.x_dim,
+                              u_dim=self.u_dim, obs=state.obs, first_obs=state.info['first_obs'], steps=state.info['steps'],
+                              done=state.done, n_steps=T, episode_length=self.episode_length, action_repeat=self.action_repeat,
+                              norm_mean=nm, norm_std=ns, ppo_extras=True, env_major=True, seed=cur_key,
+                              offset=self._next_offset(), out=self._data[k * N:(k + 1) * N].reshape(N * T, self.row_len), **spec)
+            cur_key = next_key
+        # running_statistics.update(normalizer_params, data.observation)   (:216-219)
+        rows = self._data.reshape(-1, self.row_len)
+        ops.running_stats_update(rows, 0, self.x_dim, training_state.normalizer_params.vec, all_reduce=self._all_reduce,
+                                 sums=self._stats_sums, workspace=self._stats_ws)
+        for _ in range(self.num_updates_per_batch):                                              # scan :222-226
+            key_sgd, k = K.split(key_sgd)
+            self.sgd_step(self._data, training_state.normalizer_params, k)
+        training_state = training_state.replace(env_steps=training_state.env_steps + self.env_step_per_training_step)
+        return training_state, state, new_key
+
+    def training_epoch(self, training_state: TrainingState, state: State, key: int):
+        """ppo.py:235-247."""
+        self.updater.metrics_accum.zero_()
+        for _ in range(self.num_training_steps_per_epoch):
+            training_state, state, key = self.training_step(training_state, state, key)
+        acc = self.updater.metrics_accum.cpu()
+        cnt = max(float(acc[4]), 1.0)
+        metrics = {'total_loss': float(acc[0]) / cnt, 'policy_loss': float(acc[1]) / cnt, 'v_loss': float(acc[2]) / cnt,
+                   'entropy_loss': float(acc[3]) / cnt}
+        return training_state, state, metrics
+
+    def training_epoch_with_timing(self, training_state, env_state, key):
+        """ppo.py:249-263."""
+        torch.cuda.synchronize()
+        t = time.time()
+        training_state, env_state, metrics = self.training_epoch(training_state, env_state, key)
+        torch.cuda.synchronize()
+        epoch_training_time = time.time() - t
+        sps = (self.num_training_steps_per_epoch * self.env_step_per_training_step) / epoch_training_time
+        metrics = {'training/sps': sps, **{f'training/{name}': value for name, value in metrics.items()}}
+        return training_state, env_state, metrics
+
+    def run_training(self, key: int, progress_fn: Callable[[int, Metrics], None] = lambda *args: None):
+        """ppo.py:279-339."""
+        key, subkey = K.split(key)
+        training_state = self.init_training_state(subkey)
+        key, rb_key, env_key, eval_key = K.split(key, 4)
+        env_state = self.env.reset(K.split(env_key, self.num_envs))
+        evaluator = Evaluator(self, self.env, num_eval_envs=self.num_eval_envs, episode_length=self.episode_length,
+                              action_repeat=self.action_repeat, key=eval_key)
+        all_metrics: List[Metrics] = []
+        if self.num_evals > 1:
+            metrics = evaluator.run_evaluation(self._snapshot(training_state), training_metrics={})
+            all_metrics.append(metrics)
+            progress_fn(0, metrics)
+        key, prefill_key = K.split(key)
+        current_step = 0
+        for _ in range(self.num_evals_after_init):
+            key, epoch_key = K.split(key)
+            training_state, env_state, training_metrics = self.training_epoch_with_timing(training_state, env_state, epoch_key)
+            current_step = training_state.env_steps
+            metrics = evaluator.run_evaluation(self._snapshot(training_state), training_metrics)
+            all_metrics.append(metrics)
+            progress_fn(current_step, metrics)
+        return self._snapshot(training_state), all_metrics
+
+    def _snapshot(self, training_state: TrainingState):
+        return (RunningStatisticsState(training_state.normalizer_params.vec.clone(), self.x_dim),
+                training_state.params.policy.clone())
