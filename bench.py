@@ -127,14 +127,22 @@ def cpu_baseline(budget_s=12.0):
     system = osys.EnsembleSystem(dpar, dd, N_MEMBERS, X_DIM, U_DIM, reward_fn=rf)
     cfg = osac.SacConfig(X_DIM, U_DIM, [X_DIM, *HIDDEN, 2 * U_DIM], [X_DIM + U_DIM, *HIDDEN, 1], discounting=0.99,
                          lr_policy=3e-4, lr_q=3e-4, lr_alpha=3e-4)
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box exposes the whole host in os.cpu_count() but gives this job a ~16-core share: more threads than that
+    # only makes torch's CPU kernels spin against each other
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, 16)))
+    log(f"cpu baseline on {torch.get_num_threads()} threads (affinity {avail}, cpu_count {os.cpu_count()})")
     loop = otr.CpuSacLoop(cfg, system, N_ENVS, S_STEPS, EPISODE_LEN, BATCH, GRAD_UPDATES, MAX_REPLAY, True)
     loop.training_step(n_sgd=2)   # warm-up
     t0 = time.time()
     n = 0
-    while time.time() - t0 < budget_s or n == 0:
+    while (time.time() - t0 < budget_s or n == 0) and n < 64:
         loop.training_step()
         n += 1
+        log(f"cpu baseline: {n} training_steps in {time.time() - t0:.1f} s")
     dt = time.time() - t0
     return {"value": N_ENVS * S_STEPS * n / dt, "unit": "transitions/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} full SAC training_steps (N={N_ENVS}, S={S_STEPS}, G={GRAD_UPDATES}, B={BATCH}) of oracle/trainer.py "
