@@ -254,6 +254,48 @@ int64_t mbpo_ppo_workspace_floats(const mbpo_ppo_desc *d);
 int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream);
 int mbpo_ppo_apply(const mbpo_ppo_desc *d, void *stream);
 
+/* ---- B1-B5: BPTT actor gradient (bptt_optimizer.py:327-378) -----------------------------------------
+ * replaces: value_and_grad(vmap(actor_loss)) of BPTTOptimizer._train_step, i.e. rollout_policy with stop_grads=True
+ *           (utils/optimizer_utils.py:62-116) through System.step, target-critic min(v1,v2) on the normalised next states,
+ *           lambda_return (:119-152), discount cumprod, Actor.get_log_prob (:144-152), and the backward pass through ALL of
+ *           it with respect to the actor parameters (gradient flows a -> x' -> ... through the model and the target
+ *           critic; the policy's own observation input is stop-gradiented when acting but NOT inside get_log_prob).
+ * One launch: forward rollout (checkpoints x_t, a_t, eps_t in `workspace`), lambda-returns, reverse sweep with per-step
+ * recomputation of the activations in LDS.  Outputs: actor `grads` [P]; the simulated transitions
+ * [n*horizon, 2x+u+2] = [obs, action, reward(raw), discount=1, next_obs] (what :478-479 inserts into the sampling buffer);
+ * lambda_values [n*horizon] (the critic targets of :385-419); metrics = {actor_loss, entropy_loss}.
+ * Log-prob for u_dim > 1 uses sum_A logN - sum_A log(1-a^2) per step (identical to the reference at u_dim = 1).
+ */
+typedef struct mbpo_bptt_desc {
+  int32_t x_dim, u_dim, horizon;
+  int32_t actor_layers;
+  int32_t actor_dims[MBPO_MAX_LAYERS + 1];   /* [x_dim, features..., 2*u_dim] */
+  int32_t critic_layers;
+  int32_t critic_dims[MBPO_MAX_LAYERS + 1];  /* [x_dim, features..., 1] */
+  int32_t actor_activation, critic_activation;
+  float init_stddev;                         /* Actor.init_stddev (:127) */
+  const float *actor_params;                 /* [P] */
+  const float *target_critic_params;         /* [2*C] = [critic_1 | critic_2] */
+  int32_t system_kind;                       /* MBPO_SYS_* */
+  mbpo_mlp_desc dynamics;                    /* ensemble (MBPO_ENS_MEAN semantics), ignored for MBPO_SYS_PENDULUM */
+  int32_t ens_predict_delta;
+  int32_t reward_kind;                       /* MBPO_REWARD_* */
+  const float *reward_params, *sys_params;
+  const float *state_mean, *state_std;       /* [x_dim] state normaliser */
+  const float *reward_mean_std;              /* [2] reward normaliser {mean, std} */
+  const float *init_states;                  /* [n, x_dim] */
+  int64_t n;
+  const float *act_noise;                    /* [n, horizon, u_dim] or NULL -> Philox(seed, offset(+offset_dev), stream 1) */
+  uint64_t seed, offset;
+  const float *offset_dev;
+  float discount, lambda_, ent_coef;
+  float *transitions, *lambda_values, *grads, *metrics;
+  float *workspace;                          /* >= mbpo_bptt_workspace_floats() floats */
+} mbpo_bptt_desc;
+
+int64_t mbpo_bptt_workspace_floats(const mbpo_bptt_desc *d);
+int mbpo_bptt_actor_grads(const mbpo_bptt_desc *d, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

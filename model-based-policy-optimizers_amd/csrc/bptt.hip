@@ -1,0 +1,693 @@
+// bptt.hip — B1-B5: BPTT actor gradient through the learned model (see include/mbpo_hip.h).
+//
+// One workgroup (8 waves) owns a tile of 16 trajectories for the whole horizon.
+//   FORWARD  t = 0..H-1 : policy (4 waves share the chain) -> sample -> model (ensemble members, 2 waves per chain, 4 chains
+//                         per round; or the analytic pendulum) -> reward -> target critics on the next state.  Checkpoints
+//                         x_t, a_t, eps_t, r_t, V_t, argmin go to HBM (the same workgroup reads them back: workgroup-scope
+//                         visibility after __syncthreads), transitions go to the output.
+//   LAMBDA              : R_t = r~_t + g(1-l)V_t + g*l*R_{t+1} per trajectory; dL/dR_t has a closed form (same for every row).
+//   BACKWARD t = H-1..0 : recompute policy (z,h kept) and target critics (z kept) in lockstep; critic input-gradient;
+//                         per ensemble round: recompute members (z kept) + input-gradient; reward gradient; action /
+//                         log-prob terms; policy backward = two delta chains (total, log-prob-only) + one wgrad chain that
+//                         ACCUMULATES into this workgroup's slab.  dL/dx_t is carried in LDS.
+// Recompute instead of stashing: the stash would be ~180 KB per (tile, step) (E=10), i.e. GBs per train step through HBM;
+// recomputation costs one extra forward (4x instead of 3x forward FLOPs) and keeps everything in LDS.
+// Algorithmic FLOP per (trajectory, step): 3*(2P) + 2*(2*E*M) + 2*(2*2V)  (SURVEY §8d).
+#include "common.hpp"
+#include "wave_mlp.hpp"
+#include <string.h>
+
+#define LOG_SQRT_2PI_B 0.91893853320467274178f
+
+struct BpttArgs {
+  MlpDev pi, cr, dyn;
+  int X, U, H;
+  long long n;
+  int system_kind, predict_delta, reward_kind;
+  const float *reward_params, *sys_params, *s_mean, *s_std, *r_ms;
+  const float *init_states, *act_noise;
+  unsigned long long seed, offset;
+  const float *offset_dev;
+  float c0, discount, lambda_, ent_coef;
+  float *transitions, *lambda_values;
+  float *w_xs, *w_as, *w_eps, *w_rs, *w_vs, *w_km;
+  float *slabs, *extras;
+  int ld_x, ld_xu, ld_h, ld_y, ld_ye, LH, EC;
+};
+
+// analytic pendulum step + vector-Jacobian product (dynamics/pendulum_dynamics.py:29-63)
+__device__ __forceinline__ void pend_fwd(const float *x, float u, const float *sp, float *xn) {
+  const float ms = sp[0], mt = sp[1], dt = sp[2], g = sp[3], mm = sp[4], l = sp[5];
+  const float th = atan2f(x[1], x[0]);
+  const float uc = fminf(fmaxf(u, -1.f), 1.f) * mt;
+  const float thdd = (3.f * g) / (2.f * l) * sinf(th) + 3.f / (mm * (l * l)) * uc;
+  float nv = x[2] + thdd * dt;
+  nv = fminf(fmaxf(nv, -ms), ms);
+  const float nth = th + nv * dt;
+  xn[0] = cosf(nth);
+  xn[1] = sinf(nth);
+  xn[2] = nv;
+}
+// gx[3] = dL/dx'  ->  dL/dx (3) and dL/du
+__device__ __forceinline__ void pend_vjp(const float *x, float u, const float *sp, const float *gx, float *dx, float *du) {
+  const float ms = sp[0], mt = sp[1], dt = sp[2], g = sp[3], mm = sp[4], l = sp[5];
+  const float r2 = x[0] * x[0] + x[1] * x[1];
+  const float th = atan2f(x[1], x[0]);
+  const float K = (3.f * g) / (2.f * l), c = 3.f / (mm * (l * l));
+  const bool uin = (u > -1.f) && (u < 1.f);
+  const float uc = fminf(fmaxf(u, -1.f), 1.f) * mt;
+  const float thdd = K * sinf(th) + c * uc;
+  const float nv_raw = x[2] + thdd * dt;
+  const bool vin = (nv_raw > -ms) && (nv_raw < ms);
+  const float nv = fminf(fmaxf(nv_raw, -ms), ms);
+  const float nth = th + nv * dt;
+  // x' = (cos nth, sin nth, nv)
+  const float g_nth = -sinf(nth) * gx[0] + cosf(nth) * gx[1];
+  const float g_nv = gx[2] + g_nth * dt;
+  const float g_raw = vin ? g_nv : 0.f;
+  const float g_th = g_nth + g_raw * dt * K * cosf(th);
+  dx[0] = g_th * (-x[1] / r2);
+  dx[1] = g_th * (x[0] / r2);
+  dx[2] = g_raw;
+  *du = uin ? g_raw * dt * c * mt : 0.f;
+}
+
+__device__ __forceinline__ float reward_fwd(const BpttArgs &A, const float *xu) {
+  const int X = A.X, U = A.U;
+  if (A.reward_kind == MBPO_REWARD_PENDULUM) {
+    const float *rp = A.reward_params;
+    const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
+    const float theta = atan2f(xu[1], xu[0]);
+    float mpy = fmodf(theta - rp[2] + PI_F, TWO_PI_F);
+    if (mpy < 0.f) mpy += TWO_PI_F;
+    const float d = mpy - PI_F;
+    return -(rp[0] * (d * d) + 0.1f * (xu[2] * xu[2])) - rp[1] * (xu[X] * xu[X]);
+  }
+  const float *tp = A.reward_params, *qp = tp + X, *rp = qp + X;
+  float cx = 0.f, cu = 0.f;
+  for (int c = 0; c < X; ++c) { float dd = xu[c] - tp[c]; cx += qp[c] * (dd * dd); }
+  for (int d = 0; d < U; ++d) cu += rp[d] * (xu[X + d] * xu[X + d]);
+  return -cx - cu;
+}
+// dxu[0..X+U) += g * d reward / d(x,u)
+__device__ __forceinline__ void reward_vjp(const BpttArgs &A, const float *xu, float g, float *dxu) {
+  const int X = A.X, U = A.U;
+  if (A.reward_kind == MBPO_REWARD_PENDULUM) {
+    const float *rp = A.reward_params;
+    const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
+    const float theta = atan2f(xu[1], xu[0]);
+    float mpy = fmodf(theta - rp[2] + PI_F, TWO_PI_F);
+    if (mpy < 0.f) mpy += TWO_PI_F;
+    const float d = mpy - PI_F;
+    const float r2 = xu[0] * xu[0] + xu[1] * xu[1];
+    const float g_th = g * (-2.f * rp[0] * d);
+    dxu[0] += g_th * (-xu[1] / r2);
+    dxu[1] += g_th * (xu[0] / r2);
+    dxu[2] += g * (-0.2f * xu[2]);
+    dxu[X] += g * (-2.f * rp[1] * xu[X]);
+    return;
+  }
+  const float *tp = A.reward_params, *qp = tp + X, *rp = qp + X;
+  for (int c = 0; c < X; ++c) dxu[c] += g * (-2.f * qp[c] * (xu[c] - tp[c]));
+  for (int d = 0; d < U; ++d) dxu[X + d] += g * (-2.f * rp[d] * xu[X + d]);
+}
+
+template <int H>
+__global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int HT = H / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int X = A.X, U = A.U, HZ = A.H;
+  const int ld_x = A.ld_x, ld_xu = A.ld_xu, ld_h = A.ld_h, ld_y = A.ld_y, ld_ye = A.ld_ye, LH = A.LH, EC = A.EC;
+  const int T = 16 * ld_h;
+  const int E = (A.system_kind == MBPO_SYS_ENSEMBLE) ? A.dyn.n_nets : 0;
+  const int DT = 2 * X + U + 2;   // transition row (no extras)
+  // ---- LDS carve ----
+  float *s_x = smem;                          // [16][ld_x]   x_t
+  float *s_on = s_x + 16 * ld_x;              // [16][ld_x]   normalised x_t (policy input)
+  float *s_nn = s_on + 16 * ld_x;             // [16][ld_x]   normalised x_{t+1} (critic input)
+  float *s_xn = s_nn + 16 * ld_x;             // [16][ld_x]   x_{t+1}
+  float *s_gx = s_xn + 16 * ld_x;             // [16][ld_x]   dL/dx_{t+1} carry
+  float *s_don = s_gx + 16 * ld_x;            // [16][ld_x]   policy input gradient (log-prob chain)
+  float *s_dxc = s_don + 16 * ld_x;           // [2][16][ld_x] critic input gradients
+  float *s_xu = s_dxc + 2 * 16 * ld_x;        // [16][ld_xu]  [x_t, a_t]
+  float *s_dxu = s_xu + 16 * ld_xu;           // [16][ld_xu]  dL/d[x_t, a_t] (model + reward)
+  float *s_dxe = s_dxu + 16 * ld_xu;          // [EC][16][ld_xu] per-chain model input gradients
+  float *s_y = s_dxe + EC * 16 * ld_xu;       // [16][ld_y]   policy logits
+  float *s_dyt = s_y + 16 * ld_y;             // [16][ld_y]   dL/dlogits, total
+  float *s_dyl = s_dyt + 16 * ld_y;           // [16][ld_y]   dL/dlogits, log-prob path only
+  float *s_yv = s_dyl + 16 * ld_y;            // [2][16][4]   critic outputs
+  float *s_dyv = s_yv + 2 * 16 * 4;           // [2][16][4]
+  float *s_ye = s_dyv + 2 * 16 * 4;           // [EC][16][ld_ye] ensemble outputs (one round)
+  float *s_dye = s_ye + EC * 16 * ld_ye;      // [EC][16][ld_ye]
+  const int U4 = (16 * U + 3) & ~3;
+  float *s_a = s_dye + EC * 16 * ld_ye;       // [16][U]
+  float *s_eps = s_a + U4;
+  float *s_scal = s_eps + U4;                 // [8][16] per-row scalars
+  float *s_gR = s_scal + 128;                 // [HZ+1]  dL/dR_t (row independent)
+  float *s_pi = s_gR + ((HZ + 4) & ~3);       // 2*LH tiles: policy z, h
+  float *s_B = s_pi + 2 * LH * T;             // shared region: critics (2*LH z + 4 pp) | ensemble round EC*(LH+2) | policy deltas
+  float *zp = s_pi, *hp = s_pi + LH * T;
+
+  const float gam = A.discount, lam = A.lambda_;
+  const float r_mean = A.r_ms[0], r_std = A.r_ms[1];
+  const float invNH = 1.0f / ((float)A.n * (float)HZ);
+  const float w_lp = -A.ent_coef * invNH;      // dL/d log_prob_t   (entropy_loss = -mean_t lp, weight ent_coef)
+  const unsigned long long rng_off = A.offset + (A.offset_dev ? (unsigned long long)A.offset_dev[0] : 0ull);
+  const int PL = A.pi.n_layers, CL = A.cr.n_layers, DL = A.dyn.n_layers;
+  const float *cr1 = A.cr.params, *cr2 = A.cr.params + A.cr.net_stride;
+  const int chain2 = wave >> 1, sub2 = wave & 1;   // SP = 2 grouping
+
+  // dL/dR_t: R_t enters the loss with -g^t/(nH) and R_{t-1} with g*l  (closed form, same for every trajectory)
+  if (tid == 0) {
+    float gr = 0.f, gp = 1.f;
+    for (int t = 0; t < HZ; ++t) {
+      gr = -gp * invNH + gam * lam * gr;
+      s_gR[t] = gr;
+      gp *= gam;
+    }
+    s_gR[HZ] = gam * lam * gr;   // R_H = V_{H-1}
+  }
+
+  float *slab = A.slabs + (long long)blockIdx.x * A.pi.n_params;
+  float loss_ret = 0.f, loss_lp = 0.f;   // threads 0..15
+  bool first_tile = true;
+  const long long n_tiles = (A.n + 15) >> 4;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, first_tile = false) {
+    const long long row0 = tile * 16;
+    // ================================================= FORWARD =================================================
+    for (int idx = tid; idx < 16 * X; idx += nthreads) {
+      const int r = idx / X, c = idx - r * X;
+      const long long i = row0 + r;
+      const float v = i < A.n ? A.init_states[i * X + c] : 0.f;
+      s_x[r * ld_x + c] = v;
+      if (i < A.n) A.w_xs[(i * (HZ + 1)) * X + c] = v;
+    }
+    __syncthreads();
+    for (int t = 0; t < HZ; ++t) {
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        const int r = idx / X, c = idx - r * X;
+        s_on[r * ld_x + c] = (s_x[r * ld_x + c] - A.s_mean[c]) / A.s_std[c];
+      }
+      __syncthreads();
+      {  // policy(stop_gradient(obs))  (optimizer_utils.py:85-86, bptt_optimizer.py:305-325)
+        FwdChain fc{&A.pi, A.pi.params, s_on, ld_x, s_B, s_B + T, nullptr, nullptr, s_y};
+        for (int l = 0; l < PL; ++l) {
+          if (wave < 4) group_fwd_step<HT, 4>(fc, l, ld_h, ld_y, wave, lane);
+          __syncthreads();
+        }
+      }
+      for (int idx = tid; idx < 16 * U; idx += nthreads) {
+        const int r = idx / U, d = idx - r * U;
+        const long long i = row0 + r;
+        const float mu = s_y[r * ld_y + d];
+        const float sg = fminf(fmaxf(softplus_f(s_y[r * ld_y + U + d] + A.c0), 1e-6f), 1e2f);
+        float eps = 0.f;
+        if (i < A.n) {
+          const long long nidx = (i * HZ + t) * U + d;
+          eps = A.act_noise ? A.act_noise[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
+          A.w_eps[nidx] = eps;
+        }
+        const float a = fminf(fmaxf(tanhf(mu + eps * sg), -0.999f), 0.999f);   // squash_action (:313-317)
+        s_xu[r * ld_xu + X + d] = a;
+        if (i < A.n) A.w_as[(i * HZ + t) * U + d] = a;
+      }
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        const int r = idx / X, c = idx - r * X;
+        s_xu[r * ld_xu + c] = s_x[r * ld_x + c];
+      }
+      __syncthreads();
+      // ---- System.step: next state + reward
+      if (A.system_kind == MBPO_SYS_ENSEMBLE) {
+        for (int idx = tid; idx < 16 * X; idx += nthreads) {
+          const int r = idx / X, c = idx - r * X;
+          s_xn[r * ld_x + c] = A.predict_delta ? s_x[r * ld_x + c] : 0.f;
+        }
+        for (int e0 = 0; e0 < E; e0 += EC) {
+          const int e = e0 + chain2;
+          const bool on = chain2 < EC && e < E;
+          FwdChain fc{&A.dyn, A.dyn.params + (long long)(on ? e : 0) * A.dyn.net_stride, s_xu, ld_xu, s_B + chain2 * 2 * T,
+                      s_B + chain2 * 2 * T + T, nullptr, nullptr, s_ye + chain2 * 16 * ld_ye};
+          for (int l = 0; l < DL; ++l) {
+            if (on) group_fwd_step<HT, 2>(fc, l, ld_h, ld_ye, sub2, lane);
+            __syncthreads();
+          }
+          for (int idx = tid; idx < 16 * X; idx += nthreads) {
+            const int r = idx / X, c = idx - r * X;
+            float acc = 0.f;
+            for (int cc = 0; cc < EC && e0 + cc < E; ++cc) acc += s_ye[(cc * 16 + r) * ld_ye + c];
+            s_xn[r * ld_x + c] += acc / (float)E;
+          }
+          __syncthreads();
+        }
+      } else if (tid < 16) {
+        float xn[3];
+        pend_fwd(s_xu + tid * ld_xu, s_xu[tid * ld_xu + X], A.sys_params, xn);
+        s_xn[tid * ld_x + 0] = xn[0]; s_xn[tid * ld_x + 1] = xn[1]; s_xn[tid * ld_x + 2] = xn[2];
+      }
+      if (tid < 16) {
+        const long long i = row0 + tid;
+        const float rew = reward_fwd(A, s_xu + tid * ld_xu);
+        if (i < A.n) A.w_rs[i * HZ + t] = rew;
+        s_scal[tid] = rew;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        const int r = idx / X, c = idx - r * X;
+        s_nn[r * ld_x + c] = (s_xn[r * ld_x + c] - A.s_mean[c]) / A.s_std[c];
+      }
+      __syncthreads();
+      {  // target critics on the normalised next state (:338-343)
+        FwdChain fc;
+        if (chain2 == 0) fc = FwdChain{&A.cr, cr1, s_nn, ld_x, s_B, s_B + T, nullptr, nullptr, s_yv};
+        else fc = FwdChain{&A.cr, cr2, s_nn, ld_x, s_B + 2 * T, s_B + 3 * T, nullptr, nullptr, s_yv + 16 * 4};
+        for (int l = 0; l < CL; ++l) {
+          if (chain2 < 2) group_fwd_step<HT, 2>(fc, l, ld_h, 4, sub2, lane);
+          __syncthreads();
+        }
+      }
+      if (tid < 16) {
+        const long long i = row0 + tid;
+        const float v1 = s_yv[tid * 4], v2 = s_yv[(16 + tid) * 4];
+        if (i < A.n) {
+          A.w_vs[i * HZ + t] = fminf(v1, v2);
+          A.w_km[i * HZ + t] = v1 < v2 ? 0.f : (v2 < v1 ? 1.f : 2.f);
+        }
+      }
+      // transition row + advance
+      for (int idx = tid; idx < 16 * DT; idx += nthreads) {
+        const int r = idx / DT, c = idx - r * DT;
+        const long long i = row0 + r;
+        if (i < A.n) {
+          float v;
+          if (c < X + U) v = s_xu[r * ld_xu + c];
+          else if (c == X + U) v = s_scal[r];
+          else if (c == X + U + 1) v = 1.0f;                     // discount = ones (optimizer_utils.py:114)
+          else v = s_xn[r * ld_x + (c - X - U - 2)];
+          A.transitions[(i * HZ + t) * DT + c] = v;
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        const int r = idx / X, c = idx - r * X;
+        const long long i = row0 + r;
+        const float v = s_xn[r * ld_x + c];
+        s_x[r * ld_x + c] = v;
+        if (i < A.n) A.w_xs[(i * (HZ + 1) + t + 1) * X + c] = v;
+      }
+      __syncthreads();
+    }
+    // ================================================= LAMBDA RETURNS =================================================
+    if (tid < 16) {
+      const long long i = row0 + tid;
+      if (i < A.n) {
+        float agg = A.w_vs[i * HZ + HZ - 1];
+        for (int t = HZ - 1; t >= 0; --t) {
+          const float rn = (A.w_rs[i * HZ + t] - r_mean) / r_std;
+          agg = rn + gam * A.w_vs[i * HZ + t] * (1.f - lam) + gam * lam * agg;
+          A.lambda_values[i * HZ + t] = agg;
+        }
+        float gp = 1.f, acc = 0.f;
+        for (int t = 0; t < HZ; ++t) {
+          acc += A.lambda_values[i * HZ + t] * gp;
+          gp *= gam;
+        }
+        loss_ret += acc;
+      }
+    }
+    for (int idx = tid; idx < 16 * ld_x; idx += nthreads) s_gx[idx] = 0.f;
+    __syncthreads();
+    // ================================================= BACKWARD =================================================
+    for (int t = HZ - 1; t >= 0; --t) {
+      // ---- reload the step: x_t, x_{t+1}, a_t, eps_t
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        const int r = idx / X, c = idx - r * X;
+        const long long i = row0 + r;
+        const float xt = i < A.n ? A.w_xs[(i * (HZ + 1) + t) * X + c] : 0.f;
+        const float xn = i < A.n ? A.w_xs[(i * (HZ + 1) + t + 1) * X + c] : 0.f;
+        s_x[r * ld_x + c] = xt;
+        s_xu[r * ld_xu + c] = xt;
+        s_on[r * ld_x + c] = (xt - A.s_mean[c]) / A.s_std[c];
+        s_nn[r * ld_x + c] = (xn - A.s_mean[c]) / A.s_std[c];
+      }
+      for (int idx = tid; idx < 16 * U; idx += nthreads) {
+        const int r = idx / U, d = idx - r * U;
+        const long long i = row0 + r;
+        const float a = i < A.n ? A.w_as[(i * HZ + t) * U + d] : 0.f;
+        s_a[idx] = a;
+        s_eps[idx] = i < A.n ? A.w_eps[(i * HZ + t) * U + d] : 0.f;
+        s_xu[r * ld_xu + X + d] = a;
+      }
+      __syncthreads();
+      // ---- recompute: policy (z,h kept) || target critics (z kept)
+      float *zc1 = s_B, *zc2 = s_B + LH * T, *ppc = s_B + 2 * LH * T;   // critics: z | z | 4 pp tiles
+      {
+        FwdChain fc;
+        if (chain2 == 0) fc = FwdChain{&A.pi, A.pi.params, s_on, ld_x, nullptr, nullptr, zp, hp, s_y};
+        else if (chain2 == 1) fc = FwdChain{&A.cr, cr1, s_nn, ld_x, ppc, ppc + T, zc1, nullptr, s_yv};
+        else fc = FwdChain{&A.cr, cr2, s_nn, ld_x, ppc + 2 * T, ppc + 3 * T, zc2, nullptr, s_yv + 16 * 4};
+        const int Lm = PL > CL ? PL : CL;
+        for (int l = 0; l < Lm; ++l) {
+          if (chain2 < 3) group_fwd_step<HT, 2>(fc, l, ld_h, chain2 == 0 ? ld_y : 4, sub2, lane);
+          __syncthreads();
+        }
+      }
+      // ---- dL/dV_t on the arg-min target critic
+      if (tid < 16) {
+        const long long i = row0 + tid;
+        float dV = s_gR[t] * gam * (1.f - lam);
+        if (t == HZ - 1) dV += s_gR[HZ];
+        const float km = i < A.n ? A.w_km[i * HZ + t] : 0.f;
+        if (i >= A.n) dV = 0.f;
+        s_dyv[tid * 4] = km == 0.f ? dV : (km == 2.f ? 0.5f * dV : 0.f);
+        s_dyv[(16 + tid) * 4] = km == 1.f ? dV : (km == 2.f ? 0.5f * dV : 0.f);
+      }
+      __syncthreads();
+      {  // critic input gradients
+        const int net = chain2 - 1;
+        const float *dcur = s_dyv + (net > 0 ? 16 * 4 : 0);
+        int ldc = 4;
+        float *d0 = ppc + (net > 0 ? 2 * T : 0), *d1 = d0 + T;
+        for (int l = CL - 1; l >= 0; --l) {
+          float *dn = (l & 1) ? d1 : d0;
+          if (chain2 == 1 || chain2 == 2)
+            group_bwd_dgrad_layer<HT, 2>(A.cr, net ? cr2 : cr1, l, dcur, ldc, net ? zc2 : zc1, ld_h, dn, s_dxc + (net > 0 ? 16 * ld_x : 0), ld_x, sub2, lane);
+          __syncthreads();
+          dcur = dn;
+          ldc = ld_h;
+        }
+      }
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        const int r = idx / X, c = idx - r * X;
+        s_gx[r * ld_x + c] += (s_dxc[r * ld_x + c] + s_dxc[(16 + r) * ld_x + c]) / A.s_std[c];   // d nn / d x' = 1/std
+      }
+      for (int idx = tid; idx < 16 * ld_xu; idx += nthreads) s_dxu[idx] = 0.f;
+      __syncthreads();
+      // ---- model backward: dL/d[x_t, a_t] from dL/dx_{t+1}
+      if (A.system_kind == MBPO_SYS_ENSEMBLE) {
+        if (A.predict_delta)
+          for (int idx = tid; idx < 16 * X; idx += nthreads) {
+            const int r = idx / X, c = idx - r * X;
+            s_dxu[r * ld_xu + c] = s_gx[r * ld_x + c];
+          }
+        const int dout = A.dyn.dims[DL];
+        for (int e0 = 0; e0 < E; e0 += EC) {
+          const int e = e0 + chain2;
+          const bool on = chain2 < EC && e < E;
+          const float *ep = A.dyn.params + (long long)(on ? e : 0) * A.dyn.net_stride;
+          float *ze = s_B + chain2 * (LH + 2) * T, *ppe = ze + LH * T;
+          FwdChain fc{&A.dyn, ep, s_xu, ld_xu, ppe, ppe + T, ze, nullptr, s_ye + chain2 * 16 * ld_ye};
+          for (int l = 0; l < DL; ++l) {
+            if (on) group_fwd_step<HT, 2>(fc, l, ld_h, ld_ye, sub2, lane);
+            __syncthreads();
+          }
+          for (int idx = tid; idx < EC * 16 * dout; idx += nthreads) {
+            const int cc = idx / (16 * dout), rem = idx - cc * 16 * dout;
+            const int r = rem / dout, c = rem - r * dout;
+            s_dye[(cc * 16 + r) * ld_ye + c] = c < X ? s_gx[r * ld_x + c] / (float)E : 0.f;   // x' = base + mean_e mu_e
+          }
+          __syncthreads();
+          {
+            const float *dcur = s_dye + chain2 * 16 * ld_ye;
+            int ldc = ld_ye;
+            for (int l = DL - 1; l >= 0; --l) {
+              float *dn = (l & 1) ? ppe + T : ppe;
+              if (on) group_bwd_dgrad_layer<HT, 2>(A.dyn, ep, l, dcur, ldc, ze, ld_h, dn, s_dxe + chain2 * 16 * ld_xu, ld_xu, sub2, lane);
+              __syncthreads();
+              dcur = dn;
+              ldc = ld_h;
+            }
+          }
+          for (int idx = tid; idx < 16 * (X + U); idx += nthreads) {
+            const int r = idx / (X + U), c = idx - r * (X + U);
+            float acc = 0.f;
+            for (int cc = 0; cc < EC && e0 + cc < E; ++cc) acc += s_dxe[(cc * 16 + r) * ld_xu + c];
+            s_dxu[r * ld_xu + c] += acc;
+          }
+          __syncthreads();
+        }
+      } else if (tid < 16) {
+        float dx[3], du;
+        pend_vjp(s_xu + tid * ld_xu, s_xu[tid * ld_xu + X], A.sys_params, s_gx + tid * ld_x, dx, &du);
+        s_dxu[tid * ld_xu + 0] = dx[0]; s_dxu[tid * ld_xu + 1] = dx[1]; s_dxu[tid * ld_xu + 2] = dx[2];
+        s_dxu[tid * ld_xu + X] = du;
+      }
+      __syncthreads();
+      // ---- reward gradient, action / log-prob terms -> dL/dlogits (total, log-prob path)
+      if (tid < 16) {
+        const int r = tid;
+        const long long i = row0 + r;
+        const bool ok = i < A.n;
+        reward_vjp(A, s_xu + r * ld_xu, ok ? s_gR[t] / r_std : 0.f, s_dxu + r * ld_xu);   // dL/dr_t = dL/dR_t / r_std
+        float lp = 0.f;
+        for (int d = 0; d < U; ++d) {
+          const float mu = s_y[r * ld_y + d], sraw = s_y[r * ld_y + U + d] + A.c0;
+          const float sp = softplus_f(sraw);
+          const bool sin_ = (sp > 1e-6f) && (sp < 1e2f);
+          const float sg = fminf(fmaxf(sp, 1e-6f), 1e2f);
+          const float dsig = sin_ ? sigmoid_f(sraw) : 0.f;
+          const float a = s_a[r * U + d], eps = s_eps[r * U + d];
+          const float th = tanhf(mu + eps * sg);
+          const float dadw = (th > -0.999f && th < 0.999f) ? (1.f - th * th) : 0.f;
+          const float om = 1.f - a * a;
+          const float u = 0.5f * logf((1.f + a) / (1.f - a));            // atanh(a)   (:111-120)
+          const float q = (u - mu) / sg;
+          lp += -0.5f * q * q - logf(sg) - LOG_SQRT_2PI_B - logf(om);
+          const float dlp_da = (-q / sg) / om + 2.f * a / om;
+          const float Ga = s_dxu[r * ld_xu + X + d] + w_lp * dlp_da;
+          const float l_mu = w_lp * (q / sg), l_sr = w_lp * ((q * q - 1.f) / sg) * dsig;
+          const float a_mu = Ga * dadw, a_sr = Ga * dadw * eps * dsig;
+          s_dyl[r * ld_y + d] = ok ? l_mu : 0.f;
+          s_dyl[r * ld_y + U + d] = ok ? l_sr : 0.f;
+          s_dyt[r * ld_y + d] = ok ? l_mu + a_mu : 0.f;
+          s_dyt[r * ld_y + U + d] = ok ? l_sr + a_sr : 0.f;
+        }
+        if (ok) loss_lp += lp;
+      }
+      __syncthreads();
+      // ---- policy backward: chain 0 = delta(total), chain 1 = delta(log-prob path) with input gradient, chain 2 = wgrad
+      {
+        float *dt0 = s_B, *dt1 = s_B + T, *dl0 = s_B + 2 * T, *dl1 = s_B + 3 * T;
+        const float *dcur_t = s_dyt, *dcur_l = s_dyl;
+        int ldc = ld_y;
+        const bool accum = !(first_tile && t == HZ - 1);
+        for (int l = PL - 1; l >= 0; --l) {
+          float *dnt = (l & 1) ? dt1 : dt0, *dnl = (l & 1) ? dl1 : dl0;
+          if (chain2 == 0) group_bwd_dgrad_layer<HT, 2>(A.pi, A.pi.params, l, dcur_t, ldc, zp, ld_h, dnt, nullptr, ld_x, sub2, lane);
+          else if (chain2 == 1) group_bwd_dgrad_layer<HT, 2>(A.pi, A.pi.params, l, dcur_l, ldc, zp, ld_h, dnl, s_don, ld_x, sub2, lane);
+          else if (chain2 == 2) group_bwd_wgrad_layer<HT, 2>(A.pi, l, s_on, ld_x, hp, ld_h, dcur_t, ldc, slab, sub2, lane, accum);
+          __syncthreads();
+          dcur_t = dnt;
+          dcur_l = dnl;
+          ldc = ld_h;
+        }
+      }
+      // ---- dL/dx_t = model/reward x-part + policy-input path (through the state normaliser)
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        const int r = idx / X, c = idx - r * X;
+        s_gx[r * ld_x + c] = s_dxu[r * ld_xu + c] + s_don[r * ld_x + c] / A.s_std[c];
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < 16) {
+    s_scal[tid] = loss_ret;
+    s_scal[16 + tid] = loss_lp;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      a += s_scal[i];
+      b += s_scal[16 + i];
+    }
+    A.extras[blockIdx.x * 2 + 0] = a;
+    A.extras[blockIdx.x * 2 + 1] = b;
+  }
+}
+
+struct BpttReduceArgs {
+  const float *slabs, *extras;
+  int n_slabs, P, H;
+  long long n;
+  float ent_coef;
+  float *grads, *metrics;
+};
+
+__global__ void __launch_bounds__(256) k_bptt_reduce(BpttReduceArgs A) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < A.P) {
+    float g = 0.f;
+    for (int s = 0; s < A.n_slabs; ++s) g += A.slabs[(long long)s * A.P + i];
+    A.grads[i] = g;
+  }
+  if (i == 0) {
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < A.n_slabs; ++s) {
+      a += A.extras[s * 2 + 0];
+      b += A.extras[s * 2 + 1];
+    }
+    const float invNH = 1.0f / ((float)A.n * (float)A.H);
+    const float ent = -b * invNH;                 // entropy_loss = -mean log_prob
+    A.metrics[0] = -a * invNH + A.ent_coef * ent; // actor_loss (:352)
+    A.metrics[1] = ent;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+struct BpttPlan {
+  MlpDev pi, cr, dyn;
+  int P, C, H, LH, EC, n_slabs;
+  int ld_x, ld_xu, ld_h, ld_y, ld_ye;
+  size_t lds;
+  long long o_xs, o_as, o_eps, o_rs, o_vs, o_km, o_slabs, o_extras, total;
+};
+
+static int bptt_hidden(const int *dims, int n_layers) {
+  if (n_layers < 2) return -1;
+  for (int l = 2; l < n_layers; ++l)
+    if (dims[l] != dims[1]) return -1;
+  return dims[1];
+}
+
+static int bptt_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+static int bptt_plan(const mbpo_bptt_desc *d, BpttPlan *pl, bool need_ptrs) {
+  MBPO_REQUIRE(d, MBPO_ERR_ARG, "bptt: null descriptor");
+  MBPO_REQUIRE(d->x_dim > 0 && d->u_dim > 0 && d->horizon > 0 && d->horizon <= 1024 && d->n > 0, MBPO_ERR_ARG, "bptt: bad sizes");
+  MBPO_REQUIRE(d->actor_layers >= 2 && d->actor_layers <= MBPO_MAX_LAYERS && d->critic_layers >= 2 && d->critic_layers <= MBPO_MAX_LAYERS,
+               MBPO_ERR_ARG, "bptt: networks need at least one hidden layer");
+  MBPO_REQUIRE(d->actor_dims[0] == d->x_dim && d->actor_dims[d->actor_layers] == 2 * d->u_dim, MBPO_ERR_ARG, "bptt: actor must map [x] -> [2u]");
+  MBPO_REQUIRE(d->critic_dims[0] == d->x_dim && d->critic_dims[d->critic_layers] == 1, MBPO_ERR_ARG, "bptt: critic must map [x] -> [1]");
+  const int Ha = bptt_hidden(d->actor_dims, d->actor_layers), Hc = bptt_hidden(d->critic_dims, d->critic_layers);
+  MBPO_REQUIRE(Ha == Hc && Ha == 64, MBPO_ERR_UNSUPPORTED, "bptt: actor/critic hidden layers must all be 64 wide (got %d, %d)", Ha, Hc);
+  mbpo_mlp_desc md;
+  md.net_stride = 0; md.n_nets = 1;
+  md.params = d->actor_params ? d->actor_params : (const float *)16;
+  md.n_layers = d->actor_layers;
+  for (int l = 0; l <= d->actor_layers; ++l) md.dims[l] = d->actor_dims[l];
+  md.activation = d->actor_activation;
+  int rc = mbpo_make_mlp_dev(&md, &pl->pi, "bptt.actor");
+  if (rc != MBPO_OK) return rc;
+  pl->P = pl->pi.n_params;
+  md.params = d->target_critic_params ? d->target_critic_params : (const float *)16;
+  md.n_layers = d->critic_layers;
+  for (int l = 0; l <= d->critic_layers; ++l) md.dims[l] = d->critic_dims[l];
+  md.activation = d->critic_activation;
+  rc = mbpo_make_mlp_dev(&md, &pl->cr, "bptt.critic");
+  if (rc != MBPO_OK) return rc;
+  pl->C = pl->cr.n_params;
+  pl->cr.n_nets = 2;
+  pl->cr.net_stride = pl->C;
+  int lh = d->actor_layers - 1;
+  if (d->critic_layers - 1 > lh) lh = d->critic_layers - 1;
+  int dyn_out = 0;
+  int E = 0;
+  if (d->system_kind == MBPO_SYS_ENSEMBLE) {
+    rc = mbpo_make_mlp_dev(&d->dynamics, &pl->dyn, "bptt.dynamics");
+    if (rc != MBPO_OK) return rc;
+    E = pl->dyn.n_nets;
+    dyn_out = pl->dyn.dims[pl->dyn.n_layers];
+    MBPO_REQUIRE(pl->dyn.dims[0] == d->x_dim + d->u_dim && dyn_out >= d->x_dim, MBPO_ERR_ARG, "bptt: dynamics must map [x+u] -> [>= x]");
+    MBPO_REQUIRE(pl->dyn.n_layers >= 2 && bptt_hidden(pl->dyn.dims, pl->dyn.n_layers) == 64, MBPO_ERR_UNSUPPORTED,
+                 "bptt: dynamics hidden layers must all be 64 wide");
+    if (pl->dyn.n_layers - 1 > lh) lh = pl->dyn.n_layers - 1;
+  } else if (d->system_kind == MBPO_SYS_PENDULUM) {
+    MBPO_REQUIRE(d->x_dim == 3 && d->u_dim == 1 && d->sys_params, MBPO_ERR_ARG, "bptt: pendulum system needs x=3,u=1,sys_params");
+    memset(&pl->dyn, 0, sizeof(pl->dyn));
+    pl->dyn.n_layers = 1;
+  } else {
+    MBPO_REQUIRE(false, MBPO_ERR_ARG, "bptt: unknown system_kind");
+  }
+  MBPO_REQUIRE(d->reward_kind == MBPO_REWARD_QUADRATIC || (d->reward_kind == MBPO_REWARD_PENDULUM && d->x_dim == 3 && d->u_dim == 1),
+               MBPO_ERR_ARG, "bptt: bad reward_kind");
+  pl->H = 64;
+  pl->LH = lh;
+  auto up4 = [](int v) { return (v + 3) & ~3; };
+  pl->ld_x = up4(d->x_dim) + 4;
+  pl->ld_xu = up4(d->x_dim + d->u_dim) + 4;
+  pl->ld_h = 64 + 4;
+  pl->ld_y = up4(2 * d->u_dim) + 4;
+  pl->ld_ye = up4(dyn_out > 0 ? dyn_out : 1) + 4;
+  const int T = 16 * pl->ld_h;
+  // ensemble chains per round: as many as fit next to everything else in 160 KiB of LDS (at most 4 = 8 waves / 2)
+  pl->EC = 0;
+  for (int ec = E > 0 ? (E < 4 ? E : 4) : 1; ec >= 1; --ec) {
+    int regionB = 2 * pl->LH + 4;                                     // critics: 2 z stacks + 4 ping-pong tiles
+    if (ec * (pl->LH + 2) > regionB) regionB = ec * (pl->LH + 2);     // one ensemble round: per chain z stack + 2 tiles
+    size_t f = 8ull * 16 * pl->ld_x + 2ull * 16 * pl->ld_xu + (size_t)ec * 16 * pl->ld_xu + 3ull * 16 * pl->ld_y + 4ull * 16 * 4 +
+               2ull * ec * 16 * pl->ld_ye + 2ull * up4(16 * d->u_dim) + 128 + up4(d->horizon + 4) + (size_t)(2 * pl->LH + regionB) * T;
+    if (f * sizeof(float) <= 160 * 1024) {
+      pl->EC = ec;
+      pl->lds = f * sizeof(float);
+      break;
+    }
+  }
+  MBPO_REQUIRE(pl->EC >= 1, MBPO_ERR_UNSUPPORTED, "bptt: shapes do not fit 160 KiB of LDS");
+  long long tiles = (d->n + 15) / 16;
+  long long cap = bptt_num_cus();
+  pl->n_slabs = (int)(tiles < cap ? tiles : cap);
+  long long o = 0;
+  auto take = [&](long long n) { long long at = o; o += (n + 3) & ~3LL; return at; };
+  pl->o_xs = take(d->n * (d->horizon + 1) * d->x_dim);
+  pl->o_as = take(d->n * d->horizon * d->u_dim);
+  pl->o_eps = take(d->n * d->horizon * d->u_dim);
+  pl->o_rs = take(d->n * d->horizon);
+  pl->o_vs = take(d->n * d->horizon);
+  pl->o_km = take(d->n * d->horizon);
+  pl->o_slabs = take((long long)pl->n_slabs * pl->P);
+  pl->o_extras = take((long long)pl->n_slabs * 2);
+  pl->total = o;
+  if (need_ptrs)
+    MBPO_REQUIRE(d->actor_params && d->target_critic_params && d->reward_params && d->state_mean && d->state_std && d->reward_mean_std &&
+                     d->init_states && d->transitions && d->lambda_values && d->grads && d->metrics && d->workspace,
+                 MBPO_ERR_ARG, "bptt: null pointer");
+  return MBPO_OK;
+}
+
+extern "C" int64_t mbpo_bptt_workspace_floats(const mbpo_bptt_desc *d) {
+  BpttPlan pl;
+  int rc = bptt_plan(d, &pl, false);
+  if (rc != MBPO_OK) return rc;
+  return pl.total;
+}
+
+extern "C" int mbpo_bptt_actor_grads(const mbpo_bptt_desc *d, void *stream) {
+  BpttPlan pl;
+  int rc = bptt_plan(d, &pl, true);
+  if (rc != MBPO_OK) return rc;
+  BpttArgs A;
+  A.pi = pl.pi; A.cr = pl.cr; A.dyn = pl.dyn;
+  A.X = d->x_dim; A.U = d->u_dim; A.H = d->horizon; A.n = d->n;
+  A.system_kind = d->system_kind; A.predict_delta = d->ens_predict_delta; A.reward_kind = d->reward_kind;
+  A.reward_params = d->reward_params; A.sys_params = d->sys_params; A.s_mean = d->state_mean; A.s_std = d->state_std;
+  A.r_ms = d->reward_mean_std; A.init_states = d->init_states; A.act_noise = d->act_noise;
+  A.seed = d->seed; A.offset = d->offset; A.offset_dev = d->offset_dev;
+  const double s0 = (double)d->init_stddev;
+  A.c0 = (float)(s0 < 20.0 ? log(exp(s0) - 1.0) : s0);            // inv_softplus (:107-108)
+  A.discount = d->discount; A.lambda_ = d->lambda_; A.ent_coef = d->ent_coef;
+  A.transitions = d->transitions; A.lambda_values = d->lambda_values;
+  float *ws = d->workspace;
+  A.w_xs = ws + pl.o_xs; A.w_as = ws + pl.o_as; A.w_eps = ws + pl.o_eps; A.w_rs = ws + pl.o_rs; A.w_vs = ws + pl.o_vs;
+  A.w_km = ws + pl.o_km; A.slabs = ws + pl.o_slabs; A.extras = ws + pl.o_extras;
+  A.ld_x = pl.ld_x; A.ld_xu = pl.ld_xu; A.ld_h = pl.ld_h; A.ld_y = pl.ld_y; A.ld_ye = pl.ld_ye; A.LH = pl.LH; A.EC = pl.EC;
+  rc = mbpo_ensure_lds<k_bptt_actor<64>>(pl.lds, "bptt_actor_grads");
+  if (rc != MBPO_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_bptt_actor<64>, dim3(pl.n_slabs), dim3(512), pl.lds, st, A);
+  BpttReduceArgs R;
+  R.slabs = A.slabs; R.extras = A.extras; R.n_slabs = pl.n_slabs; R.P = pl.P; R.H = d->horizon; R.n = d->n; R.ent_coef = d->ent_coef;
+  R.grads = d->grads; R.metrics = d->metrics;
+  hipLaunchKernelGGL(k_bptt_reduce, dim3((pl.P + 255) / 256), dim3(256), 0, st, R);
+  MBPO_CHECK_LAUNCH("bptt_actor_grads");
+  return MBPO_OK;
+}

@@ -113,6 +113,25 @@ class PpoDesc(C.Structure):
     ]
 
 
+class BpttDesc(C.Structure):
+    _fields_ = [
+        ("x_dim", C.c_int32), ("u_dim", C.c_int32), ("horizon", C.c_int32),
+        ("actor_layers", C.c_int32), ("actor_dims", C.c_int32 * (MBPO_MAX_LAYERS + 1)),
+        ("critic_layers", C.c_int32), ("critic_dims", C.c_int32 * (MBPO_MAX_LAYERS + 1)),
+        ("actor_activation", C.c_int32), ("critic_activation", C.c_int32),
+        ("init_stddev", C.c_float),
+        ("actor_params", C.c_void_p), ("target_critic_params", C.c_void_p),
+        ("system_kind", C.c_int32), ("dynamics", MlpDesc), ("ens_predict_delta", C.c_int32),
+        ("reward_kind", C.c_int32), ("reward_params", C.c_void_p), ("sys_params", C.c_void_p),
+        ("state_mean", C.c_void_p), ("state_std", C.c_void_p), ("reward_mean_std", C.c_void_p),
+        ("init_states", C.c_void_p), ("n", C.c_int64),
+        ("act_noise", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64), ("offset_dev", C.c_void_p),
+        ("discount", C.c_float), ("lambda_", C.c_float), ("ent_coef", C.c_float),
+        ("transitions", C.c_void_p), ("lambda_values", C.c_void_p), ("grads", C.c_void_p), ("metrics", C.c_void_p),
+        ("workspace", C.c_void_p),
+    ]
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -175,6 +194,14 @@ def _bind_optional(lib: C.CDLL) -> None:
     if fn is not None:
         fn.restype = C.c_int64
         fn.argtypes = [C.POINTER(PpoDesc)]
+    fn = getattr(lib, "mbpo_bptt_actor_grads", None)
+    if fn is not None:
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(BpttDesc), vp]
+    fn = getattr(lib, "mbpo_bptt_workspace_floats", None)
+    if fn is not None:
+        fn.restype = C.c_int64
+        fn.argtypes = [C.POINTER(BpttDesc)]
     fn = getattr(lib, "mbpo_sac_grads_phase", None)
     if fn is not None:
         fn.restype = C.c_int

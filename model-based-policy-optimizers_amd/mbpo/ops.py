@@ -406,3 +406,75 @@ class PpoUpdater:
         if self.all_reduce is not None:
             self.all_reduce(self.grads)
         check(self.lib.mbpo_ppo_apply(C.byref(d), st), "mbpo_ppo_apply")
+
+
+# ------------------------------------------------------------------------------------------------ BPTT actor gradient (B1-B5)
+class BpttActorGrad:
+    """Drives mbpo_bptt_actor_grads: forward rollout through the model from `n` initial states, lambda-returns, and the
+    backward sweep with respect to the actor parameters.  Buffers (transitions, lambda_values, grads, metrics) are owned here."""
+
+    def __init__(self, *, x_dim: int, u_dim: int, horizon: int, actor_dims: Sequence[int], critic_dims: Sequence[int], n: int,
+                 device, actor_activation: str = "swish", critic_activation: str = "swish", init_stddev: float = 1.0,
+                 discount: float = 0.99, lambda_: float = 0.97, ent_coef: float = 0.005, seed: int = 0):
+        self.lib = load()
+        self.x_dim, self.u_dim, self.horizon, self.n = x_dim, u_dim, horizon, n
+        self.device = torch.device(device)
+        self.actor_spec = MlpSpec(list(actor_dims), actor_activation, 1)
+        self.critic_spec = MlpSpec(list(critic_dims), critic_activation, 2)
+        self.P, self.C = self.actor_spec.n_params, self.critic_spec.n_params
+        f = lambda *s: torch.zeros(*s, device=self.device, dtype=torch.float32)
+        self.row_len = 2 * x_dim + u_dim + 2
+        self.transitions, self.lambda_values = f(n * horizon, self.row_len), f(n * horizon)
+        self.grads, self.metrics = f(self.P), f(2)
+        d = _hip.BpttDesc()
+        d.x_dim, d.u_dim, d.horizon, d.n = x_dim, u_dim, horizon, n
+        d.actor_layers, d.critic_layers = len(actor_dims) - 1, len(critic_dims) - 1
+        for i, v in enumerate(actor_dims):
+            d.actor_dims[i] = int(v)
+        for i, v in enumerate(critic_dims):
+            d.critic_dims[i] = int(v)
+        d.actor_activation, d.critic_activation = _hip.ACT_IDS[actor_activation], _hip.ACT_IDS[critic_activation]
+        d.init_stddev, d.discount, d.lambda_, d.ent_coef = init_stddev, discount, lambda_, ent_coef
+        d.seed = seed
+        self.desc = d
+        self.workspace = None
+
+    def __call__(self, *, actor_params, target_critic_params, init_states, state_mean, state_std, reward_mean_std,
+                 system_kind: int, reward_kind: int, reward_params, sys_params=None, dyn_params=None, dyn_spec: Optional[MlpSpec] = None,
+                 ens_predict_delta: bool = True, act_noise=None, offset: int = 0, offset_dev=None):
+        d = self.desc
+        for t, nm in ((actor_params, "actor_params"), (target_critic_params, "target_critic_params"), (init_states, "init_states"),
+                      (state_mean, "state_mean"), (state_std, "state_std"), (reward_mean_std, "reward_mean_std"),
+                      (reward_params, "reward_params")):
+            _req(t, nm)
+        if tuple(init_states.shape) != (self.n, self.x_dim):
+            raise ValueError(f"init_states must be [{self.n},{self.x_dim}]")
+        if actor_params.numel() != self.P or target_critic_params.numel() != 2 * self.C:
+            raise ValueError("actor_params / target_critic_params have the wrong size")
+        d.actor_params, d.target_critic_params = actor_params.data_ptr(), target_critic_params.data_ptr()
+        d.system_kind, d.reward_kind, d.ens_predict_delta = system_kind, reward_kind, int(ens_predict_delta)
+        if system_kind == _hip.SYS_ENSEMBLE:
+            if dyn_params is None or dyn_spec is None:
+                raise ValueError("ensemble system needs dyn_params and dyn_spec")
+            d.dynamics = dyn_spec.desc(dyn_params)
+        d.reward_params = reward_params.data_ptr()
+        d.sys_params = ptr(_req(sys_params, "sys_params")) if sys_params is not None else None
+        d.state_mean, d.state_std, d.reward_mean_std = state_mean.data_ptr(), state_std.data_ptr(), reward_mean_std.data_ptr()
+        d.init_states = init_states.data_ptr()
+        if act_noise is not None:
+            _req(act_noise, "act_noise")
+            if act_noise.numel() != self.n * self.horizon * self.u_dim:
+                raise ValueError("act_noise must be [n,H,u]")
+        d.act_noise = ptr(act_noise)
+        d.offset = offset
+        d.offset_dev = ptr(offset_dev)
+        d.transitions, d.lambda_values = self.transitions.data_ptr(), self.lambda_values.data_ptr()
+        d.grads, d.metrics = self.grads.data_ptr(), self.metrics.data_ptr()
+        if self.workspace is None:
+            nws = self.lib.mbpo_bptt_workspace_floats(C.byref(d))
+            if nws < 0:
+                check(int(nws), "mbpo_bptt_workspace_floats")
+            self.workspace = torch.zeros(int(nws), device=self.device, dtype=torch.float32)
+        d.workspace = self.workspace.data_ptr()
+        check(self.lib.mbpo_bptt_actor_grads(C.byref(d), current_stream_ptr()), "mbpo_bptt_actor_grads")
+        return self.grads

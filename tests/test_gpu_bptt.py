@@ -1,0 +1,117 @@
+"""GPU parity: BPTT actor gradient (B1-B5) — forward rollout through the model, target critics, lambda-return and the
+hand-written reverse sweep, vs torch autograd THROUGH the model (oracle/bptt.py).
+
+Tolerances (fp32): transitions / lambda-values 2e-4 (H-step rollouts feed rounding back through the dynamics); actor
+gradient atol 5e-6 + rtol 2e-3 against the fp32 oracle and rtol 1e-3 against fp64 (the gradient is a sum over H chained
+Jacobian products); losses 2e-5.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bptt as obptt
+from oracle import nets as onets
+from oracle import systems as osys
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(X, U, H, n, system, E, seed, hidden=(64, 64, 64)):
+    g = torch.Generator().manual_seed(seed)
+    cfg = obptt.BpttConfig(x_dim=X, u_dim=U, actor_dims=[X, *hidden, 2 * U], critic_dims=[X, *hidden, 1], horizon=H,
+                           discount=0.97, lambda_=0.9, ent_coef=0.05, init_stddev=1.0)
+    ap = onets.init_mlp_flat(cfg.actor_dims, g) + 0.02 * torch.randn(cfg.P, generator=g)
+    cp = torch.cat([onets.init_mlp_flat(cfg.critic_dims, g) + 0.02 * torch.randn(cfg.C, generator=g) for _ in range(2)])
+    if X == 3:
+        th = (torch.rand(n, generator=g) * 2 - 1) * math.pi
+        x0 = torch.stack([torch.cos(th), torch.sin(th), (torch.rand(n, generator=g) * 2 - 1) * 4], 1)
+    else:
+        x0 = torch.randn(n, X, generator=g)
+    noise = torch.randn(n, H, U, generator=g)
+    s_mean, s_std = torch.randn(X, generator=g) * 0.2, torch.rand(X, generator=g) + 0.6
+    r_ms = torch.tensor([-1.3, 2.1])
+    extra = {}
+    if system == "pendulum":
+        tsys = obptt.TorchPendulumSystem()
+    else:
+        dd = [X + U, *hidden, 2 * X]
+        dp = torch.cat([onets.init_mlp_flat(dd, g) * 0.5 + 0.01 * torch.randn(onets.n_params(dd), generator=g) for _ in range(E)])
+        tgt, q, r = torch.randn(X, generator=g) * 0.3, torch.rand(X, generator=g), torch.rand(U, generator=g) * 0.2
+        tsys = obptt.TorchEnsembleSystem(dp, dd, E, X, U, tgt, q, r)
+        extra = dict(dd=dd, dp=dp, tgt=tgt, q=q, r=r)
+    return cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, tsys, extra
+
+
+def _run_hip(dev, cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, system, extra, n, explicit_noise=True, seed=0, offset=0):
+    from mbpo import _hip, ops
+    op = ops.BpttActorGrad(x_dim=cfg.x_dim, u_dim=cfg.u_dim, horizon=cfg.horizon, actor_dims=cfg.actor_dims,
+                           critic_dims=cfg.critic_dims, n=n, device=dev, init_stddev=cfg.init_stddev, discount=cfg.discount,
+                           lambda_=cfg.lambda_, ent_coef=cfg.ent_coef, seed=seed)
+    kw = {}
+    if system == "pendulum":
+        pp = osys.PendulumParams()
+        kw.update(system_kind=_hip.SYS_PENDULUM, reward_kind=_hip.REWARD_PENDULUM,
+                  reward_params=torch.tensor(pp.reward_vector()).to(dev), sys_params=torch.tensor(pp.sys_vector()).to(dev))
+    else:
+        kw.update(system_kind=_hip.SYS_ENSEMBLE, reward_kind=_hip.REWARD_QUADRATIC,
+                  reward_params=torch.cat([extra["tgt"], extra["q"], extra["r"]]).to(dev), dyn_params=extra["dp"].to(dev),
+                  dyn_spec=ops.MlpSpec(extra["dd"], "swish", extra["dp"].numel() // onets.n_params(extra["dd"])))
+    op(actor_params=ap.to(dev), target_critic_params=cp.to(dev), init_states=x0.to(dev), state_mean=s_mean.to(dev),
+       state_std=s_std.to(dev), reward_mean_std=r_ms.to(dev), act_noise=noise.to(dev) if explicit_noise else None, offset=offset, **kw)
+    torch.cuda.synchronize()
+    return op
+
+
+@pytest.mark.parametrize("X,U,H,n,system,E", [
+    (3, 1, 10, 20, "pendulum", 0),       # the reference's BPTT test system (tests/test_bptt.py), ragged n
+    (3, 1, 20, 16, "pendulum", 0),       # reference horizon 20
+    (4, 1, 5, 48, "ensemble", 5),        # north-star shape, horizon 5
+    (4, 2, 6, 17, "ensemble", 3),        # u=2 (sum-over-A log-prob), ragged n
+    (17, 6, 8, 16, "ensemble", 10),      # BASELINE config 5 shape (shorter horizon for the oracle)
+])
+def test_bptt_actor_grad_parity(dev, X, U, H, n, system, E):
+    cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, tsys, extra = _setup(X, U, H, n, system, E, 0)
+    g_ref, loss_ref, aux = obptt.actor_grads(cfg, tsys, ap, cp, x0, noise, s_mean, s_std, r_ms[0], r_ms[1])
+    d = lambda t: t.double()
+    tsys64 = obptt.TorchPendulumSystem() if system == "pendulum" else obptt.TorchEnsembleSystem(
+        d(extra["dp"]), extra["dd"], E, X, U, d(extra["tgt"]), d(extra["q"]), d(extra["r"]))
+    g64, loss64, aux64 = obptt.actor_grads(cfg, tsys64, d(ap), d(cp), d(x0), d(noise), d(s_mean), d(s_std), d(r_ms[0]), d(r_ms[1]))
+    op = _run_hip(dev, cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, system, extra, n)
+    rows = op.transitions.cpu().reshape(n, H, -1)
+    torch.testing.assert_close(rows[..., :X], aux["observation"], atol=2e-4, rtol=2e-4)
+    torch.testing.assert_close(rows[..., X:X + U], aux["action"], atol=2e-4, rtol=2e-4)
+    torch.testing.assert_close(rows[..., X + U], aux["reward"], atol=5e-4, rtol=5e-4)
+    assert torch.all(rows[..., X + U + 1] == 1.0)
+    torch.testing.assert_close(rows[..., X + U + 2:], aux["next_observation"], atol=2e-4, rtol=2e-4)
+    torch.testing.assert_close(op.lambda_values.cpu().reshape(n, H), aux["lambda_values"], atol=5e-4, rtol=5e-4)
+    m = op.metrics.cpu().tolist()
+    np.testing.assert_allclose(m[0], loss64, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(m[1], float(aux64["entropy_loss"]), rtol=1e-4, atol=2e-5)
+    g = op.grads.cpu()
+    torch.testing.assert_close(g, g_ref, atol=5e-6, rtol=2e-3)
+    torch.testing.assert_close(g.double(), g64, atol=5e-6, rtol=1e-3)
+
+
+def test_bptt_philox_noise_path(dev):
+    from oracle import philox
+    X, U, H, n = 3, 1, 6, 16
+    cfg, ap, cp, x0, _, s_mean, s_std, r_ms, tsys, extra = _setup(X, U, H, n, "pendulum", 0, 1)
+    seed, offset = 4242, 7
+    noise = torch.from_numpy(philox.philox_normal(seed, offset, philox.STREAM_POLICY_NOISE, np.arange(n * H * U, dtype=np.uint64))).reshape(n, H, U)
+    a = _run_hip(dev, cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, "pendulum", extra, n, explicit_noise=True)
+    b = _run_hip(dev, cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, "pendulum", extra, n, explicit_noise=False, seed=seed, offset=offset)
+    torch.testing.assert_close(a.grads, b.grads, atol=1e-6, rtol=1e-4)
+
+
+def test_bptt_many_tiles_accumulate(dev):
+    """n = 16 * 300 trajectories > number of workgroups: workgroups walk several tiles and accumulate into their slab;
+    linearity check: the gradient of the mean over 2 copies of a batch equals the gradient of one copy."""
+    X, U, H, n = 3, 1, 4, 16
+    cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, tsys, extra = _setup(X, U, H, n, "pendulum", 0, 2)
+    one = _run_hip(dev, cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, "pendulum", extra, n)
+    reps = 300
+    many = _run_hip(dev, cfg, ap, cp, x0.repeat(reps, 1), noise.repeat(reps, 1, 1), s_mean, s_std, r_ms, "pendulum", extra, n * reps)
+    torch.testing.assert_close(many.grads, one.grads, atol=2e-6, rtol=2e-4)
+    torch.testing.assert_close(many.metrics, one.metrics, atol=1e-5, rtol=1e-4)
