@@ -101,6 +101,7 @@ typedef struct mbpo_rollout_desc {
   int32_t deterministic;     /* 1: action = tanh(loc) (mode) */
   int32_t ppo_extras;        /* 1: rows carry log_prob and raw_action (ppo_network.py:72-80) */
   int32_t env_major;         /* 0: row = s*N + i (SAC concat order, sac.py:296); 1: row = i*S + s (PPO [B*M,T]) */
+  float action_clip;         /* > 0: action = clip(tanh(z), +-action_clip) — BPTT's squash_action (bptt_optimizer.py:313-317) */
   const float *actions;        /* optional [S, N, u_dim] open-loop actions: the policy is skipped (`policy` may be zeroed) —
                                   rollout_actions (utils/optimizer_utils.py:11-59) and, with S=1, System.step itself */
   /* randomness: explicit tensors when non-NULL, else counter-based Philox4x32-10 keyed by (seed, offset) */
@@ -148,12 +149,14 @@ int mbpo_replay_sample(const float *data, int64_t max_size, int32_t row_len, con
  *   pass 0: sums[0] = n, sums[1..x] = sum(d),  d = obs - mean_old  over rows[:, col_off : col_off+x_dim]
  *   pass 1: sums[1+x..1+2x) = sum(d * (d - upd)),  upd = sums[1..x] / (count + sums[0])
  *   apply : count += n; mean += sum_d/count; summed_variance += pass-1 sums;
- *           std = clip(sqrt(max(summed_variance,0)/count), 1e-6, 1e6)
+ *           std = clip(sqrt(max(summed_variance,0)/count), std_min, std_max)   (brax: 1e-6, 1e6)
+ * The same update IS BPTT's Normalizer.update (bptt_optimizer.py:52-67) with summed_variance = std^2 * size:
+ *   sum (x - new_mean)^2 + size*(mean - new_mean)^2 == sum d*(d - upd); its floor is std_min = 1e-8, no ceiling.
  * stats (device, fp32) = [count, mean[x], summed_variance[x], std[x]];  workspace >= 64*x_dim floats.
  */
 int mbpo_running_stats_reduce(const float *rows, int64_t n_rows, int32_t row_len, int32_t col_off, int32_t x_dim,
                               const float *stats, float *sums, float *workspace, int32_t pass, void *stream);
-int mbpo_running_stats_apply(float *stats, const float *sums, int32_t x_dim, void *stream);
+int mbpo_running_stats_apply(float *stats, const float *sums, int32_t x_dim, float std_min, float std_max, void *stream);
 
 /* ---- P4: GAE (ppo/losses.py:128-184) and B2: lambda-return (utils/optimizer_utils.py:119-152) -------
  * Reverse first-order linear recurrences evaluated as wavefront-shuffle segmented scans.
@@ -295,6 +298,29 @@ typedef struct mbpo_bptt_desc {
 
 int64_t mbpo_bptt_workspace_floats(const mbpo_bptt_desc *d);
 int mbpo_bptt_actor_grads(const mbpo_bptt_desc *d, void *stream);
+
+/* ---- B4: twin-V critic regression (bptt_optimizer.py:385-419) ----------------------------------------
+ * replaces: value_and_grad(critic_loss_fn) of update_critic: loss = 0.5*(mean l2(v1, lamb) + mean l2(v2, lamb)), l2 = 0.5(.)^2,
+ *           on a minibatch gathered (with replacement) from the flattened simulated transitions:
+ *           obs_j = transitions[idx[j], 0:x_dim] (normalised with the state normaliser), target_j = lambda_values[idx[j]].
+ * grads [2*C] in the [critic_1 | critic_2] layout; metrics[0] = critic loss.  workspace >= mbpo_critic_workspace_floats().
+ */
+int64_t mbpo_critic_workspace_floats(int32_t x_dim, int32_t critic_layers, const int32_t *critic_dims, int64_t batch);
+int mbpo_critic_grads(const float *critic_params, int32_t x_dim, int32_t critic_layers, const int32_t *critic_dims,
+                      int32_t activation, const float *transitions, int32_t row_len, const float *lambda_values,
+                      const int32_t *idx, int64_t batch, const float *state_mean, const float *state_std, float *grads,
+                      float *metrics, float *workspace, void *stream);
+
+/* ---- generic optimizer step: [optax.apply_if_finite(] optax.adamw(lr, wd) [)] + optional Polyak target ----------------
+ * replaces: actor_optimizer.update/apply_updates (bptt_optimizer.py:218-225, 374-378), critic_optimizer + soft_update
+ *           (:406-410; utils/optimizer_utils.py:155-161).
+ * grads *= grad_scale; if apply_if_finite and any gradient is non-finite the whole update (params, moments, count) is
+ * skipped; count (device scalar) advances by one otherwise; grad_norm_out (optional) = optax.global_norm(grads);
+ * target (optional) <- (1 - tau) * target + tau * new_params.   workspace >= 2 * ceil(n / 256) + 4 floats.
+ */
+int mbpo_adamw_step(float *params, const float *grads, float *adam_m, float *adam_v, float *step_count, int64_t n, float lr,
+                    float wd, float grad_scale, int32_t apply_if_finite, float *target, float tau, float *grad_norm_out,
+                    float *workspace, void *stream);
 
 #ifdef __cplusplus
 }

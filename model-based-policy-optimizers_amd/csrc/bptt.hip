@@ -691,3 +691,158 @@ extern "C" int mbpo_bptt_actor_grads(const mbpo_bptt_desc *d, void *stream) {
   MBPO_CHECK_LAUNCH("bptt_actor_grads");
   return MBPO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// B4: twin-V critic regression on gathered transitions (bptt_optimizer.py:385-419)
+// ------------------------------------------------------------------------------------------------
+struct CriticArgs {
+  MlpDev cr;
+  int X, D;
+  const float *transitions, *lambda_values, *s_mean, *s_std;
+  const int *idx;
+  long long batch;
+  float *slabs, *extras;
+  int ld_x, ld_h, LH;
+};
+
+// 8 waves: forward = critic_1 | critic_2 (2 waves each, z and h kept); backward = 2 dgrad chains + 2 wgrad chains.
+template <int H>
+__global__ void __launch_bounds__(512) k_critic_fwd_bwd(CriticArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int HT = H / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int chain = wave >> 1, sub = wave & 1;
+  const int X = A.X, ld_x = A.ld_x, ld_h = A.ld_h, LH = A.LH;
+  const int T = 16 * ld_h;
+  float *s_x = smem;                    // [16][ld_x] normalised obs
+  float *s_yv = s_x + 16 * ld_x;        // [2][16][4]
+  float *s_dyv = s_yv + 128;            // [2][16][4]
+  float *s_tg = s_dyv + 128;            // [16] targets
+  float *s_ls = s_tg + 16;              // [32] loss partials
+  float *s_st = s_ls + 32;              // 4*LH tiles: z1 h1 z2 h2
+  float *s_pp = s_st + 4 * LH * T;      // 4 delta tiles
+  float *z1 = s_st, *h1 = s_st + LH * T, *z2 = s_st + 2 * LH * T, *h2 = s_st + 3 * LH * T;
+  const float *p1 = A.cr.params, *p2 = A.cr.params + A.cr.net_stride;
+  const int CL = A.cr.n_layers;
+  const float invB = 1.0f / (float)A.batch;
+  float *slab = A.slabs + (long long)blockIdx.x * 2 * A.cr.n_params;
+  float loss = 0.f;
+  bool first = true;
+  const long long n_tiles = (A.batch + 15) >> 4;
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, first = false) {
+    const long long j0 = tile * 16;
+    for (int idx = tid; idx < 16 * X; idx += nthreads) {
+      const int r = idx / X, c = idx - r * X;
+      const long long j = j0 + r;
+      float o = 0.f;
+      if (j < A.batch) o = (A.transitions[(long long)A.idx[j] * A.D + c] - A.s_mean[c]) / A.s_std[c];   // traj.observation normalised (:399)
+      s_x[r * ld_x + c] = o;
+    }
+    if (tid < 16) s_tg[tid] = (j0 + tid < A.batch) ? A.lambda_values[A.idx[j0 + tid]] : 0.f;
+    __syncthreads();
+    {
+      FwdChain fc;
+      if (chain == 0) fc = FwdChain{&A.cr, p1, s_x, ld_x, nullptr, nullptr, z1, h1, s_yv};
+      else fc = FwdChain{&A.cr, p2, s_x, ld_x, nullptr, nullptr, z2, h2, s_yv + 64};
+      for (int l = 0; l < CL; ++l) {
+        if (chain < 2) group_fwd_step<HT, 2>(fc, l, ld_h, 4, sub, lane);
+        __syncthreads();
+      }
+    }
+    if (tid < 32) {
+      const int k = tid >> 4, r = tid & 15;
+      const bool ok = j0 + r < A.batch;
+      const float e = ok ? s_yv[(k * 16 + r) * 4] - s_tg[r] : 0.f;
+      s_ls[tid] = 0.5f * e * e;                         // optax.l2_loss
+      s_dyv[(k * 16 + r) * 4] = 0.5f * e * invB;        // d [0.5 * mean_j l2] / dv
+    }
+    __syncthreads();
+    if (tid == 0)
+      for (int i = 0; i < 32; ++i) loss += s_ls[i];
+    {
+      const int net = chain & 1;
+      const float *pp = net ? p2 : p1;
+      const float *zb = net ? z2 : z1, *hb = net ? h2 : h1;
+      float *d0 = s_pp + (2 * net) * T, *d1 = d0 + T;
+      const float *dcur = s_dyv + net * 64;
+      int ldc = 4;
+      for (int l = CL - 1; l >= 0; --l) {
+        float *dn = (l & 1) ? d1 : d0;
+        if (chain < 2) group_bwd_dgrad_layer<HT, 2>(A.cr, pp, l, dcur, ldc, zb, ld_h, dn, nullptr, ld_x, sub, lane);
+        else group_bwd_wgrad_layer<HT, 2>(A.cr, l, s_x, ld_x, hb, ld_h, dcur, ldc, slab + (long long)net * A.cr.n_params, sub, lane, !first);
+        __syncthreads();
+        dcur = dn;
+        ldc = ld_h;
+      }
+    }
+  }
+  if (tid == 0) A.extras[blockIdx.x] = loss;
+}
+
+__global__ void __launch_bounds__(256) k_critic_reduce(const float *slabs, const float *extras, int n_slabs, int C2, long long batch,
+                                                        float *grads, float *metrics) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < C2) {
+    float g = 0.f;
+    for (int s = 0; s < n_slabs; ++s) g += slabs[(long long)s * C2 + i];
+    grads[i] = g;
+  }
+  if (i == 0) {
+    float a = 0.f;
+    for (int s = 0; s < n_slabs; ++s) a += extras[s];
+    metrics[0] = 0.5f * a / (float)batch;     // 0.5 * (mean l2(v1) + mean l2(v2))
+  }
+}
+
+static int critic_plan(int x_dim, int critic_layers, const int *critic_dims, long long batch, MlpDev *cr, int *n_slabs, size_t *lds,
+                       int *ld_x, int *ld_h, int *LH, long long *total) {
+  MBPO_REQUIRE(x_dim > 0 && batch > 0 && critic_dims, MBPO_ERR_ARG, "critic: bad sizes");
+  MBPO_REQUIRE(critic_layers >= 2 && critic_layers <= MBPO_MAX_LAYERS, MBPO_ERR_ARG, "critic: need at least one hidden layer");
+  MBPO_REQUIRE(critic_dims[0] == x_dim && critic_dims[critic_layers] == 1, MBPO_ERR_ARG, "critic must map [x] -> [1]");
+  MBPO_REQUIRE(bptt_hidden(critic_dims, critic_layers) == 64, MBPO_ERR_UNSUPPORTED, "critic: hidden layers must all be 64 wide");
+  mbpo_mlp_desc md;
+  md.net_stride = 0; md.n_nets = 1; md.params = (const float *)16; md.n_layers = critic_layers; md.activation = 0;
+  for (int l = 0; l <= critic_layers; ++l) md.dims[l] = critic_dims[l];
+  int rc = mbpo_make_mlp_dev(&md, cr, "critic");
+  if (rc != MBPO_OK) return rc;
+  *LH = critic_layers - 1;
+  *ld_x = ((x_dim + 3) & ~3) + 4;
+  *ld_h = 68;
+  *lds = sizeof(float) * (16ull * *ld_x + 128 + 128 + 16 + 32 + (size_t)(4 * *LH + 4) * 16 * *ld_h);
+  long long tiles = (batch + 15) / 16, cap = 2LL * bptt_num_cus();
+  *n_slabs = (int)(tiles < cap ? tiles : cap);
+  *total = (long long)*n_slabs * 2 * cr->n_params + ((*n_slabs + 3) & ~3);
+  return MBPO_OK;
+}
+
+extern "C" int64_t mbpo_critic_workspace_floats(int32_t x_dim, int32_t critic_layers, const int32_t *critic_dims, int64_t batch) {
+  MlpDev cr; int ns, ldx, ldh, lh; size_t lds; long long total;
+  int rc = critic_plan(x_dim, critic_layers, critic_dims, batch, &cr, &ns, &lds, &ldx, &ldh, &lh, &total);
+  if (rc != MBPO_OK) return rc;
+  return total;
+}
+
+extern "C" int mbpo_critic_grads(const float *critic_params, int32_t x_dim, int32_t critic_layers, const int32_t *critic_dims,
+                                 int32_t activation, const float *transitions, int32_t row_len, const float *lambda_values,
+                                 const int32_t *idx, int64_t batch, const float *state_mean, const float *state_std, float *grads,
+                                 float *metrics, float *workspace, void *stream) {
+  CriticArgs A;
+  int ns; size_t lds; long long total;
+  int rc = critic_plan(x_dim, critic_layers, critic_dims, batch, &A.cr, &ns, &lds, &A.ld_x, &A.ld_h, &A.LH, &total);
+  if (rc != MBPO_OK) return rc;
+  MBPO_REQUIRE(critic_params && transitions && lambda_values && idx && state_mean && state_std && grads && metrics && workspace,
+               MBPO_ERR_ARG, "critic_grads: null pointer");
+  MBPO_REQUIRE(activation >= 0 && activation <= 2 && row_len >= x_dim, MBPO_ERR_ARG, "critic_grads: bad activation/row_len");
+  A.cr.params = critic_params; A.cr.act = activation; A.cr.n_nets = 2; A.cr.net_stride = A.cr.n_params;
+  A.X = x_dim; A.D = row_len; A.transitions = transitions; A.lambda_values = lambda_values; A.s_mean = state_mean; A.s_std = state_std;
+  A.idx = idx; A.batch = batch; A.slabs = workspace; A.extras = workspace + (long long)ns * 2 * A.cr.n_params;
+  rc = mbpo_ensure_lds<k_critic_fwd_bwd<64>>(lds, "critic_grads");
+  if (rc != MBPO_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_critic_fwd_bwd<64>, dim3(ns), dim3(512), lds, st, A);
+  const int C2 = 2 * A.cr.n_params;
+  hipLaunchKernelGGL(k_critic_reduce, dim3((C2 + 255) / 256), dim3(256), 0, st, (const float *)A.slabs, (const float *)A.extras, ns, C2,
+                     (long long)batch, grads, metrics);
+  MBPO_CHECK_LAUNCH("critic_grads");
+  return MBPO_OK;
+}

@@ -1,0 +1,99 @@
+// optim.hip — generic optimizer step: [optax.apply_if_finite(] optax.adamw [)] + optional Polyak target (see mbpo_hip.h).
+// HBM-bound elementwise work: 28 B per parameter (36 B with a target).  Three tiny launches:
+//   k_grad_stats   per-block sum g^2 and count of non-finite gradients (fixed order, deterministic)
+//   k_adamw_step   every block re-reduces the partials (wave shuffle), decides skip/apply, updates its 256 parameters
+//   k_adamw_bump   count += 1 unless the update was skipped (a separate launch: every block of k_adamw_step reads count)
+#include "common.hpp"
+
+__device__ __forceinline__ float opt_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) k_grad_stats(const float *grads, long long n, float scale, float *part) {
+  __shared__ float s_a[4], s_b[4];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  float g = i < n ? grads[i] * scale : 0.f;
+  const bool fin = isfinite(g);
+  float ss = opt_wave_sum(fin ? g * g : 0.f), nf = opt_wave_sum(fin ? 0.f : 1.f);
+  if ((threadIdx.x & 63) == 0) {
+    s_a[threadIdx.x >> 6] = ss;
+    s_b[threadIdx.x >> 6] = nf;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x + 0] = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+    part[2 * blockIdx.x + 1] = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+  }
+}
+
+struct AdamwArgs {
+  float *params, *m, *v, *target, *grad_norm_out;
+  const float *grads, *count, *part;
+  long long n;
+  int n_parts, apply_if_finite;
+  float lr, wd, scale, tau, one_minus_tau;
+};
+
+__device__ __forceinline__ void reduce_parts(const float *part, int n_parts, float *ss_out, float *nf_out) {
+  __shared__ float s_r[2];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (w < 2) {
+    float a = 0.f;
+    for (int p = lane; p < n_parts; p += 64) a += part[2 * p + w];
+    a = opt_wave_sum(a);
+    if (lane == 0) s_r[w] = a;
+  }
+  __syncthreads();
+  *ss_out = s_r[0];
+  *nf_out = s_r[1];
+}
+
+__global__ void __launch_bounds__(256) k_adamw_step(AdamwArgs A) {
+  float ss, nf;
+  reduce_parts(A.part, A.n_parts, &ss, &nf);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && A.grad_norm_out) A.grad_norm_out[0] = nf > 0.f ? NAN : sqrtf(ss);   // optax.global_norm
+  if (A.apply_if_finite && nf > 0.f) return;   // [3P optax.apply_if_finite] skip params, moments and count
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.n) return;
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+  const float count = A.count[0] + 1.0f;
+  const float g = A.grads[i] * A.scale;
+  const float mu = b1 * A.m[i] + 0.1f * g;                 // optax forms (1 - b) in double: f32(0.1), f32(0.001)
+  const float nu = b2 * A.v[i] + 0.001f * (g * g);
+  A.m[i] = mu;
+  A.v[i] = nu;
+  const float mu_hat = mu / (1.f - powf(b1, count));
+  const float nu_hat = nu / (1.f - powf(b2, count));
+  const float p = A.params[i];
+  const float pn = p + (-A.lr) * (mu_hat / (sqrtf(nu_hat) + eps) + A.wd * p);
+  A.params[i] = pn;
+  if (A.target) A.target[i] = A.one_minus_tau * A.target[i] + A.tau * pn;   // soft_update (optimizer_utils.py:155-161)
+}
+
+__global__ void k_adamw_bump(float *count, const float *part, int n_parts, int apply_if_finite) {
+  if (threadIdx.x == 0) {
+    float nf = 0.f;
+    for (int p = 0; p < n_parts; ++p) nf += part[2 * p + 1];
+    if (!(apply_if_finite && nf > 0.f)) count[0] = count[0] + 1.0f;
+  }
+}
+
+extern "C" int mbpo_adamw_step(float *params, const float *grads, float *adam_m, float *adam_v, float *step_count, int64_t n,
+                               float lr, float wd, float grad_scale, int32_t apply_if_finite, float *target, float tau,
+                               float *grad_norm_out, float *workspace, void *stream) {
+  MBPO_REQUIRE(params && grads && adam_m && adam_v && step_count && workspace, MBPO_ERR_ARG, "adamw_step: null pointer");
+  MBPO_REQUIRE(n > 0 && n < (1LL << 31), MBPO_ERR_ARG, "adamw_step: bad n");
+  const int blocks = (int)((n + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_grad_stats, dim3(blocks), dim3(256), 0, st, grads, (long long)n, grad_scale, workspace);
+  AdamwArgs A;
+  A.params = params; A.m = adam_m; A.v = adam_v; A.target = target; A.grad_norm_out = grad_norm_out;
+  A.grads = grads; A.count = step_count; A.part = workspace; A.n = n; A.n_parts = blocks; A.apply_if_finite = apply_if_finite;
+  A.lr = lr; A.wd = wd; A.scale = grad_scale; A.tau = tau; A.one_minus_tau = (float)(1.0 - (double)tau);
+  hipLaunchKernelGGL(k_adamw_step, dim3(blocks), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_adamw_bump, dim3(1), dim3(64), 0, st, step_count, (const float *)workspace, blocks, apply_if_finite);
+  MBPO_CHECK_LAUNCH("adamw_step");
+  return MBPO_OK;
+}

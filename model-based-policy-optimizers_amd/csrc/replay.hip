@@ -202,7 +202,7 @@ extern "C" int mbpo_running_stats_reduce(const float *rows, int64_t n_rows, int3
   return MBPO_OK;
 }
 
-__global__ void k_stats_apply(float *stats, const float *sums, int X) {
+__global__ void k_stats_apply(float *stats, const float *sums, int X, float std_min, float std_max) {
   const int c = threadIdx.x;
   // [3P] running_statistics.update: count = state.count + step_increment; mean += sum(diff_to_old_mean)/count;
   // summed_variance += sum(diff_to_old * diff_to_new); std = clip(sqrt(max(sv,0)/count), 1e-6, 1e6)
@@ -213,16 +213,16 @@ __global__ void k_stats_apply(float *stats, const float *sums, int X) {
     float nsv = sv[c] + sums[1 + X + c];
     sv[c] = nsv;
     float s = sqrtf(fmaxf(nsv, 0.f) / count);
-    sd[c] = fminf(fmaxf(s, 1e-6f), 1e6f);
+    sd[c] = fminf(fmaxf(s, std_min), std_max);
   }
   __syncthreads();
   if (c == 0) stats[0] = count;
 }
 
-extern "C" int mbpo_running_stats_apply(float *stats, const float *sums, int32_t x_dim, void *stream) {
+extern "C" int mbpo_running_stats_apply(float *stats, const float *sums, int32_t x_dim, float std_min, float std_max, void *stream) {
   MBPO_REQUIRE(stats && sums, MBPO_ERR_ARG, "running_stats_apply: null pointer");
   MBPO_REQUIRE(x_dim > 0 && x_dim <= 128, MBPO_ERR_ARG, "running_stats_apply: x_dim out of range");
-  hipLaunchKernelGGL(k_stats_apply, dim3(1), dim3(128), 0, (hipStream_t)stream, stats, sums, x_dim);
+  hipLaunchKernelGGL(k_stats_apply, dim3(1), dim3(128), 0, (hipStream_t)stream, stats, sums, x_dim, std_min, std_max);
   MBPO_CHECK_LAUNCH("running_stats_apply");
   return MBPO_OK;
 }

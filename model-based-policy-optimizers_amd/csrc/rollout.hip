@@ -147,6 +147,7 @@ struct RolloutArgs {
   int reward_kind;
   const float *reward_params, *sys_params, *norm_mean, *norm_std;
   int deterministic, ppo_extras, env_major;
+  float action_clip;
   const float *actions;
   const float *policy_noise, *model_noise;
   const int *member_idx;
@@ -278,6 +279,7 @@ __global__ void __launch_bounds__(512) k_model_rollout(RolloutArgs A) {
         }
         float z = loc + sigma * eps;
         float a = tanhf(z);
+        if (A.action_clip > 0.f) a = fminf(fmaxf(a, -A.action_clip), A.action_clip);
         s_xu[r * A.ld_xu + X + d] = a;
         s_row[r * D + X + d] = a;
         if (A.ppo_extras) {
@@ -501,6 +503,7 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   A.norm_mean = d->norm_mean; A.norm_std = d->norm_std;
   A.deterministic = d->deterministic; A.ppo_extras = d->ppo_extras; A.env_major = d->env_major;
   A.actions = d->actions;
+  A.action_clip = d->action_clip;
   if (!has_policy) memset(&A.policy, 0, sizeof(A.policy));
   A.policy_noise = d->policy_noise; A.model_noise = d->model_noise; A.member_idx = d->member_idx;
   A.seed = d->seed; A.offset = d->offset; A.offset_dev = d->offset_dev;

@@ -60,6 +60,7 @@ class RolloutDesc(C.Structure):
         ("deterministic", C.c_int32),
         ("ppo_extras", C.c_int32),
         ("env_major", C.c_int32),
+        ("action_clip", C.c_float),
         ("actions", C.c_void_p),
         ("policy_noise", C.c_void_p),
         ("model_noise", C.c_void_p),
@@ -171,9 +172,11 @@ def _bind_optional(lib: C.CDLL) -> None:
         "mbpo_replay_gather": [vp, i64, i32, vp, vp, i64, vp, vp],
         "mbpo_replay_sample": [vp, i64, i32, vp, u64, u64, vp, i64, vp, vp, vp],
         "mbpo_running_stats_reduce": [vp, i64, i32, i32, i32, vp, vp, vp, i32, vp],
-        "mbpo_running_stats_apply": [vp, vp, i32, vp],
+        "mbpo_running_stats_apply": [vp, vp, i32, f32, f32, vp],
         "mbpo_gae_scan": [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp],
         "mbpo_lambda_return_scan": [vp, vp, vp, i64, i32, f32, f32, i32, vp],
+        "mbpo_critic_grads": [vp, i32, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp],
+        "mbpo_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, i32, vp, f32, vp, vp, vp],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name, None)
@@ -194,6 +197,10 @@ def _bind_optional(lib: C.CDLL) -> None:
     if fn is not None:
         fn.restype = C.c_int64
         fn.argtypes = [C.POINTER(PpoDesc)]
+    fn = getattr(lib, "mbpo_critic_workspace_floats", None)
+    if fn is not None:
+        fn.restype = C.c_int64
+        fn.argtypes = [i32, i32, vp, i64]
     fn = getattr(lib, "mbpo_bptt_actor_grads", None)
     if fn is not None:
         fn.restype = C.c_int

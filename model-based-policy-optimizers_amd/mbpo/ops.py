@@ -70,7 +70,7 @@ def model_rollout(*, policy_params: Optional[torch.Tensor] = None, policy_spec: 
                   reward_kind: int = _hip.REWARD_PENDULUM, reward_params: torch.Tensor = None,
                   sys_params: Optional[torch.Tensor] = None,
                   norm_mean: Optional[torch.Tensor] = None, norm_std: Optional[torch.Tensor] = None,
-                  deterministic: bool = False, ppo_extras: bool = False, env_major: bool = False,
+                  deterministic: bool = False, ppo_extras: bool = False, env_major: bool = False, action_clip: float = 0.0,
                   policy_noise: Optional[torch.Tensor] = None, model_noise: Optional[torch.Tensor] = None,
                   member_idx: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0,
                   offset_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -114,6 +114,7 @@ def model_rollout(*, policy_params: Optional[torch.Tensor] = None, policy_spec: 
     d.norm_mean = ptr(_req(norm_mean, "norm_mean")) if norm_mean is not None else None
     d.norm_std = ptr(_req(norm_std, "norm_std")) if norm_std is not None else None
     d.deterministic, d.ppo_extras, d.env_major = int(deterministic), int(ppo_extras), int(env_major)
+    d.action_clip = action_clip
     if policy_noise is not None:
         _req(policy_noise, "policy_noise")
         if policy_noise.numel() != n_steps * n_envs * u_dim:
@@ -157,13 +158,19 @@ def replay_gather(data: torch.Tensor, state: torch.Tensor, idx: torch.Tensor) ->
 
 
 def replay_sample(data: torch.Tensor, state: torch.Tensor, n: int, seed: int, offset: int, return_idx: bool = False,
-                  out: Optional[torch.Tensor] = None, offset_dev: Optional[torch.Tensor] = None):
+                  out: Optional[torch.Tensor] = None, offset_dev: Optional[torch.Tensor] = None,
+                  idx_out: Optional[torch.Tensor] = None):
     """UniformSamplingQueue.sample: Philox randint in [sample_position, insert_position) + gather, one launch."""
     lib = load()
     _req(data, "data"); _req(state, "state", torch.int32)
     if out is None:
         out = torch.empty((n, data.shape[1]), device=data.device, dtype=torch.float32)
     idx = torch.empty((n,), device=data.device, dtype=torch.int32) if return_idx else None
+    if idx_out is not None:
+        _req(idx_out, "idx_out", torch.int32)
+        if idx_out.numel() != n:
+            raise ValueError(f"idx_out must have {n} entries")
+        idx = idx_out
     check(lib.mbpo_replay_sample(data.data_ptr(), data.shape[0], data.shape[1], state.data_ptr(), seed, offset,
                                  ptr(offset_dev), n, ptr(idx), out.data_ptr(), current_stream_ptr()), "mbpo_replay_sample")
     return (out, idx) if return_idx else out
@@ -189,7 +196,8 @@ def running_stats_reduce(rows: torch.Tensor, col_off: int, x_dim: int, stats: to
 
 
 def running_stats_update(rows: torch.Tensor, col_off: int, x_dim: int, stats: torch.Tensor, all_reduce=None,
-                         sums: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> None:
+                         sums: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+                         std_min: float = 1e-6, std_max: float = 1e6) -> None:
     """running_statistics.update(state, rows[:, col_off:col_off+x_dim]); `all_reduce(t)` sums `t` over ranks in place
     (the reference's psum under pmap_axis_name, sac/sac.py:298-301)."""
     sums = running_stats_reduce(rows, col_off, x_dim, stats, 0, sums=sums, workspace=workspace)
@@ -198,13 +206,13 @@ def running_stats_update(rows: torch.Tensor, col_off: int, x_dim: int, stats: to
     running_stats_reduce(rows, col_off, x_dim, stats, 1, sums=sums, workspace=workspace)
     if all_reduce is not None:
         all_reduce(sums[1 + x_dim:])
-    running_stats_apply(stats, sums, x_dim)
+    running_stats_apply(stats, sums, x_dim, std_min, std_max)
 
 
-def running_stats_apply(stats: torch.Tensor, sums: torch.Tensor, x_dim: int) -> None:
+def running_stats_apply(stats: torch.Tensor, sums: torch.Tensor, x_dim: int, std_min: float = 1e-6, std_max: float = 1e6) -> None:
     lib = load()
     _req(stats, "stats"); _req(sums, "sums")
-    check(lib.mbpo_running_stats_apply(stats.data_ptr(), sums.data_ptr(), x_dim, current_stream_ptr()),
+    check(lib.mbpo_running_stats_apply(stats.data_ptr(), sums.data_ptr(), x_dim, std_min, std_max, current_stream_ptr()),
           "mbpo_running_stats_apply")
 
 
@@ -478,3 +486,75 @@ class BpttActorGrad:
         d.workspace = self.workspace.data_ptr()
         check(self.lib.mbpo_bptt_actor_grads(C.byref(d), current_stream_ptr()), "mbpo_bptt_actor_grads")
         return self.grads
+
+
+class CriticGrad:
+    """Drives mbpo_critic_grads: twin-V regression loss and gradient on a gathered minibatch (bptt_optimizer.py:385-404)."""
+
+    def __init__(self, *, x_dim: int, critic_dims: Sequence[int], batch: int, device, activation: str = "swish"):
+        self.lib = load()
+        self.x_dim, self.batch, self.device = x_dim, int(batch), torch.device(device)
+        self.spec = MlpSpec(list(critic_dims), activation, 2)
+        self.C = self.spec.n_params
+        self.dims = (C.c_int32 * (len(critic_dims)))(*[int(v) for v in critic_dims])
+        self.layers = len(critic_dims) - 1
+        self.act = _hip.ACT_IDS[activation]
+        nws = self.lib.mbpo_critic_workspace_floats(x_dim, self.layers, self.dims, self.batch)
+        if nws < 0:
+            check(int(nws), "mbpo_critic_workspace_floats")
+        self.workspace = torch.zeros(int(nws), device=self.device, dtype=torch.float32)
+        self.grads = torch.zeros(2 * self.C, device=self.device, dtype=torch.float32)
+        self.metrics = torch.zeros(1, device=self.device, dtype=torch.float32)
+
+    def __call__(self, critic_params, transitions, lambda_values, idx, state_mean, state_std) -> torch.Tensor:
+        for t, nm in ((critic_params, "critic_params"), (transitions, "transitions"), (lambda_values, "lambda_values"),
+                      (state_mean, "state_mean"), (state_std, "state_std")):
+            _req(t, nm)
+        _req(idx, "idx", torch.int32)
+        if critic_params.numel() != 2 * self.C:
+            raise ValueError("critic_params must be [2*C]")
+        if idx.numel() != self.batch:
+            raise ValueError(f"idx must have {self.batch} entries")
+        if transitions.dim() != 2 or lambda_values.numel() != transitions.shape[0]:
+            raise ValueError("transitions must be [R, D] with lambda_values [R]")
+        check(self.lib.mbpo_critic_grads(critic_params.data_ptr(), self.x_dim, self.layers, self.dims, self.act,
+                                         transitions.data_ptr(), transitions.shape[1], lambda_values.data_ptr(), idx.data_ptr(),
+                                         self.batch, state_mean.data_ptr(), state_std.data_ptr(), self.grads.data_ptr(),
+                                         self.metrics.data_ptr(), self.workspace.data_ptr(), current_stream_ptr()),
+              "mbpo_critic_grads")
+        return self.grads
+
+
+class AdamW:
+    """optax.adamw (optionally under optax.apply_if_finite) on a flat parameter vector, with an optional Polyak target.
+    State (moments, count) lives on the device: graph-replayable."""
+
+    def __init__(self, n: int, device, lr: float, weight_decay: float, apply_if_finite: bool = False):
+        self.lib = load()
+        self.n, self.lr, self.wd, self.apply_if_finite = int(n), float(lr), float(weight_decay), bool(apply_if_finite)
+        dev = torch.device(device)
+        self.m = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.count = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.workspace = torch.zeros(2 * ((n + 255) // 256) + 4, device=dev, dtype=torch.float32)
+
+    def state_tensors(self):
+        return self.m, self.v, self.count
+
+    def load_state(self, m, v, count):
+        self.m.copy_(m); self.v.copy_(v); self.count.copy_(torch.as_tensor(count, dtype=torch.float32).reshape(1))
+
+    def step(self, params: torch.Tensor, grads: torch.Tensor, target: Optional[torch.Tensor] = None, tau: float = 0.0,
+             grad_scale: float = 1.0) -> None:
+        _req(params, "params"); _req(grads, "grads")
+        if params.numel() != self.n or grads.numel() != self.n:
+            raise ValueError("params/grads must have n elements")
+        if target is not None:
+            _req(target, "target")
+            if target.numel() != self.n:
+                raise ValueError("target must have n elements")
+        check(self.lib.mbpo_adamw_step(params.data_ptr(), grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                       self.count.data_ptr(), self.n, self.lr, self.wd, grad_scale, int(self.apply_if_finite),
+                                       ptr(target), tau, self.grad_norm.data_ptr(), self.workspace.data_ptr(),
+                                       current_stream_ptr()), "mbpo_adamw_step")

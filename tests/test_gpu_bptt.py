@@ -115,3 +115,120 @@ def test_bptt_many_tiles_accumulate(dev):
     many = _run_hip(dev, cfg, ap, cp, x0.repeat(reps, 1), noise.repeat(reps, 1, 1), s_mean, s_std, r_ms, "pendulum", extra, n * reps)
     torch.testing.assert_close(many.grads, one.grads, atol=2e-6, rtol=2e-4)
     torch.testing.assert_close(many.metrics, one.metrics, atol=1e-5, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ B4: critic regression
+@pytest.mark.parametrize("X,R,batch,hidden,seed", [
+    (3, 1000, 1000, (64, 64, 64), 0),     # the reference test's shape: n=50 x H=20 transitions, one critic update
+    (3, 200, 67, (64, 64, 64), 1),        # ragged batch (ceil(200/3)), sampling with replacement
+    (11, 320, 160, (64, 64), 2),          # wider observation, two hidden layers
+    (5, 40, 7, (64,), 3),                 # less than one tile, one hidden layer
+    (3, 16 * 700, 16 * 700, (64, 64, 64), 4),   # more tiles than workgroups: slabs accumulate
+])
+def test_critic_grads_parity(dev, X, R, batch, hidden, seed):
+    """Loss and gradient vs torch autograd (oracle/bptt.py:critic_grads).  Tolerance: atol 2e-6 + rtol 5e-4 (fp32 sums over the
+    batch in a different association order)."""
+    from mbpo import ops
+    g = torch.Generator().manual_seed(seed)
+    cfg = obptt.BpttConfig(x_dim=X, u_dim=1, actor_dims=[X, 64, 2], critic_dims=[X, *hidden, 1])
+    cp = torch.cat([onets.init_mlp_flat(cfg.critic_dims, g) + 0.02 * torch.randn(cfg.C, generator=g) for _ in range(2)])
+    D = 2 * X + 1 + 2
+    rows = torch.randn(R, D, generator=g)
+    lam = torch.randn(R, generator=g) * 3
+    idx = torch.randint(0, R, (batch,), generator=g, dtype=torch.int32)
+    s_mean, s_std = torch.randn(X, generator=g) * 0.2, torch.rand(X, generator=g) + 0.6
+    ref_g, ref_l = obptt.critic_grads(cfg, cp, rows[idx.long(), :X], lam[idx.long()], s_mean, s_std)
+    op = ops.CriticGrad(x_dim=X, critic_dims=cfg.critic_dims, batch=batch, device=dev)
+    got = op(cp.to(dev), rows.to(dev), lam.to(dev), idx.to(dev), s_mean.to(dev), s_std.to(dev))
+    torch.cuda.synchronize()
+    assert abs(float(op.metrics[0]) - ref_l) <= 1e-5 + 2e-5 * abs(ref_l)
+    torch.testing.assert_close(got.cpu(), ref_g, atol=2e-6, rtol=5e-4)
+    # fp64 oracle: bounds the error of the fp32 oracle itself
+    g64, _ = obptt.critic_grads(cfg, cp.double(), rows[idx.long(), :X].double(), lam[idx.long()].double(), s_mean.double(), s_std.double())
+    rel = float((got.cpu().double() - g64).norm() / g64.norm())
+    assert rel < 2e-5, rel
+
+
+def test_critic_grads_rejects_bad_shapes(dev):
+    from mbpo import _hip, ops
+    with pytest.raises(_hip.MbpoHipError):
+        ops.CriticGrad(x_dim=3, critic_dims=[3, 32, 1], batch=8, device=dev)      # hidden width must be 64
+    op = ops.CriticGrad(x_dim=3, critic_dims=[3, 64, 1], batch=8, device=dev)
+    with pytest.raises(ValueError):
+        op(torch.zeros(op.C * 2, device=dev), torch.zeros(4, 9, device=dev), torch.zeros(4, device=dev),
+           torch.zeros(5, device=dev, dtype=torch.int32), torch.zeros(3, device=dev), torch.ones(3, device=dev))
+
+
+# ------------------------------------------------------------------------------------------------ generic AdamW step
+@pytest.mark.parametrize("n", [1, 255, 4673, 100_003])
+def test_adamw_step_parity(dev, n):
+    """5 chained apply_if_finite(adamw) steps with a Polyak target vs oracle.sac.adamw_step; the 3rd gradient holds a NaN and
+    must be skipped entirely (params, moments, count).  Tolerance: moments 1e-6 rel, params atol 2e-7 (fp32 pow/sqrt)."""
+    from mbpo import ops
+    g = torch.Generator().manual_seed(n)
+    p = torch.randn(n, generator=g)
+    tgt = p.clone()
+    m, v, cnt = torch.zeros(n), torch.zeros(n), 0
+    opt = ops.AdamW(n, dev, lr=3e-3, weight_decay=1e-2, apply_if_finite=True)
+    dp, dt = p.to(dev), tgt.to(dev)
+    tau = 0.05
+    for it in range(5):
+        gr = torch.randn(n, generator=g) * (10.0 ** (it - 2))
+        if it == 2:
+            gr[n // 2] = float("nan")
+        p, m, v, cnt2 = obptt.apply_if_finite_adamw(p, gr, m, v, cnt, 3e-3, 1e-2)
+        if cnt2 != cnt:
+            tgt = (1 - tau) * tgt + tau * p
+        cnt = cnt2
+        opt.step(dp, gr.to(dev), target=dt, tau=tau)
+        torch.cuda.synchronize()
+        if it == 2:
+            assert math.isnan(float(opt.grad_norm))
+        else:
+            assert abs(float(opt.grad_norm) - float(gr.norm())) <= 1e-5 * float(gr.norm())
+        assert float(opt.count) == cnt
+        torch.testing.assert_close(opt.m.cpu(), m, atol=1e-12, rtol=2e-6)
+        torch.testing.assert_close(opt.v.cpu(), v, atol=1e-12, rtol=2e-6)
+        torch.testing.assert_close(dp.cpu(), p, atol=3e-7, rtol=1e-6)
+        torch.testing.assert_close(dt.cpu(), tgt, atol=3e-7, rtol=1e-6)
+    assert cnt == 4
+
+
+def test_adamw_step_without_finite_guard_and_scale(dev):
+    """grad_scale (the 1/world_size of a data-parallel mean) and the unguarded path."""
+    from mbpo import ops
+    from oracle.sac import adamw_step
+    n = 1000
+    g = torch.Generator().manual_seed(5)
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    opt = ops.AdamW(n, dev, lr=1e-3, weight_decay=1e-5, apply_if_finite=False)
+    dp = p.to(dev)
+    opt.step(dp, (gr * 4).to(dev), grad_scale=0.25)
+    p2, m2, v2 = adamw_step(p, gr, torch.zeros(n), torch.zeros(n), 1, 1e-3, 1e-5)
+    torch.testing.assert_close(dp.cpu(), p2, atol=2e-7, rtol=1e-6)
+    torch.testing.assert_close(opt.v.cpu(), v2, atol=1e-12, rtol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------ BPTT Normalizer
+def test_bptt_normalizer_matches_reference_form(dev):
+    """Normalizer.update (bptt_optimizer.py:52-67) via mbpo_running_stats_* with the BPTT clip.  Three chained batches,
+    the last one constant (std floor 1e-8 is NOT reached because earlier variance remains)."""
+    import sys
+    from mbpo.optimizers.policy_optimizers.bptt_optimizer import Normalizer
+    g = torch.Generator().manual_seed(0)
+    nz = Normalizer((4,))
+    st = nz.initialize_normalizer_state(dev)
+    mean, std, size = torch.zeros(4), torch.ones(4), 0
+    for k, nrows in enumerate((1000, 37, 64)):
+        x = torch.randn(nrows, 4, generator=g) * torch.tensor([1.0, 5.0, 0.1, 30.0]) + torch.tensor([0.0, 2.0, -1.0, 100.0])
+        if k == 2:
+            x = x[:1].repeat(nrows, 1)
+        st = nz.update(x.to(dev), st)
+        mean, std, size = obptt.normalizer_update(x, mean, std, size)
+        assert float(st.size) == size
+        torch.testing.assert_close(st.mean.cpu(), mean, atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(st.std.cpu(), std, atol=1e-5, rtol=2e-5)
+    # degenerate: constant data from the start -> std clamps at 1e-8 (brax's clip would give 1e-6)
+    st = nz.update(torch.full((8, 4), 2.5, device=dev), nz.initialize_normalizer_state(dev))
+    assert torch.allclose(st.std.cpu(), torch.full((4,), 1e-8))
+    assert torch.allclose(st.mean.cpu(), torch.full((4,), 2.5))

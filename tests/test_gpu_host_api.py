@@ -1,6 +1,7 @@
 """GPU: the host-side mirror of the reference API (mbpo.systems / mbpo.optimizers) — usage modelled on the reference's
 own tests (tests/test_sys_pendulum.py, tests/test_sac.py), plus the golden Pendulum KATs through System.step."""
 import json
+import math
 from pathlib import Path
 
 import numpy as np
@@ -206,3 +207,83 @@ def test_ppo_optimizer_learns_pendulum(dev):
         x, r = nxt.x_next, float(nxt.reward)
     assert out.summary[-1]["eval/episode_reward"] >= -400
     assert abs(r) <= 0.1
+
+
+def _bptt_pendulum_setup(dev, buffer_rows=10000):
+    """tests/test_bptt.py:11-50: a 1-transition true buffer at the hanging-down state (theta = pi, omega = 0)."""
+    from mbpo.replay import UniformSamplingQueue
+    from mbpo.systems import PendulumSystem
+    from mbpo.types import Transition
+    system = PendulumSystem()
+    init_sys_state = system.reset()
+    theta = torch.tensor([math.pi], device=dev)
+    obs = torch.cat([torch.cos(theta), torch.sin(theta), torch.zeros(1, device=dev)])[None]
+    dummy_sample = Transition(observation=init_sys_state.x_next, action=torch.zeros(system.u_dim, device=dev),
+                              reward=init_sys_state.reward, discount=torch.tensor(0.99, device=dev),
+                              next_observation=init_sys_state.x_next)
+    sampling_buffer = UniformSamplingQueue(max_replay_size=buffer_rows, dummy_data_sample=dummy_sample, sample_batch_size=1, device=dev)
+    sbs = sampling_buffer.init(0)
+    sample = Transition(observation=obs, action=torch.zeros(1, system.u_dim, device=dev), reward=torch.zeros(1, device=dev),
+                        discount=torch.ones(1, device=dev), next_observation=obs)
+    return system, init_sys_state, sampling_buffer.insert(sbs, sample)
+
+
+@pytest.mark.timeout(900)
+def test_bptt_optimizer_learns_pendulum(dev):
+    """The reference's acceptance test (tests/test_bptt.py:52-95) on the HIP path: 1000 BPTT train steps (n=50, H=20) on the
+    analytic Pendulum, then a 200-step closed loop with the deterministic policy; summed reward >= -400."""
+    from mbpo.optimizers import BPTTOptimizer
+    system, init_sys_state, sbs = _bptt_pendulum_setup(dev)
+    optimizer = BPTTOptimizer(action_dim=1, obs_dim=3, horizon=20, num_samples_per_gradient_update=50, train_steps=1000,
+                              init_stddev=2.0, lambda_=0.97, critic_updates_per_policy_update=1, use_best_trained_policy=True,
+                              sampling_buffer_size=2_000_000)      # 10 M rows in the reference; 1.01 M are ever used here
+    optimizer.set_system(system=system)
+    bptt_state = optimizer.init(key=0, true_buffer_state=sbs)
+    output = optimizer.train(bptt_state=bptt_state)
+    bptt_state = output.optimizer_state
+    s = output.bptt_summary
+    assert s.actor_loss.shape == (1000,) and bool(torch.isfinite(s.actor_loss).all()) and bool(torch.isfinite(s.critic_loss).all())
+    assert float(bptt_state.actor_opt_state.count) == 1000 and float(bptt_state.critic_opt_state.count) == 1000
+    assert float(bptt_state.state_normalizer_state.size) == 1000 * 50 * 20
+    x, rewards = init_sys_state.x_next, []
+    for _ in range(200):
+        u, bptt_state = optimizer.act(obs=x, opt_state=bptt_state)
+        nxt = system.step(x=x, u=u, system_params=bptt_state.system_params)
+        x = nxt.x_next
+        rewards.append(float(nxt.reward))
+    print("bptt closed-loop reward:", sum(rewards))
+    assert sum(rewards) >= -400
+
+
+def test_bptt_optimizer_evaluation_and_best_policy(dev):
+    """evaluate_agent path (:479-512): eval every 2 steps + the last one; best_reward is the running max of reward; the
+    returned state is the best one when use_best_trained_policy; critic_updates_per_policy_update > 1; EnsembleSystem model."""
+    from mbpo.optimizers import BPTTOptimizer
+    from mbpo.systems import EnsembleDynamics, EnsembleSystem, QuadraticReward
+    from mbpo.replay import UniformSamplingQueue
+    from mbpo.types import Transition
+    X, U = 4, 2
+    system = EnsembleSystem(EnsembleDynamics(X, U, n_members=3), QuadraticReward(X, U), mode="mean")
+    dummy = Transition(observation=torch.zeros(X, device=dev), action=torch.zeros(U, device=dev), reward=torch.zeros((), device=dev),
+                       discount=torch.ones((), device=dev), next_observation=torch.zeros(X, device=dev))
+    q = UniformSamplingQueue(max_replay_size=64, dummy_data_sample=dummy, sample_batch_size=1, device=dev)
+    g = torch.Generator().manual_seed(0)
+    obs = torch.randn(40, X, generator=g).to(dev)
+    sbs = q.insert(q.init(0), Transition(observation=obs, action=torch.zeros(40, U, device=dev), reward=torch.zeros(40, device=dev),
+                                         discount=torch.ones(40, device=dev), next_observation=obs))
+    opt = BPTTOptimizer(obs_dim=X, action_dim=U, horizon=5, num_samples_per_gradient_update=24, train_steps=7, evaluation_samples=16,
+                        evaluation_horizon=10, evaluation_frequency=2, critic_updates_per_policy_update=3,
+                        use_best_trained_policy=True, sampling_buffer_size=4096)
+    opt.set_system(system)
+    st = opt.init(key=1, true_buffer_state=sbs)
+    out = opt.train(bptt_state=st)
+    s = out.bptt_summary
+    r, b = s.reward.cpu(), s.best_reward.cpu()
+    assert bool(torch.isfinite(r).all())
+    assert r[1] == r[0] and r[3] == r[2] and r[5] == r[4]            # skipped evaluations carry the previous reward
+    assert torch.equal(b, torch.cummax(r, 0).values)
+    assert float(out.optimizer_state.critic_opt_state.count) <= 7 * 3
+    a, _ = opt.act(obs[:5], out.optimizer_state)
+    assert a.shape == (5, U) and float(a.abs().max()) <= 0.999
+    a2, st2 = opt.act(obs[0], out.optimizer_state, evaluate=False)
+    assert a2.shape == (U,) and st2.key != out.optimizer_state.key
