@@ -163,7 +163,7 @@ def test_critic_grads_rejects_bad_shapes(dev):
 @pytest.mark.parametrize("n", [1, 255, 4673, 100_003])
 def test_adamw_step_parity(dev, n):
     """5 chained apply_if_finite(adamw) steps with a Polyak target vs oracle.sac.adamw_step; the 3rd gradient holds a NaN and
-    must be skipped entirely (params, moments, count).  Tolerance: moments 1e-6 rel, params atol 2e-7 (fp32 pow/sqrt)."""
+    must be skipped entirely (params, moments, count).  Tolerance: moments 2e-6 rel (+1 ulp of the largest), params atol 3e-7 (fp32 pow/sqrt)."""
     from mbpo import ops
     g = torch.Generator().manual_seed(n)
     p = torch.randn(n, generator=g)
@@ -187,8 +187,9 @@ def test_adamw_step_parity(dev, n):
         else:
             assert abs(float(opt.grad_norm) - float(gr.norm())) <= 1e-5 * float(gr.norm())
         assert float(opt.count) == cnt
-        torch.testing.assert_close(opt.m.cpu(), m, atol=1e-12, rtol=2e-6)
-        torch.testing.assert_close(opt.v.cpu(), v, atol=1e-12, rtol=2e-6)
+        # b1*m + 0.1*g may cancel: absolute slack of one fp32 ulp of the largest moment (hipcc contracts to FMA, torch does not)
+        torch.testing.assert_close(opt.m.cpu(), m, atol=2e-7 * float(m.abs().max()), rtol=2e-6)
+        torch.testing.assert_close(opt.v.cpu(), v, atol=2e-7 * float(v.abs().max()), rtol=2e-6)
         torch.testing.assert_close(dp.cpu(), p, atol=3e-7, rtol=1e-6)
         torch.testing.assert_close(dt.cpu(), tgt, atol=3e-7, rtol=1e-6)
     assert cnt == 4
