@@ -327,6 +327,7 @@ class BPTTOptimizer(BaseOptimizer):
         self._reward_ms[0:1].copy_(w.reward_norm.vec[1:2])
         self._reward_ms[1:2].copy_(w.reward_norm.vec[3:4])
         ag = self._actor_grad
+        ag.desc.seed = act_seed
         ag(actor_params=w.actor_params, target_critic_params=w.target_critic_params, init_states=self._init_obs,
            state_mean=w.state_norm.mean, state_std=w.state_norm.std, reward_mean_std=self._reward_ms, offset=0,
            offset_dev=self._step_dev, **w.sys_kw)
@@ -403,6 +404,7 @@ class BPTTOptimizer(BaseOptimizer):
         self._step_dev.zero_()
         # per-train() Philox seeds; the step counter is the Philox offset (the reference re-splits a key every step)
         seeds = tuple(K.split(train_key, 4)[:3])
+        self._last_seeds = seeds                       # (initial-state sampling, action noise, critic minibatch) — for parity tests
         summaries = torch.zeros(self.train_steps, 6, device=self.device, dtype=torch.float32)
         prev_reward = torch.zeros((), device=self.device)
         best_reward = torch.full((), -math.inf, device=self.device)

@@ -203,3 +203,59 @@ class TorchPendulumSystem:
     def step(self, x, u):
         from .systems import pendulum_next_state, pendulum_reward
         return pendulum_next_state(x, u, self.p), pendulum_reward(x, u, self.p)
+
+
+# ------------------------------------------------------------------------------------------------ whole train steps
+class CpuBpttLoop:
+    """`train`'s scan body (bptt_optimizer.py:463-522) composed from the pieces above, with the product's Philox streams
+    (seeds = (initial-state sampling, action noise, critic minibatch); Philox offset = train-step index)."""
+
+    def __init__(self, cfg: BpttConfig, system, actor_params, critic_params, true_rows, n, critic_updates, seeds,
+                 buffer_size=4096, normalize=True, insert=True):
+        from . import replay as oreplay
+        self.cfg, self.system, self.n, self.K = cfg, system, n, critic_updates
+        self.seeds, self.do_norm, self.do_insert = seeds, normalize, insert
+        self.ap, self.cp, self.tp = actor_params.clone(), critic_params.clone(), critic_params.clone()
+        z = torch.zeros_like
+        self.am, self.av, self.ac = z(self.ap), z(self.ap), 0
+        self.cm, self.cv, self.cc = z(self.cp), z(self.cp), 0
+        X = cfg.x_dim
+        self.s_mean, self.s_std, self.s_size = torch.zeros(X), torch.ones(X), 0
+        self.r_mean, self.r_std, self.r_size = torch.zeros(1), torch.ones(1), 0
+        self.D = 2 * X + cfg.u_dim + 2
+        self.queue = oreplay.UniformSamplingQueue(buffer_size, self.D, n)
+        self.buf = self.queue.insert(self.queue.init(), true_rows.numpy())
+        self.step_idx = 0
+
+    def step(self):
+        import numpy as np
+        from . import philox
+        cfg, n, H, X, U = self.cfg, self.n, self.cfg.horizon, self.cfg.x_dim, self.cfg.u_dim
+        obs_seed, act_seed, critic_seed = self.seeds
+        _, rows = self.queue.sample(self.buf, obs_seed, self.step_idx, n)
+        x0 = torch.from_numpy(rows[:, :X].copy())
+        noise = torch.from_numpy(philox.philox_normal(act_seed, self.step_idx, philox.STREAM_POLICY_NOISE,
+                                                      np.arange(n * H * U, dtype=np.uint64))).reshape(n, H, U)
+        g, loss, aux = actor_grads(cfg, self.system, self.ap, self.tp, x0, noise, self.s_mean, self.s_std, self.r_mean[0], self.r_std[0])
+        self.ap, self.am, self.av, self.ac = apply_if_finite_adamw(self.ap, g, self.am, self.av, self.ac, cfg.lr_actor, cfg.wd_actor)
+        R = n * H
+        B = -(-R // self.K)
+        idx = philox.philox_randint(critic_seed, self.step_idx, philox.STREAM_REPLAY, np.arange(self.K * B, dtype=np.uint64), 0, R)
+        obs_flat, lam_flat = aux["observation"].reshape(R, X), aux["lambda_values"].reshape(R)
+        closs = gnorm = None
+        for k in range(self.K):
+            j = torch.from_numpy(idx[k * B:(k + 1) * B].astype(np.int64))
+            cg, closs = critic_grads(cfg, self.cp, obs_flat[j], lam_flat[j], self.s_mean, self.s_std)
+            gnorm = float(cg.norm())
+            before = self.cc
+            self.cp, self.cm, self.cv, self.cc = apply_if_finite_adamw(self.cp, cg, self.cm, self.cv, self.cc, cfg.lr_critic, cfg.wd_critic)
+            self.tp = (1 - cfg.tau) * self.tp + cfg.tau * self.cp
+        rows_out = torch.cat([obs_flat, aux["action"].reshape(R, U), aux["reward"].reshape(R, 1), torch.ones(R, 1),
+                              aux["next_observation"].reshape(R, X)], dim=1)
+        if self.do_norm:
+            self.s_mean, self.s_std, self.s_size = normalizer_update(obs_flat, self.s_mean, self.s_std, self.s_size)
+            self.r_mean, self.r_std, self.r_size = normalizer_update(aux["reward"].reshape(R, 1), self.r_mean, self.r_std, self.r_size)
+        if self.do_insert:
+            self.buf = self.queue.insert(self.buf, rows_out.numpy())
+        self.step_idx += 1
+        return dict(actor_loss=loss, actor_grad_norm=float(g.norm()), critic_loss=closs, critic_grad_norm=gnorm, rows=rows_out)
