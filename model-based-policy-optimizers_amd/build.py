@@ -26,6 +26,9 @@ CXXFLAGS = [
     "-std=c++17",
     "-fPIC",
     "-fno-fast-math",          # parity: keep IEEE semantics, precise expf/logf/tanhf
+    # SimplifyCFG's common-code sinking merges the identical load sequences of the two weight register sets (chain_run.hpp)
+    # into one block addressed through a phi of allocas; the sets then cannot be promoted to registers and live in scratch.
+    "-mllvm", "-simplifycfg-sink-common=false",
     "-ffp-contract=on",
     "-Wall",
     "-Wno-unused-function",

@@ -1,0 +1,592 @@
+// chain_run.hpp — phase-level runners: one wave group walks a whole MLP chain (forward, input-gradient or weight-gradient)
+// with its barriers inside, from shapes that live in SGPRs.
+//
+// Why (measured on MI355X, scripts/sac_phase_stamps.py + scripts/probes/icache_probe.hip):
+//  * a kernel assembled from per-phase inlined copies of the layer routines was 270 KB of straight-line code against a
+//    64 KB instruction cache: every step streamed cold code (~1.1 B/cycle);
+//  * a step-level interpreter that looked its shapes up in an LDS table was compact but every shape became a VGPR
+//    ("divergent") value: hipcc wrapped each weight load in its own exec-mask block and the step got slower;
+//  * a lone wave issues ~1 instruction per 4-5 cycles, so a layer step costs what its instruction count costs:
+//    32 MFMAs are 1024 cycles, everything else has to stay in the low hundreds of instructions.
+// So: shapes are kernel-argument scalars (NetShape), the wave's role comes from readfirstlane, each runner is ONE loop whose
+// body holds each layer routine once, weights are requested one layer ahead (WPre, wave_mlp.hpp), and a kernel calls each
+// runner from a single call site.  Waves of different chains run different runners between the same barriers: every
+// runner executes exactly `n_steps` workgroup barriers.
+#pragma once
+#include "wave_mlp.hpp"
+
+struct NetShape {
+  int K_in;    // network input width
+  int L;       // number of Dense layers (>= 2); hidden layers are all 16*HT wide
+  int N_out;   // network output width
+  int act;
+};
+
+// Re-materialise the lane id inside a loop body: hipcc otherwise hoists every per-lane address of every phase out of the
+// phase loop (LICM), keeps them all live (256 VGPRs, ~90 spills) and the hot loop pays for the spill traffic.
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+__device__ __forceinline__ NetShape net_shape(const MlpDev &m) { return NetShape{m.dims[0], m.n_layers, m.dims[m.n_layers], m.act}; }
+
+// floats of layer l's weight+bias block, and the flat offset of layer l (hidden width H)
+__device__ __forceinline__ int layer_floats(const NetShape &s, int H, int l) {
+  const int K = l == 0 ? s.K_in : H, N = l == s.L - 1 ? s.N_out : H;
+  return K * N + N;
+}
+
+// ------------------------------------------------------------------------------------------------ weight prefetch
+// The next layer's weights are requested one step ahead into the OTHER of two register sets; the sets swap roles by
+// unrolling the hidden-layer loop by two.  (A struct copy `cur = next` at the end of a step reads registers whose loads are
+// still in flight, i.e. waits for them on the spot — measured: no overlap at all.  Inline-asm loads with a manual
+// s_waitcnt are not an option either: hipcc copies/spills asm outputs right after the asm statement, before the data lands.)
+// Plain loads keep hipcc's own counted vmcnt(N) waits exact.
+typedef float f2v __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f4v __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ const float *gaddr(const float *base, unsigned voff) {
+  return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + voff);
+}
+__device__ __forceinline__ void gload1(float &d, const float *base, unsigned voff) { d = *gaddr(base, voff); }
+__device__ __forceinline__ void gload2(float *d, const float *base, unsigned voff) {
+  f2v t = *reinterpret_cast<const f2v *>(gaddr(base, voff));
+  d[0] = t[0]; d[1] = t[1];
+}
+__device__ __forceinline__ void gload4(float *d, const float *base, unsigned voff) {
+  f4v t = *reinterpret_cast<const f4v *>(gaddr(base, voff));
+  d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = t[3];
+}
+template <int NV>
+__device__ __forceinline__ void gloadv(float *d, const float *base, unsigned voff) {
+  if constexpr (NV == 1) gload1(d[0], base, voff);
+  else if constexpr (NV == 2) gload2(d, base, voff);
+  else {
+    static_assert(NV % 4 == 0, "gloadv width");
+#pragma unroll
+    for (int c = 0; c < NV / 4; ++c) gload4(d + 4 * c, base, voff + 16u * c);
+  }
+}
+
+// One lane's share of one layer (NW weights + NB biases) and what it holds.
+template <int HT, int SP>
+struct WSet {
+  static constexpr int KS = 4 * HT, CT = HT / SP, NW = KS * CT;
+  float w[NW];
+  float b[CT];
+};
+
+// (kept as the place where a set's requests are expected to have landed; the compiler places the counted wait itself)
+template <int HT, int SP>
+__device__ __forceinline__ void wset_wait(WSet<HT, SP> &S) {}
+
+// forward, hidden -> hidden slice: w[s*CT + t] = W[g*KS + s][c0 + CT*r + t], b[t] = bias[c0 + CT*r + t]
+template <int HT, int SP>
+__device__ __forceinline__ void wset_load_fwd_full(WSet<HT, SP> &S, const float *W, int sub, int lane) {
+  constexpr int H = 16 * HT, KS = 4 * HT, CT = HT / SP;
+  const int r = lane & 15, g = lane >> 4;
+  const unsigned v0 = (unsigned)(((g * KS) * H + sub * 16 * CT + CT * r) * 4);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) gloadv<CT>(&S.w[s * CT], W, v0 + (unsigned)(s * H * 4));
+  gloadv<CT>(S.b, W, (unsigned)((H * H + sub * 16 * CT + CT * r) * 4));
+}
+
+// forward, network input layer (K <= 32): w[s*CT + t] = W[clamp(g*kc + s)][c0 + CT*r + t], s < 8
+template <int HT, int SP>
+__device__ __forceinline__ void wset_load_fwd_in(WSet<HT, SP> &S, const float *W, int K, int sub, int lane) {
+  constexpr int H = 16 * HT, CT = HT / SP;
+  const int r = lane & 15, g = lane >> 4;
+  const int kc = (K + 3) >> 2;
+  const unsigned vc = (unsigned)((sub * 16 * CT + CT * r) * 4);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int k = g * kc + s;
+    const int kk = ((s < kc) && (k < K)) ? k : 0;
+    gloadv<CT>(&S.w[s * CT], W, vc + (unsigned)(kk * H * 4));
+  }
+  gloadv<CT>(S.b, W, vc + (unsigned)(K * H * 4));
+}
+
+// forward, output layer (K == H, N <= 16*NTL <= 16*CT), wave 0 of the group: w[s*NTL + t] = W[g*KS + s][col(t)]
+template <int HT, int SP, int NTL>
+__device__ __forceinline__ void wset_load_fwd_out(WSet<HT, SP> &S, const float *W, int N, int lane) {
+  constexpr int H = 16 * HT, KS = 4 * HT;
+  const int r = lane & 15, g = lane >> 4;
+  unsigned vcol[NTL];
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) vcol[t] = (unsigned)(((NTL * r + t < N) ? NTL * r + t : 0) * 4);
+  const unsigned vrow = (unsigned)(g * KS * N * 4);
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) gload1(S.w[s * NTL + t], W, vrow + (unsigned)(s * N * 4) + vcol[t]);
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) gload1(S.b[t], W, (unsigned)(H * N * 4) + vcol[t]);
+}
+
+// dgrad of a hidden layer (W [H][H]): w[t*NS + n] = W[k0 + CT*r + t][g*NS + n]
+template <int HT, int SP>
+__device__ __forceinline__ void wset_load_dg_full(WSet<HT, SP> &S, const float *W, int sub, int lane) {
+  constexpr int H = 16 * HT, NS = 4 * HT, CT = HT / SP;
+  const int r = lane & 15, g = lane >> 4;
+  const unsigned v0 = (unsigned)(((sub * 16 * CT + CT * r) * H + g * NS) * 4);
+#pragma unroll
+  for (int t = 0; t < CT; ++t) gloadv<NS>(&S.w[t * NS], W, v0 + (unsigned)(t * H * 4));
+}
+
+// dgrad of the output layer (W [H][N], N <= 32): w[s*CT + t] = W[k0 + CT*r + t][clamp(g*nc + s)], s < 8
+template <int HT, int SP>
+__device__ __forceinline__ void wset_load_dg_out(WSet<HT, SP> &S, const float *W, int N, int sub, int lane) {
+  constexpr int CT = HT / SP;
+  const int r = lane & 15, g = lane >> 4;
+  const int nc = (N + 3) >> 2;
+  const unsigned vrow = (unsigned)((sub * 16 * CT + CT * r) * N * 4);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int n = g * nc + s;
+    const int nn = ((s < nc) && (n < N)) ? n : 0;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) gload1(S.w[s * CT + t], W, vrow + (unsigned)((t * N + nn) * 4));
+  }
+}
+
+// dgrad of layer 0 towards the network input (W [K][H], K <= 16), wave 0: w[n] = W[clamp(r)][g*NS + n]
+template <int HT, int SP>
+__device__ __forceinline__ void wset_load_dg_in(WSet<HT, SP> &S, const float *W, int K, int lane) {
+  constexpr int H = 16 * HT, NS = 4 * HT;
+  const int r = lane & 15, g = lane >> 4;
+  gloadv<NS>(S.w, W, (unsigned)((((r < K) ? r : 0) * H + g * NS) * 4));
+}
+
+// ---- computes on a register image ----------------------------------------------------------------------------
+// hidden slice from a full (K == H) or input (K <= 32) image
+template <int HT, int SP, bool IN>
+__device__ __forceinline__ void wset_fwd_hidden(const WSet<HT, SP> &S, const float *x, int ldx, int K, float *h_out, float *z_out,
+                                                int ldo, int act, int lane) {
+  constexpr int KS = 4 * HT, CT = HT / SP;
+  const int r = lane & 15, g = lane >> 4;
+  f32x4 acc[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (!IN) {
+    const float *xr = x + r * ldx + g * KS;
+#pragma unroll
+    for (int q = 0; q < KS / 4; ++q) {
+      float av[4];
+      load_vec_lds<4>(xr + 4 * q, av);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], S.w[(4 * q + u) * CT + t], acc[t], 0, 0, 0);
+    }
+  } else {
+    const int kc = (K + 3) >> 2;
+    float av[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k = g * kc + s;
+      const bool ok = (s < kc) && (k < K);
+      av[s] = x[r * ldx + (ok ? k : 0)];
+      av[s] = ok ? av[s] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], S.w[s * CT + t], acc[t], 0, 0, 0);
+  }
+  // epilogue: the (uniform) activation / z-store decisions are taken once, not per row, and the 4*CT values of a lane go
+  // through the activation together (independent transcendental ops pipeline instead of serialising per row)
+  float zv[4 * CT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < CT; ++t) zv[i * CT + t] = acc[t][i] + S.b[t];
+  const int o0 = (4 * g) * ldo + CT * r;
+  if (z_out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_vec_lds<CT>(z_out + o0 + i * ldo, *reinterpret_cast<float(*)[CT]>(&zv[i * CT]));
+  }
+  act_apply_vec<4 * CT>(zv, act);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) store_vec_lds<CT>(h_out + o0 + i * ldo, *reinterpret_cast<float(*)[CT]>(&zv[i * CT]));
+}
+
+template <int HT, int SP, int NTL>
+__device__ __forceinline__ void wset_fwd_out(const WSet<HT, SP> &S, const float *x, int ldx, int N, float *y, int ldy, int lane) {
+  constexpr int KS = 4 * HT;
+  const int r = lane & 15, g = lane >> 4;
+  f32x4 acc[NTL];
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float *xr = x + r * ldx + g * KS;
+#pragma unroll
+  for (int q = 0; q < KS / 4; ++q) {
+    float av[4];
+    load_vec_lds<4>(xr + 4 * q, av);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], S.w[(4 * q + u) * NTL + t], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    const int n = NTL * r + t;
+    if (n < N) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[(4 * g + i) * ldy + n] = acc[t][i] + S.b[t];
+    }
+  }
+}
+
+// delta_{l-1}[:, k0 .. k0+16*CT) from a hidden (FULL) or output-layer (OUT: N <= 32) dgrad image
+template <int HT, int SP, bool OUT>
+__device__ __forceinline__ void wset_dgrad(const WSet<HT, SP> &S, const float *delta, int ldd, int N, const float *zp, float *dx, int ldh,
+                                           int act, int lane) {
+  constexpr int NS = 4 * HT, CT = HT / SP;
+  const int r = lane & 15, g = lane >> 4;
+  f32x4 acc[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (!OUT) {
+    const float *dr = delta + r * ldd + g * NS;
+#pragma unroll
+    for (int q = 0; q < NS / 4; ++q) {
+      float av[4];
+      load_vec_lds<4>(dr + 4 * q, av);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], S.w[t * NS + 4 * q + u], acc[t], 0, 0, 0);
+    }
+  } else {
+    const int nc = (N + 3) >> 2;
+    float av[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int n = g * nc + s;
+      const bool ok = (s < nc) && (n < N);
+      av[s] = delta[r * ldd + (ok ? n : 0)];
+      av[s] = ok ? av[s] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], S.w[s * CT + t], acc[t], 0, 0, 0);
+  }
+  float ov[4 * CT], zv[4 * CT];
+  const int o0 = (4 * g) * ldh + CT * r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    load_vec_lds<CT>(zp + o0 + i * ldh, *reinterpret_cast<float(*)[CT]>(&zv[i * CT]));
+#pragma unroll
+    for (int t = 0; t < CT; ++t) ov[i * CT + t] = acc[t][i];
+  }
+  act_grad_mul_vec<4 * CT>(ov, zv, act);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) store_vec_lds<CT>(dx + o0 + i * ldh, *reinterpret_cast<float(*)[CT]>(&ov[i * CT]));
+}
+
+template <int HT, int SP>
+__device__ __forceinline__ void wset_dgrad_in(const WSet<HT, SP> &S, const float *delta, int ldd, int K, float *dX, int ld_dx, int lane) {
+  constexpr int NS = 4 * HT;
+  const int r = lane & 15, g = lane >> 4;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float *dr = delta + r * ldd + g * NS;
+#pragma unroll
+  for (int q = 0; q < NS / 4; ++q) {
+    float av[4];
+    load_vec_lds<4>(dr + 4 * q, av);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], S.w[4 * q + u], acc, 0, 0, 0);
+  }
+  if (r < K) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dX[(4 * g + i) * ld_dx + r] = acc[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fast-path predicates
+template <int HT, int SP>
+__device__ __forceinline__ bool fast_shape(const NetShape &sh) {
+  // input layer through the 8-step image, output layer through one n-tile image, hidden layers always
+  return (4 * HT * (HT / SP) <= 64) && sh.K_in <= 32 && sh.N_out <= 16 * (HT / SP) && sh.N_out <= 32 && sh.L >= 2;
+}
+
+// First-layer request of a forward / dgrad phase (issued by the kernel before the preceding elementwise section).
+template <int HT, int SP>
+__device__ __forceinline__ void chain_fwd_prefetch(WSet<HT, SP> &A, const NetShape sh, const float *params, int sub, int lane) {
+  if (fast_shape<HT, SP>(sh)) wset_load_fwd_in<HT, SP>(A, params, sh.K_in, sub, lane);
+}
+template <int HT, int SP>
+__device__ __forceinline__ void chain_dgrad_prefetch(WSet<HT, SP> &A, const NetShape sh, const float *params, int sub, int lane) {
+  constexpr int H = 16 * HT;
+  if (fast_shape<HT, SP>(sh)) wset_load_dg_out<HT, SP>(A, params + (sh.K_in * H + H) + (sh.L - 2) * (H * H + H), sh.N_out, sub, lane);
+}
+
+// request for layer ln (>= 1) of a forward chain: a hidden image, or the output image for the wave that computes it
+template <int HT, int SP>
+__device__ __forceinline__ void fwd_request(WSet<HT, SP> &S, const float *W1, int ln, int L, int N_out, int sub, int lane) {
+  constexpr int H = 16 * HT;
+  const float *Wn = W1 + (ln - 1) * (H * H + H);
+  if (ln < L - 1) wset_load_fwd_full<HT, SP>(S, Wn, sub, lane);
+  else if (ln == L - 1 && sub == 0) wset_load_fwd_out<HT, SP, 1>(S, Wn, N_out, lane);   // N_out <= 16 per n-tile image
+}
+
+// request for layer ln's dgrad image (ln <= L-2): hidden layers, or the input layer when the input gradient is wanted
+template <int HT, int SP>
+__device__ __forceinline__ void dgrad_request(WSet<HT, SP> &S, const float *params, const float *W1, int ln, int K_in, bool want_dx,
+                                              int sub, int lane) {
+  constexpr int H = 16 * HT;
+  if (ln >= 1) wset_load_dg_full<HT, SP>(S, W1 + (ln - 1) * (H * H + H), sub, lane);
+  else if (ln == 0 && want_dx && sub == 0) wset_load_dg_in<HT, SP>(S, params, K_in, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ forward runner
+// x: network input tile [16][ldx].  Hidden outputs go to hbuf + l*T (when hbuf) or ping-pong pp0/pp1; pre-activations to
+// zbuf + l*T (when zbuf); the output layer to y [16][ldy].  A must hold layer 0's request (chain_fwd_prefetch).
+// Executes exactly n_steps workgroup barriers.
+template <int HT, int SP>
+__device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__restrict__ params, const float *x, int ldx, float *pp0,
+                                              float *pp1, float *zbuf, float *hbuf, float *y, int ldy, int ldh, int n_steps, int sub,
+                                              int lane_, WSet<HT, SP> &A, unsigned long long *dbg = nullptr) {
+  constexpr int H = 16 * HT, CT = HT / SP;
+  const int T = 16 * ldh, c0 = sub * 16 * CT;
+  const int L = sh.L;
+#define DBG_STAMP(i)                                                                 \
+  if (dbg && lane_ == 0) {                                                           \
+    unsigned long long t_;                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+    dbg[i] = t_;                                                                     \
+  }
+  // (macros, not [&] lambdas: a by-reference closure kept in memory pins every captured variable — and the register sets
+  //  passed through it — to scratch)
+#define hout(l) ((hbuf ? hbuf + (l) * T : (((l) & 1) ? pp1 : pp0)) + c0)
+#define zout(l) (zbuf ? zbuf + (l) * T + c0 : nullptr)
+#define hin(l) ((const float *)(hbuf ? hbuf + ((l) - 1) * T : ((((l) - 1) & 1) ? pp1 : pp0)))   /* l >= 1 */
+  if (fast_shape<HT, SP>(sh)) {
+    if constexpr (4 * HT * (HT / SP) <= 64) {
+      WSet<HT, SP> B;
+      const float *W1 = params + sh.K_in * H + H;   // layer 1
+#define request(S, ln, lane) fwd_request<HT, SP>(S, W1, ln, L, sh.N_out, sub, lane)
+      // ---- layer 0 (input image in A) ----
+      {
+        const int lane = opaque(lane_);
+        wset_wait(A);
+        request(B, 1, lane);
+        wset_fwd_hidden<HT, SP, true>(A, x, ldx, sh.K_in, hout(0), zout(0), ldh, sh.act, lane);
+        __syncthreads();
+      }
+      // ---- hidden layers 1 .. L-2, two per trip: B then A ----
+      int l = 1;
+#pragma nounroll
+      for (; l + 1 <= L - 2; l += 2) {
+        const int lane = opaque(lane_);
+        DBG_STAMP(0);
+        wset_wait(B);
+        request(A, l + 1, lane);
+        DBG_STAMP(1);
+        wset_fwd_hidden<HT, SP, false>(B, hin(l), ldh, H, hout(l), zout(l), ldh, sh.act, lane);
+        DBG_STAMP(2);
+        __syncthreads();
+        DBG_STAMP(3);
+        wset_wait(A);
+        request(B, l + 2, lane);
+        DBG_STAMP(4);
+        wset_fwd_hidden<HT, SP, false>(A, hin(l + 1), ldh, H, hout(l + 1), zout(l + 1), ldh, sh.act, lane);
+        DBG_STAMP(5);
+        __syncthreads();
+        DBG_STAMP(6);
+      }
+      bool in_a = false;
+      if (l <= L - 2) {   // one hidden layer left: it is in B, the output image goes to A
+        const int lane = opaque(lane_);
+        wset_wait(B);
+        request(A, l + 1, lane);
+        wset_fwd_hidden<HT, SP, false>(B, hin(l), ldh, H, hout(l), zout(l), ldh, sh.act, lane);
+        __syncthreads();
+        ++l;
+        in_a = true;
+      }
+      // ---- output layer L-1 (image in B, or in A after an odd number of hidden layers; no register copies) ----
+      if (sub == 0) {
+        const int lane = opaque(lane_);
+        if (sh.N_out <= 16) {
+          if (in_a) wset_fwd_out<HT, SP, 1>(A, hin(L - 1), ldh, sh.N_out, y, ldy, lane);
+          else wset_fwd_out<HT, SP, 1>(B, hin(L - 1), ldh, sh.N_out, y, ldy, lane);
+        } else {
+          if constexpr (CT >= 2) gen_dense_fwd(hin(L - 1), ldh, H, W1 + (L - 2) * (H * H + H), sh.N_out,
+                                               W1 + (L - 2) * (H * H + H) + H * sh.N_out, 0, sh.N_out, y, nullptr, ldy, -1, lane);
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    // shapes without register images: self-loading routines (banked for wide hidden layers, generic otherwise)
+    const float *W = params;
+    const float *cur = x;
+    int ldc = ldx;
+#pragma nounroll
+    for (int l = 0; l < L; ++l) {
+      const int lane = opaque(lane_);
+      const int K = (l == 0) ? sh.K_in : H;
+      const bool last = (l == L - 1);
+      const int N = last ? sh.N_out : H;
+      if (!last) {
+        float *ho = hout(l), *zo = zout(l);
+        if (K == H) wave_dense_fwd<CT, 4 * HT>(cur, ldc, K, W + c0, H, W + K * H + c0, 16 * CT, ho, zo, ldh, sh.act, lane);
+        else if (K <= 32) wave_dense_fwd<CT>(cur, ldc, K, W + c0, H, W + K * H + c0, 16 * CT, ho, zo, ldh, sh.act, lane);
+        else gen_dense_fwd(cur, ldc, K, W, H, W + K * H, c0, c0 + 16 * CT, ho - c0, zo ? zo - c0 : nullptr, ldh, sh.act, lane);
+        cur = ho - c0;
+        ldc = ldh;
+      } else if (sub == 0) {
+        if (N <= 16) wave_dense_fwd<1, 4 * HT>(cur, ldc, K, W, N, W + K * N, N, y, nullptr, ldy, -1, lane);
+        else gen_dense_fwd(cur, ldc, K, W, N, W + K * N, 0, N, y, nullptr, ldy, -1, lane);
+      }
+      __syncthreads();
+      W += K * N + N;
+    }
+  }
+#pragma nounroll
+  for (int l = L; l < n_steps; ++l) __syncthreads();
+#undef hout
+#undef zout
+#undef hin
+#undef request
+#undef DBG_STAMP
+}
+
+// ------------------------------------------------------------------------------------------------ dgrad runner
+// dY [16][ldy] is the delta of the output layer; deltas of hidden layers ping-pong through d0/d1 (layer l's dgrad writes
+// delta_{l-1} to (l&1 ? d1 : d0)); zbuf from the forward (layer l at + l*T); dX (optional) receives the input gradient.
+// A must hold layer L-1's request (chain_dgrad_prefetch).  Executes exactly n_steps workgroup barriers.
+template <int HT, int SP>
+__device__ __forceinline__ void chain_dgrad_run(const NetShape sh, const float *__restrict__ params, const float *dY, int ldy,
+                                                const float *zbuf, float *d0, float *d1, float *dX, int ld_dx, int ldh, int n_steps,
+                                                int sub, int lane_, WSet<HT, SP> &A) {
+  constexpr int H = 16 * HT, CT = HT / SP;
+  const int T = 16 * ldh, k0 = sub * 16 * CT;
+  const int L = sh.L;
+#define din(l) ((const float *)((((l) + 1) & 1) ? d1 : d0))   /* delta_l for l < L-1 */
+#define dout(l) ((((l) & 1) ? d1 : d0) + k0)                 /* delta_{l-1}, this wave's slice */
+#define zprev(l) (zbuf + ((l) - 1) * T + k0)
+  const float *W1 = params + sh.K_in * H + H;   // layer 1
+  const bool fast = fast_shape<HT, SP>(sh) && (dX == nullptr || sh.K_in <= 16);
+  if (fast) {
+    if constexpr (4 * HT * (HT / SP) <= 64) {
+      WSet<HT, SP> B;
+#define request(S, ln, lane) dgrad_request<HT, SP>(S, params, W1, ln, sh.K_in, dX != nullptr, sub, lane)
+      // ---- output layer L-1 (image in A) ----
+      {
+        const int lane = opaque(lane_);
+        wset_wait(A);
+        request(B, L - 2, lane);
+        wset_dgrad<HT, SP, true>(A, dY, ldy, sh.N_out, zprev(L - 1), dout(L - 1), ldh, sh.act, lane);
+        __syncthreads();
+      }
+      // ---- hidden layers L-2 .. 1, two per trip: B then A ----
+      int l = L - 2;
+#pragma nounroll
+      for (; l - 1 >= 1; l -= 2) {
+        const int lane = opaque(lane_);
+        wset_wait(B);
+        request(A, l - 1, lane);
+        wset_dgrad<HT, SP, false>(B, din(l), ldh, H, zprev(l), dout(l), ldh, sh.act, lane);
+        __syncthreads();
+        wset_wait(A);
+        request(B, l - 2, lane);
+        wset_dgrad<HT, SP, false>(A, din(l - 1), ldh, H, zprev(l - 1), dout(l - 1), ldh, sh.act, lane);
+        __syncthreads();
+      }
+      bool in_a = false;
+      if (l >= 1) {   // one hidden layer left: it is in B, the input image (if any) goes to A
+        const int lane = opaque(lane_);
+        wset_wait(B);
+        request(A, l - 1, lane);
+        wset_dgrad<HT, SP, false>(B, din(l), ldh, H, zprev(l), dout(l), ldh, sh.act, lane);
+        __syncthreads();
+        --l;
+        in_a = true;
+      }
+      // ---- layer 0: input gradient (image in B, or in A after an odd number of hidden layers) ----
+      if (dX && sub == 0) {
+        const int lane = opaque(lane_);
+        if (in_a) wset_dgrad_in<HT, SP>(A, din(0), ldh, sh.K_in, dX, ld_dx, lane);
+        else wset_dgrad_in<HT, SP>(B, din(0), ldh, sh.K_in, dX, ld_dx, lane);
+      }
+      __syncthreads();
+    }
+  } else {
+    const float *W = W1 + (L - 2) * (H * H + H);   // layer L-1
+    const float *delta = dY;
+    int ldd = ldy;
+#pragma nounroll
+    for (int l = L - 1; l >= 0; --l) {
+      const int lane = opaque(lane_);
+      const int N = (l == L - 1) ? sh.N_out : H;
+      if (l > 0) {
+        if (N == H) wave_dense_dgrad<CT, 4 * HT>(delta, ldd, N, W + k0 * N, N, 16 * CT, zprev(l), ldh, sh.act, dout(l), ldh, lane);
+        else if (N <= 32) wave_dense_dgrad<CT>(delta, ldd, N, W + k0 * N, N, 16 * CT, zprev(l), ldh, sh.act, dout(l), ldh, lane);
+        else gen_dense_dgrad(delta, ldd, N, W, N, k0, k0 + 16 * CT, zbuf + (l - 1) * T, ldh, sh.act, dout(l) - k0, ldh, lane);
+      } else if (dX && sub == 0) {
+        if (sh.K_in <= 16) wave_dense_dgrad<1, 4 * HT>(delta, ldd, H, W, H, sh.K_in, nullptr, 0, 0, dX, ld_dx, lane);
+        else gen_dense_dgrad(delta, ldd, H, W, H, 0, sh.K_in, nullptr, 0, 0, dX, ld_dx, lane);
+      }
+      __syncthreads();
+      delta = dout(l) - k0;
+      ldd = ldh;
+      W -= (l - 1 == 0) ? (sh.K_in * H + H) : (H * H + H);
+    }
+  }
+#pragma nounroll
+  for (int l = L; l < n_steps; ++l) __syncthreads();
+#undef din
+#undef dout
+#undef zprev
+#undef request
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad runner
+// Walks L-1..0 beside a dgrad runner that shares dY/d0/d1: dW_l, db_l from (h_{l-1} | x, delta_l) into `slab` (flat layout
+// of one net).  Executes n_steps barriers.
+template <int HT, int SP>
+__device__ __forceinline__ void chain_wgrad_run(const NetShape sh, const float *x, int ldx, const float *hbuf, const float *dY, int ldy,
+                                                const float *d0, const float *d1, float *__restrict__ slab, bool accumulate, int ldh,
+                                                int n_steps, int sub, int lane_) {
+  constexpr int H = 16 * HT, CT = HT / SP;
+  const int T = 16 * ldh;
+  const int L = sh.L;
+  float *gW = slab + (sh.K_in * H + H) + (L - 2) * (H * H + H);   // layer L-1
+#pragma nounroll
+  for (int l = L - 1; l >= 0; --l) {
+    const int lane = opaque(lane_);
+    const bool out_layer = (l == L - 1);
+    const int K = (l == 0) ? sh.K_in : H, N = out_layer ? sh.N_out : H;
+    const float *delta = out_layer ? dY : (((l + 1) & 1) ? d1 : d0);
+    const int ldd = out_layer ? ldy : ldh;
+    const float *hp = (l == 0) ? x : hbuf + (l - 1) * T;
+    const int ldp = (l == 0) ? ldx : ldh;
+    float *gb = gW + K * N;
+    if (out_layer) {
+      const int k0 = sub * 16 * CT;  // split the H rows of dW over the SP waves
+      if (N <= 16) wave_dense_wgrad<CT, 1>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, lane, accumulate);
+      else gen_dense_wgrad(hp, ldp, k0, k0 + 16 * CT, delta, ldd, 0, N, gW, N, lane, accumulate);
+      if (sub == 0) wave_dense_bgrad(delta, ldd, N, gb, lane, accumulate);
+    } else {
+      const int c0 = sub * 16 * CT;
+      if (l > 0) wave_dense_wgrad<HT, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane, accumulate);
+      else if (K <= 16) wave_dense_wgrad<1, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane, accumulate);
+      else gen_dense_wgrad(hp, ldp, 0, K, delta, ldd, c0, c0 + 16 * CT, gW, N, lane, accumulate);
+      wave_dense_bgrad(delta + c0, ldd, 16 * CT, gb + c0, lane, accumulate);
+    }
+    __syncthreads();
+    gW -= (l - 1 == 0) ? (sh.K_in * H + H) : (H * H + H);
+  }
+#pragma nounroll
+  for (int l = L; l < n_steps; ++l) __syncthreads();
+}
+
+__device__ __forceinline__ void chain_idle_run(int n_steps) {
+#pragma nounroll
+  for (int l = 0; l < n_steps; ++l) __syncthreads();
+}

@@ -12,13 +12,14 @@
 // Algorithmic work per sample per sgd_step: 2*(5P + 12Q) FLOP — latency-bound at B=256, hence the
 // few fat launches and the slab scheme instead of a tree of small kernels.
 #include "common.hpp"
-#include "wave_mlp.hpp"
+#include "chain_run.hpp"
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
 #define LOG_2 0.69314718055994530942f
 
 struct SacArgs {
   MlpDev pi, q, qt;
+  NetShape sh_pi, sh_q;
   int X, U, B, D;
   const float *batch, *norm_mean, *norm_std, *log_alpha;
   const float *noise_alpha, *noise_critic, *noise_actor;
@@ -27,7 +28,24 @@ struct SacArgs {
   float discounting, reward_scaling, target_entropy;
   float *slab_pi, *slab_q, *slab_ex;
   int ld_x, ld_xu, ld_h, ld_y, LH;
+  unsigned long long *stamps;   // measurement hook (mbpo_debug_set_stamps): [2 roles][16] s_memtime values of tile 0, or NULL
 };
+
+// Timeline stamps for DESIGN.md's phase breakdown: one s_memtime per phase boundary, written by thread 0 of tile 0.
+#define SAC_STAMP(i)                                                                   \
+  if (A.stamps && tile == 0 && tid == 0) {                                             \
+    unsigned long long t_;                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+    A.stamps[role * 16 + (i)] = t_;                                                    \
+  }
+
+static unsigned long long *g_sac_stamps = nullptr;
+// Measurement hook (not part of include/mbpo_hip.h): device buffer of >= 32 uint64 that k_sac_fwd_bwd fills with
+// s_memtime stamps at its phase boundaries (tile 0, both roles); NULL switches the stamps off.
+extern "C" int mbpo_debug_set_stamps(void *buf) {
+  g_sac_stamps = (unsigned long long *)buf;
+  return MBPO_OK;
+}
 
 // per action-dim pieces of NormalTanh (sac/parametric_distribution.py:66-73,117-120)
 struct ActSample {
@@ -57,12 +75,12 @@ __device__ __forceinline__ ActSample normal_tanh_sample(float loc, float raw, fl
 //   P3  per layer: c0/c1: Q1/Q2 dgrad               P3  per layer: c0/c1: Q1/Q2 input-gradient
 //                  c2/c3: Q1/Q2 wgrad               -- dL/dlogits
 //                                                   P4  per layer: c0: pi dgrad   c1: pi wgrad
-template <int H>
-__global__ void __launch_bounds__(512) k_sac_fwd_bwd(SacArgs A) {
+template <int H, int SP>   // SP = waves per chain: 4 chains x SP waves
+__global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
-  constexpr int SP = 2;   // waves per chain: 4 chains x 2 waves = 8 waves (512 threads keep 256 VGPRs per wave)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int tid_ = threadIdx.x, nthreads = 256 * SP;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   const int chain = wave / SP, sub = wave % SP;
   const int role = blockIdx.x & 1;  // 0 = critic, 1 = actor(+alpha)
   const int tile = blockIdx.x >> 1;
@@ -92,6 +110,10 @@ __global__ void __launch_bounds__(512) k_sac_fwd_bwd(SacArgs A) {
   float *s_lpa = s_lp + U4;
   float *s_scal = s_lpa + U4;               // [4][16]
 
+  {
+    const int tid = tid_;
+    SAC_STAMP(0);
+  }
   const float alpha = expf(A.log_alpha[0]);
   const float invB = 1.0f / (float)B;
   const unsigned long long rng_off = A.offset + (unsigned long long)A.step_count[0];
@@ -100,236 +122,234 @@ __global__ void __launch_bounds__(512) k_sac_fwd_bwd(SacArgs A) {
   const int QL = A.q.n_layers, PL = A.pi.n_layers;
   const int Lmax = QL > PL ? QL : PL;
   float *y_pi = s_y, *y_q1 = s_y + 16 * ld_y, *y_q2 = s_y + 2 * 16 * ld_y;
+  // stored activations.  critic role: Q1 (z,h), Q2 (z,h);  actor role: policy (z,h), Q1 z, Q2 z
+  const int o_sn = (int)(s_sn - smem), o_sn2 = (int)(s_sn2 - smem), o_qin = (int)(s_qin - smem), o_qin2 = (int)(s_qin2 - smem);
+  const int o_pp = (int)(s_pp - smem), o_y = (int)(s_y - smem), o_dy = (int)(s_dy - smem), o_dx = (int)(s_dx - smem);
+  const int o_st0 = (int)(s_store - smem), o_st1 = o_st0 + LH * T, o_st2 = o_st0 + 2 * LH * T, o_st3 = o_st0 + 3 * LH * T;
 
-  // ---- load the tile's transitions; normalise observations (q and policy both preprocess obs: sac/networks.py:76-78,96-98)
-  for (int idx = tid; idx < 16 * D; idx += nthreads) {
-    int r = idx / D, c = idx - r * D;
-    s_row[r * D4 + c] = (row0 + r < B) ? A.batch[(long long)(row0 + r) * D + c] : 0.f;
-  }
-  __syncthreads();
-  for (int idx = tid; idx < 16 * X; idx += nthreads) {
-    int r = idx / X, c = idx - r * X;
-    float o = s_row[r * D4 + c], o2 = s_row[r * D4 + X + U + 2 + c];
-    if (A.norm_mean) {
-      o = (o - A.norm_mean[c]) / A.norm_std[c];
-      o2 = (o2 - A.norm_mean[c]) / A.norm_std[c];
+  // Phases (one barrier per layer step inside a phase, one after each elementwise section E):
+  //   critic role:  E load | F0: c0 pi(s') fwd, c1/c2 Q1/Q2(s,a) fwd | E sample a' | F1: c0/c1 Qtgt1/2(s',a') fwd | E targets
+  //                 | B2: c0/c1 Q1/Q2 dgrad, c2/c3 Q1/Q2 wgrad | E loss partials
+  //   actor role:   E load | F0: c0 pi(s) fwd | E sample a | F1: c0/c1 Q1/Q2(s,a) fwd | E dL/dq | B2: c0/c1 Q input-grad
+  //                 | E dL/dlogits | B3: c0 pi dgrad, c1 pi wgrad | E loss partials
+  // What this wave walks in the current phase (wave-uniform scalars; LDS operands as offsets from smem, -1 = none).
+  WSet<HT, SP> R;
+  int mode = CH_IDLE, netid = 0;
+  const float *cparams = pi_p;
+  float *cslab = nullptr;
+  int cx = -1, cldx = ld_x, cpp0 = -1, cpp1 = -1, czb = -1, chb = -1, cy = -1, cdx = -1;
+#define P(off) ((off) < 0 ? (float *)nullptr : smem + (off))
+  const int nph = role == 0 ? 3 : 4;
+#pragma nounroll
+  for (int ph = -1; ph < nph; ++ph) {
+    const int tid = opaque(tid_), lane = tid & 63;   // keeps per-lane addresses of all phases from being hoisted and spilled
+    if (ph >= 0) {
+      const int len = (role == 0) ? (ph == 0 ? Lmax : QL) : ((ph == 0 || ph == 3) ? PL : QL);
+      const NetShape sh = netid == 0 ? A.sh_pi : A.sh_q;
+      if (mode == CH_FWD)
+        chain_fwd_run<HT, SP>(sh, cparams, P(cx), cldx, P(cpp0), P(cpp1), P(czb), P(chb), P(cy), ld_y, ld_h, len, sub, lane, R,
+                              (A.stamps && tile == 0 && role == 1 && ph == 0 && wave == 0) ? A.stamps + 40 : nullptr);
+      else if (mode == CH_DGRAD)
+        chain_dgrad_run<HT, SP>(sh, cparams, P(cy), ld_y, P(czb), P(cpp0), P(cpp1), P(cdx), ld_xu, ld_h, len, sub, lane, R);
+      else if (mode == CH_WGRAD)
+        chain_wgrad_run<HT, SP>(sh, P(cx), cldx, P(chb), P(cy), ld_y, P(cpp0), P(cpp1), cslab, false, ld_h, len, sub, lane);
+      else
+        chain_idle_run(len);
     }
-    s_sn[r * ld_x + c] = o;
-    s_sn2[r * ld_x + c] = o2;
-    s_qin[r * ld_xu + c] = o;
-    s_qin2[r * ld_xu + c] = o2;
-  }
-  if (role == 0) {
-    for (int idx = tid; idx < 16 * U; idx += nthreads) {
-      int r = idx / U, d = idx - r * U;
-      s_qin[r * ld_xu + X + d] = s_row[r * D4 + X + d];  // transitions.action
-    }
-  }
-  __syncthreads();
-
-  if (role == 0) {
-    // ============================== CRITIC (sac/losses.py:74-110) ==============================
-    float *z1 = s_store, *h1 = s_store + LH * T, *z2 = s_store + 2 * LH * T, *h2 = s_store + 3 * LH * T;
-    // P1: next_dist_params = policy(next_observation) (:80-81)  ||  q_old_action = q(q_params, obs, action) (:78-79)
+    SAC_STAMP(2 * ph + 3);
+    // ---- the chain this wave walks in the NEXT phase; its first layer's weights are requested now ----
     {
-      FwdChain fc;
-      if (chain == 0) fc = FwdChain{&A.pi, pi_p, s_sn2, ld_x, s_pp, s_pp + T, nullptr, nullptr, y_pi};
-      else if (chain == 1) fc = FwdChain{&A.q, q1_p, s_qin, ld_xu, nullptr, nullptr, z1, h1, y_q1};
-      else fc = FwdChain{&A.q, q2_p, s_qin, ld_xu, nullptr, nullptr, z2, h2, y_q2};
-      for (int l = 0; l < Lmax; ++l) {
-        if (chain < 3) group_fwd_step<HT, SP>(fc, l, ld_h, ld_y, sub, lane);
-        __syncthreads();
-      }
-    }
-    // next_action ~ ; next_log_prob (:82-87)
-    for (int idx = tid; idx < 16 * U; idx += nthreads) {
-      int r = idx / U, d = idx - r * U;
-      long long nidx = (long long)(row0 + r) * U + d;
-      float eps = 0.f;
-      if (row0 + r < B)
-        eps = A.noise_critic ? A.noise_critic[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_CRITIC, (unsigned long long)nidx);
-      ActSample sm = normal_tanh_sample(y_pi[r * ld_y + d], y_pi[r * ld_y + U + d], eps);
-      s_qin2[r * ld_xu + X + d] = sm.a;  // postprocess(next_action)
-      s_lp[idx] = sm.lp;
-    }
-    if (tid < 32) {  // keep q_old_action out of the way of P2's outputs
-      const int k = tid >> 4, r = tid & 15;
-      s_scal[32 + tid] = (k == 0 ? y_q1 : y_q2)[r * ld_y];
-    }
-    __syncthreads();
-    // P2: next_q = q(target_q_params, next_observation, next_action) (:88-89)
-    {
-      FwdChain fc;
-      if (chain == 0) fc = FwdChain{&A.qt, t1_p, s_qin2, ld_xu, s_pp, s_pp + T, nullptr, nullptr, y_q1};
-      else fc = FwdChain{&A.qt, t2_p, s_qin2, ld_xu, s_pp + 2 * T, s_pp + 3 * T, nullptr, nullptr, y_q2};
-      for (int l = 0; l < QL; ++l) {
-        if (chain < 2) group_fwd_step<HT, SP>(fc, l, ld_h, ld_y, sub, lane);
-        __syncthreads();
-      }
-    }
-    if (tid < 32) {
-      const int k = tid >> 4, r = tid & 15;
-      const bool ok = row0 + r < B;
-      float nlp = 0.f;
-      for (int d = 0; d < U; ++d) nlp += s_lp[r * U + d];
-      const float nq = fminf(y_q1[r * ld_y], y_q2[r * ld_y]);
-      const float next_v = nq - alpha * nlp;                                                   // :89
-      const float rew = s_row[r * D4 + X + U], disc = s_row[r * D4 + X + U + 1];
-      const float target = rew * A.reward_scaling + disc * A.discounting * next_v;             // :101-103
-      const float trunc = s_row[r * D4 + D - 1];
-      const float err = ok ? (s_scal[32 + tid] - target) * (1.f - trunc) : 0.f;               // q_error :104-108
-      s_scal[tid] = err * err;
-      // loss = 0.5*mean(err^2) over [B,2]  ->  dL/dq = err*(1-trunc)/(2B)
-      s_dy[(k * 16 + r) * ld_y] = err * (1.f - trunc) * (0.5f * invB);
-    }
-    __syncthreads();
-    // P3: backward through both critics, one layer per barrier: chains 0/1 push delta down, chains 2/3 form dW/db
-    float *slab = A.slab_q + (long long)tile * (2 * A.q.n_params);
-    {
+      const int nx = ph + 1;
+      mode = CH_IDLE;
+      czb = chb = cdx = cpp0 = cpp1 = -1;
       const int net = chain & 1;
-      const float *qp = net ? q2_p : q1_p;
-      const float *zb = net ? z2 : z1, *hb = net ? h2 : h1;
-      float *d0 = s_pp + (2 * net) * T, *d1 = d0 + T;
-      const float *dcur = s_dy + net * 16 * ld_y;
-      int ldc = ld_y;
-      for (int l = QL - 1; l >= 0; --l) {
-        float *dn = (l & 1) ? d1 : d0;
-        if (chain < 2) group_bwd_dgrad_layer<HT, SP>(A.q, qp, l, dcur, ldc, zb, ld_h, dn, nullptr, ld_xu, sub, lane);
-        else group_bwd_wgrad_layer<HT, SP>(A.q, l, s_qin, ld_xu, hb, ld_h, dcur, ldc, slab + (long long)net * A.q.net_stride, sub, lane);
-        __syncthreads();
-        dcur = dn;
-        ldc = ld_h;
-      }
-    }
-    if (tid == 0) {
-      float acc = 0.f;
-      for (int i = 0; i < 32; ++i) acc += s_scal[i];
-      A.slab_ex[tile * 4 + 0] = acc;
-    }
-  } else {
-    // ============================== ACTOR + ALPHA (sac/losses.py:61-72, 112-125) ==============================
-    float *zp = s_store, *hp = s_store + LH * T;               // policy: z, h
-    float *zq1 = s_store + 2 * LH * T, *zq2 = s_store + 3 * LH * T;   // critics: z only
-    // P1: dist_params = policy(observation)
-    {
-      FwdChain fc{&A.pi, pi_p, s_sn, ld_x, nullptr, nullptr, zp, hp, y_pi};
-      for (int l = 0; l < PL; ++l) {
-        if (chain == 0) group_fwd_step<HT, SP>(fc, l, ld_h, ld_y, sub, lane);
-        __syncthreads();
-      }
-    }
-    for (int idx = tid; idx < 16 * U; idx += nthreads) {
-      int r = idx / U, d = idx - r * U;
-      long long nidx = (long long)(row0 + r) * U + d;
-      const bool ok = row0 + r < B;
-      const float loc = y_pi[r * ld_y + d], raw = y_pi[r * ld_y + U + d];
-      float e_al = 0.f, e_ac = 0.f;
-      if (ok) {
-        e_al = A.noise_alpha ? A.noise_alpha[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ALPHA, (unsigned long long)nidx);
-        e_ac = A.noise_actor ? A.noise_actor[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ACTOR, (unsigned long long)nidx);
-      }
-      ActSample sal = normal_tanh_sample(loc, raw, e_al);   // alpha loss sample (:66-68)
-      ActSample sac = normal_tanh_sample(loc, raw, e_ac);   // actor loss sample (:117-119)
-      s_lp[idx] = sac.lp;
-      s_lpa[idx] = sal.lp;
-      s_eps[idx] = e_ac;
-      s_a[idx] = sac.a;
-      s_sig[idx] = sac.sigma;
-      s_raw[idx] = raw;
-      s_qin[r * ld_xu + X + d] = sac.a;  // postprocess(action) (:120)
-    }
-    __syncthreads();
-    // P2: q_action = q(q_params, observation, action) with the OLD q_params (sac.py:253)   (:121-122)
-    {
-      FwdChain fc;
-      if (chain == 0) fc = FwdChain{&A.q, q1_p, s_qin, ld_xu, s_pp, s_pp + T, zq1, nullptr, y_q1};
-      else fc = FwdChain{&A.q, q2_p, s_qin, ld_xu, s_pp + 2 * T, s_pp + 3 * T, zq2, nullptr, y_q2};
-      if (wave == 4 && lane < 16) {
-        const int r = lane;
-        const bool ok = row0 + r < B;
-        float lp_al = 0.f, lp_ac = 0.f;
-        for (int d = 0; d < U; ++d) {
-          lp_al += s_lpa[r * U + d];
-          lp_ac += s_lp[r * U + d];
+      if (role == 0) {
+        if (nx == 0 && chain < 3) {
+          mode = CH_FWD;
+          if (chain == 0) {
+            netid = 0; cparams = pi_p; cx = o_sn2; cldx = ld_x; cpp0 = o_pp; cpp1 = o_pp + T; cy = o_y;
+          } else {
+            netid = 1; cparams = chain == 1 ? q1_p : q2_p; cx = o_qin; cldx = ld_xu;
+            czb = chain == 1 ? o_st0 : o_st2; chb = chain == 1 ? o_st1 : o_st3; cy = o_y + (chain == 1 ? 1 : 2) * 16 * ld_y;
+          }
+        } else if (nx == 1 && chain < 2) {
+          mode = CH_FWD;
+          netid = 1; cparams = chain == 0 ? t1_p : t2_p; cx = o_qin2; cldx = ld_xu;
+          cpp0 = o_pp + 2 * chain * T; cpp1 = cpp0 + T; cy = o_y + (chain + 1) * 16 * ld_y;
+        } else if (nx == 2) {
+          mode = chain < 2 ? CH_DGRAD : CH_WGRAD;
+          netid = 1; cparams = net ? q2_p : q1_p; cx = o_qin; cldx = ld_xu;
+          cpp0 = o_pp + 2 * net * T; cpp1 = cpp0 + T; czb = net ? o_st2 : o_st0; chb = net ? o_st3 : o_st1;
+          cy = o_dy + net * 16 * ld_y;
+          cslab = A.slab_q + (long long)tile * (2 * A.q.n_params) + (long long)net * A.q.net_stride;
         }
-        // alpha_loss = alpha * stop_gradient(-log_prob - target_entropy); d/dlog_alpha = the same value   (:70-72)
-        s_scal[r] = ok ? alpha * (-lp_al - A.target_entropy) : 0.f;
-        s_scal[16 + r] = ok ? lp_ac : 0.f;
+      } else {
+        if (nx == 0 && chain == 0) {
+          mode = CH_FWD;
+          netid = 0; cparams = pi_p; cx = o_sn; cldx = ld_x; czb = o_st0; chb = o_st1; cy = o_y;
+        } else if (nx == 1 && chain < 2) {
+          mode = CH_FWD;
+          netid = 1; cparams = chain == 0 ? q1_p : q2_p; cx = o_qin; cldx = ld_xu;
+          cpp0 = o_pp + 2 * chain * T; cpp1 = cpp0 + T; czb = chain == 0 ? o_st2 : o_st3; cy = o_y + (chain + 1) * 16 * ld_y;
+        } else if (nx == 2 && chain < 2) {
+          mode = CH_DGRAD;
+          netid = 1; cparams = net ? q2_p : q1_p; cpp0 = o_pp + 2 * net * T; cpp1 = cpp0 + T; czb = net ? o_st3 : o_st2;
+          cy = o_dy + net * 16 * ld_y; cdx = o_dx + net * 16 * ld_xu;
+        } else if (nx == 3 && chain < 2) {
+          mode = chain == 0 ? CH_DGRAD : CH_WGRAD;
+          netid = 0; cparams = pi_p; cx = o_sn; cldx = ld_x; cpp0 = o_pp; cpp1 = o_pp + T; czb = o_st0; chb = o_st1;
+          cy = o_dy; cslab = A.slab_pi + (long long)tile * A.pi.n_params;
+        }
       }
-      for (int l = 0; l < QL; ++l) {
-        if (chain < 2) group_fwd_step<HT, SP>(fc, l, ld_h, ld_y, sub, lane);
-        __syncthreads();
-      }
+      const NetShape shn = netid == 0 ? A.sh_pi : A.sh_q;
+      if (mode == CH_FWD) chain_fwd_prefetch<HT, SP>(R, shn, cparams, sub, lane);
+      else if (mode == CH_DGRAD) chain_dgrad_prefetch<HT, SP>(R, shn, cparams, sub, lane);
     }
-    if (tid < 16) {
-      const int r = tid;
-      const bool ok = row0 + r < B;
-      const float q0 = y_q1[r * ld_y], q1 = y_q2[r * ld_y];
-      const float mq = fminf(q0, q1);
-      s_scal[32 + r] = ok ? (alpha * s_scal[16 + r] - mq) : 0.f;   // actor_loss = alpha*log_prob - min_q   (:123-124)
-      // d(mean(-min_q))/dq_k: -1/B on the arg-min critic (ties split evenly, as jnp.min's gradient does)
-      float g0 = 0.f, g1 = 0.f;
-      if (ok) {
-        if (q0 < q1) g0 = -invB;
-        else if (q1 < q0) g1 = -invB;
-        else g0 = g1 = -0.5f * invB;
+    // ---- elementwise section after phase ph ----
+    if (ph == -1) {
+      // load the tile's transitions; normalise observations (q and policy both preprocess obs: sac/networks.py:76-78,96-98).
+      // Every global load of this section is independent: one latency, one barrier.
+      for (int idx = tid; idx < 16 * D; idx += nthreads) {
+        int r = idx / D, cc = idx - r * D;
+        s_row[r * D4 + cc] = (row0 + r < B) ? A.batch[(long long)(row0 + r) * D + cc] : 0.f;
       }
-      s_dy[r * ld_y] = g0;
-      s_dy[(16 + r) * ld_y] = g1;
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        int r = idx / X, cc = idx - r * X;
+        float o = 0.f, o2 = 0.f;
+        if (row0 + r < B) {
+          o = A.batch[(long long)(row0 + r) * D + cc];
+          o2 = A.batch[(long long)(row0 + r) * D + X + U + 2 + cc];
+        }
+        if (A.norm_mean) {
+          const float mu = A.norm_mean[cc], sd = A.norm_std[cc];
+          o = (o - mu) / sd;
+          o2 = (o2 - mu) / sd;
+        }
+        s_sn[r * ld_x + cc] = o;
+        s_sn2[r * ld_x + cc] = o2;
+        s_qin[r * ld_xu + cc] = o;
+        s_qin2[r * ld_xu + cc] = o2;
+      }
+      if (role == 0) {
+        for (int idx = tid; idx < 16 * U; idx += nthreads) {
+          int r = idx / U, d = idx - r * U;
+          s_qin[r * ld_xu + X + d] = (row0 + r < B) ? A.batch[(long long)(row0 + r) * D + X + d] : 0.f;  // transitions.action
+        }
+      }
+    } else if (role == 0) {
+      // ============================== CRITIC (sac/losses.py:74-110) ==============================
+      if (ph == 0) {
+        // next_action ~ policy(next_observation); next_log_prob (:80-87)
+        for (int idx = tid; idx < 16 * U; idx += nthreads) {
+          int r = idx / U, d = idx - r * U;
+          long long nidx = (long long)(row0 + r) * U + d;
+          float eps = 0.f;
+          if (row0 + r < B)
+            eps = A.noise_critic ? A.noise_critic[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_CRITIC, (unsigned long long)nidx);
+          ActSample sm = normal_tanh_sample(y_pi[r * ld_y + d], y_pi[r * ld_y + U + d], eps);
+          s_qin2[r * ld_xu + X + d] = sm.a;  // postprocess(next_action)
+          s_lp[idx] = sm.lp;
+        }
+        if (tid < 32) {  // keep q_old_action (:78-79) out of the way of the target critics' outputs
+          const int k = tid >> 4, r = tid & 15;
+          s_scal[32 + tid] = (k == 0 ? y_q1 : y_q2)[r * ld_y];
+        }
+      } else if (ph == 1) {
+        if (tid < 32) {
+          const int k = tid >> 4, r = tid & 15;
+          const bool ok = row0 + r < B;
+          float nlp = 0.f;
+          for (int d = 0; d < U; ++d) nlp += s_lp[r * U + d];
+          const float nq = fminf(y_q1[r * ld_y], y_q2[r * ld_y]);
+          const float next_v = nq - alpha * nlp;                                                   // :89
+          const float rew = s_row[r * D4 + X + U], disc = s_row[r * D4 + X + U + 1];
+          const float target = rew * A.reward_scaling + disc * A.discounting * next_v;             // :101-103
+          const float trunc = s_row[r * D4 + D - 1];
+          const float err = ok ? (s_scal[32 + tid] - target) * (1.f - trunc) : 0.f;               // q_error :104-108
+          s_scal[tid] = err * err;
+          // loss = 0.5*mean(err^2) over [B,2]  ->  dL/dq = err*(1-trunc)/(2B)
+          s_dy[(k * 16 + r) * ld_y] = err * (1.f - trunc) * (0.5f * invB);
+        }
+      } else {
+        if (tid == 0) {
+          float acc = 0.f;
+          for (int i = 0; i < 32; ++i) acc += s_scal[i];
+          A.slab_ex[tile * 4 + 0] = acc;
+        }
+      }
+    } else {
+      // ============================== ACTOR + ALPHA (sac/losses.py:61-72, 112-125) ==============================
+      if (ph == 0) {
+        for (int idx = tid; idx < 16 * U; idx += nthreads) {
+          int r = idx / U, d = idx - r * U;
+          long long nidx = (long long)(row0 + r) * U + d;
+          const bool ok = row0 + r < B;
+          const float loc = y_pi[r * ld_y + d], raw = y_pi[r * ld_y + U + d];
+          float e_al = 0.f, e_ac = 0.f;
+          if (ok) {
+            e_al = A.noise_alpha ? A.noise_alpha[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ALPHA, (unsigned long long)nidx);
+            e_ac = A.noise_actor ? A.noise_actor[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ACTOR, (unsigned long long)nidx);
+          }
+          ActSample sal = normal_tanh_sample(loc, raw, e_al);   // alpha loss sample (:66-68)
+          ActSample sac = normal_tanh_sample(loc, raw, e_ac);   // actor loss sample (:117-119)
+          s_lp[idx] = sac.lp;
+          s_lpa[idx] = sal.lp;
+          s_eps[idx] = e_ac;
+          s_a[idx] = sac.a;
+          s_sig[idx] = sac.sigma;
+          s_raw[idx] = raw;
+          s_qin[r * ld_xu + X + d] = sac.a;  // postprocess(action) (:120)
+        }
+      } else if (ph == 1) {
+        if (tid < 16) {
+          const int r = tid;
+          const bool ok = row0 + r < B;
+          float lp_al = 0.f, lp_ac = 0.f;
+          for (int d = 0; d < U; ++d) {
+            lp_al += s_lpa[r * U + d];
+            lp_ac += s_lp[r * U + d];
+          }
+          // alpha_loss = alpha * stop_gradient(-log_prob - target_entropy); d/dlog_alpha = the same value   (:70-72)
+          s_scal[r] = ok ? alpha * (-lp_al - A.target_entropy) : 0.f;
+          const float q0 = y_q1[r * ld_y], q1 = y_q2[r * ld_y];
+          const float mq = fminf(q0, q1);
+          s_scal[32 + r] = ok ? (alpha * lp_ac - mq) : 0.f;   // actor_loss = alpha*log_prob - min_q   (:123-124)
+          // d(mean(-min_q))/dq_k: -1/B on the arg-min critic (ties split evenly, as jnp.min's gradient does)
+          float g0 = 0.f, g1 = 0.f;
+          if (ok) {
+            if (q0 < q1) g0 = -invB;
+            else if (q1 < q0) g1 = -invB;
+            else g0 = g1 = -0.5f * invB;
+          }
+          s_dy[r * ld_y] = g0;
+          s_dy[(16 + r) * ld_y] = g1;
+        }
+      } else if (ph == 2) {
+        for (int idx = tid; idx < 16 * U; idx += nthreads) {
+          int r = idx / U, d = idx - r * U;
+          const bool ok = row0 + r < B;
+          const float a = s_a[idx], sg = s_sig[idx], eps = s_eps[idx], raw = s_raw[idx];
+          const float dLda = s_dx[r * ld_xu + X + d] + s_dx[(16 + r) * ld_xu + X + d];
+          // z = loc + sigma*eps;  log_prob = const - log(sigma) - log(1 - tanh(z)^2)  =>  dlp/dz = 2a, dlp/dsigma = -1/sigma
+          const float gz = dLda * (1.f - a * a) + alpha * invB * 2.f * a;
+          const float gsig = gz * eps - alpha * invB / sg;
+          s_dy[r * ld_y + d] = ok ? gz : 0.f;                              // d/dloc
+          s_dy[r * ld_y + U + d] = ok ? gsig * sigmoid_f(raw) : 0.f;       // d/draw = d/dsigma * softplus'(raw)
+        }
+      } else {
+        if (tid == 0) {
+          float al = 0.f, ac = 0.f;
+          for (int i = 0; i < 16; ++i) {
+            al += s_scal[i];
+            ac += s_scal[32 + i];
+          }
+          A.slab_ex[tile * 4 + 1] = ac;
+          A.slab_ex[tile * 4 + 2] = al;
+        }
+      }
     }
     __syncthreads();
-    // P3: backward through the critics: input gradient only (q_params are not the actor's variables)
-    {
-      const int net = chain & 1;
-      const float *qp = net ? q2_p : q1_p;
-      const float *zb = net ? zq2 : zq1;
-      float *d0 = s_pp + (2 * net) * T, *d1 = d0 + T;
-      const float *dcur = s_dy + net * 16 * ld_y;
-      int ldc = ld_y;
-      for (int l = QL - 1; l >= 0; --l) {
-        float *dn = (l & 1) ? d1 : d0;
-        if (chain < 2) group_bwd_dgrad_layer<HT, SP>(A.q, qp, l, dcur, ldc, zb, ld_h, dn, s_dx + net * 16 * ld_xu, ld_xu, sub, lane);
-        __syncthreads();
-        dcur = dn;
-        ldc = ld_h;
-      }
-    }
-    for (int idx = tid; idx < 16 * U; idx += nthreads) {
-      int r = idx / U, d = idx - r * U;
-      const bool ok = row0 + r < B;
-      const float a = s_a[idx], sg = s_sig[idx], eps = s_eps[idx], raw = s_raw[idx];
-      const float dLda = s_dx[r * ld_xu + X + d] + s_dx[(16 + r) * ld_xu + X + d];
-      // z = loc + sigma*eps;  log_prob = const - log(sigma) - log(1 - tanh(z)^2)  =>  dlp/dz = 2a, dlp/dsigma = -1/sigma
-      const float gz = dLda * (1.f - a * a) + alpha * invB * 2.f * a;
-      const float gsig = gz * eps - alpha * invB / sg;
-      s_dy[r * ld_y + d] = ok ? gz : 0.f;                              // d/dloc
-      s_dy[r * ld_y + U + d] = ok ? gsig * sigmoid_f(raw) : 0.f;       // d/draw = d/dsigma * softplus'(raw)
-    }
-    __syncthreads();
-    // P4: backward through the policy, one layer per barrier: chain 0 pushes delta down, chain 1 forms dW/db
-    float *slab = A.slab_pi + (long long)tile * A.pi.n_params;
-    {
-      float *d0 = s_pp, *d1 = s_pp + T;
-      const float *dcur = s_dy;
-      int ldc = ld_y;
-      for (int l = PL - 1; l >= 0; --l) {
-        float *dn = (l & 1) ? d1 : d0;
-        if (chain == 0) group_bwd_dgrad_layer<HT, SP>(A.pi, pi_p, l, dcur, ldc, zp, ld_h, dn, nullptr, ld_x, sub, lane);
-        else if (chain == 1) group_bwd_wgrad_layer<HT, SP>(A.pi, l, s_sn, ld_x, hp, ld_h, dcur, ldc, slab, sub, lane);
-        __syncthreads();
-        dcur = dn;
-        ldc = ld_h;
-      }
-    }
-    if (tid == 0) {
-      float al = 0.f, ac = 0.f;
-      for (int i = 0; i < 16; ++i) {
-        al += s_scal[i];
-        ac += s_scal[32 + i];
-      }
-      A.slab_ex[tile * 4 + 1] = ac;
-      A.slab_ex[tile * 4 + 2] = al;
-    }
+    SAC_STAMP(2 * ph + 4);
   }
 }
 
@@ -544,6 +564,8 @@ extern "C" int64_t mbpo_sac_workspace_floats(const mbpo_sac_desc *d) {
   return pl.total;
 }
 
+constexpr int SP64 = 4;   // waves per chain at hidden width 64
+
 static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream) {
   SacPlan pl;
   int rc = sac_plan(d, &pl, true);
@@ -552,24 +574,27 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream) 
   MBPO_REQUIRE((d->norm_mean == nullptr) == (d->norm_std == nullptr), MBPO_ERR_ARG, "sac_grads: norm_mean/norm_std mismatch");
   SacArgs A;
   A.pi = pl.pi; A.q = pl.q; A.qt = pl.qt;
+  A.sh_pi = NetShape{pl.pi.dims[0], pl.pi.n_layers, pl.pi.dims[pl.pi.n_layers], pl.pi.act};
+  A.sh_q = NetShape{pl.q.dims[0], pl.q.n_layers, pl.q.dims[pl.q.n_layers], pl.q.act};
   A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.D = d->row_len;
   A.batch = d->batch; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std;
   A.log_alpha = d->params + pl.NP - 1;
   A.noise_alpha = d->noise_alpha; A.noise_critic = d->noise_critic; A.noise_actor = d->noise_actor;
   A.seed = d->seed; A.offset = d->offset; A.step_count = d->step_count;
+  A.stamps = g_sac_stamps;
   A.discounting = d->discounting; A.reward_scaling = d->reward_scaling; A.target_entropy = d->target_entropy;
   A.slab_pi = d->workspace + pl.off_slab_pi; A.slab_q = d->workspace + pl.off_slab_q; A.slab_ex = d->workspace + pl.off_slab_ex;
   A.ld_x = pl.ld_x; A.ld_xu = pl.ld_xu; A.ld_h = pl.ld_h; A.ld_y = pl.ld_y; A.LH = pl.LH;
   hipStream_t st = (hipStream_t)stream;
   if (phase_mask & 1) {
     if (pl.H == 64) {
-      rc = mbpo_ensure_lds<k_sac_fwd_bwd<64>>(pl.lds, "sac_grads");
+      rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64>>(pl.lds, "sac_grads");
       if (rc != MBPO_OK) return rc;
-      hipLaunchKernelGGL(k_sac_fwd_bwd<64>, dim3(2 * pl.n_tiles), dim3(512), pl.lds, st, A);
+      hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64>), dim3(2 * pl.n_tiles), dim3(256 * SP64), pl.lds, st, A);
     } else {
-      rc = mbpo_ensure_lds<k_sac_fwd_bwd<128>>(pl.lds, "sac_grads");
+      rc = mbpo_ensure_lds<k_sac_fwd_bwd<128, 2>>(pl.lds, "sac_grads");
       if (rc != MBPO_OK) return rc;
-      hipLaunchKernelGGL(k_sac_fwd_bwd<128>, dim3(2 * pl.n_tiles), dim3(512), pl.lds, st, A);
+      hipLaunchKernelGGL((k_sac_fwd_bwd<128, 2>), dim3(2 * pl.n_tiles), dim3(512), pl.lds, st, A);
     }
   }
   if (!(phase_mask & 2)) {
