@@ -220,6 +220,12 @@ int mbpo_sac_grads(const mbpo_sac_desc *d, void *stream);
 int mbpo_sac_grads_phase(const mbpo_sac_desc *d, int32_t phase_mask, void *stream);
 int mbpo_sac_grad_norms(const mbpo_sac_desc *d, void *stream);
 int mbpo_sac_apply(const mbpo_sac_desc *d, void *stream);
+/* Single-rank one-launch variant (measured SLOWER than grads + apply on MI355X — the device-wide meeting point costs more than
+ * the kernel boundary it removes — kept as an option): after mbpo_sac_grads_phase(d, 1) (the fwd/bwd kernel only), this ONE launch reduces the per-tile
+ * slabs, forms the global norms (device-wide arrival counter inside the kernel; bounded spin, metrics[0] = NaN and no update
+ * if it is not reached) and applies clip + AdamW + Polyak.  Same results as mbpo_sac_grads + mbpo_sac_apply.  The last 4
+ * floats of `workspace` are the counters: they must be zero before the first call (they return to zero by themselves). */
+int mbpo_sac_reduce_apply(const mbpo_sac_desc *d, void *stream);
 
 /* ---- P1-P3: PPO minibatch update (ppo/ppo.py:142-156, ppo/losses.py:56-126) -----------------------
  * replaces: PPO.minibatch_step = value_and_grad(PPOLoss.loss) + optax.adamw(lr, wd) over {policy, value} (ppo.py:128,139-140;

@@ -546,16 +546,115 @@ __device__ __forceinline__ void chain_dgrad_run(const NetShape sh, const float *
 #undef request
 }
 
+// ------------------------------------------------------------------------------------------------ fast weight gradients
+// dW block [16*KT rows][16*NT cols] = A^T . delta over the 16 batch rows, plus (BIAS) db = sum_rows delta through one more
+// MFMA tile whose A operand is the indicator of tile-row 0 (no LDS reduction, no extra reads).
+//   A image: a_src[row*lda + KT*r + a], a < KT (k = KT*rho + a: a lane's KT results for a tile row are consecutive k)
+//   B image: delta[row*ldd + NT*r + b], b < NT (n = NT*j + b)
+// Bounds: k_valid / n_valid columns are real (the rest reads as zero and is not stored).  gW points at the block's first
+// element, row stride ldw.  With `accumulate` the old values are requested before the MFMAs and added at the end.
+template <int KT, int NT, bool BIAS>
+__device__ __forceinline__ void wgrad_tile_fast(const float *a_src, int lda, int k_valid, const float *delta, int ldd, int n_valid,
+                                                float *__restrict__ gW, int ldw, float *__restrict__ gb, int lane, bool accumulate) {
+  const int r = lane & 15, g = lane >> 4;
+  const bool full = (k_valid == 16 * KT) && (n_valid == 16 * NT);
+  f32x4 acc[KT][NT];
+  f32x4 accb[NT];
+#pragma unroll
+  for (int a = 0; a < KT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < NT; ++b) accb[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float old[KT][4][NT];
+  float oldb[NT];
+  if (accumulate) {
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = KT * (4 * g + i) + a;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          const int n = NT * r + b;
+          old[a][i][b] = (k < k_valid && n < n_valid) ? gW[k * ldw + n] : 0.f;
+        }
+      }
+    if (BIAS) {
+#pragma unroll
+      for (int b = 0; b < NT; ++b) oldb[b] = (NT * r + b < n_valid) ? gb[NT * r + b] : 0.f;
+    }
+  }
+  const float one0 = (r == 0) ? 1.f : 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int row = 4 * g + s;
+    float av[KT], bv[NT];
+    if (full) {
+      load_vec_lds<KT>(a_src + row * lda + KT * r, av);
+      load_vec_lds<NT>(delta + row * ldd + NT * r, bv);
+    } else {
+#pragma unroll
+      for (int a = 0; a < KT; ++a) {
+        const int k = KT * r + a;
+        av[a] = a_src[row * lda + (k < k_valid ? k : 0)];
+        av[a] = k < k_valid ? av[a] : 0.f;
+      }
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        const int n = NT * r + b;
+        bv[b] = delta[row * ldd + (n < n_valid ? n : 0)];
+        bv[b] = n < n_valid ? bv[b] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    if (BIAS) {
+#pragma unroll
+      for (int b = 0; b < NT; ++b) accb[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(one0, bv[b], accb[b], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < KT; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = KT * (4 * g + i) + a;
+      float ov[NT];
+#pragma unroll
+      for (int b = 0; b < NT; ++b) ov[b] = acc[a][b][i] + (accumulate ? old[a][i][b] : 0.f);
+      if (full) {
+        store_vec_global<NT>(gW + k * ldw + NT * r, ov);
+      } else if (k < k_valid) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+          if (NT * r + b < n_valid) gW[k * ldw + NT * r + b] = ov[b];
+      }
+    }
+  if (BIAS && g == 0) {
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+      if (NT * r + b < n_valid) gb[NT * r + b] = accb[b][0] + (accumulate ? oldb[b] : 0.f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ wgrad runner
 // Walks L-1..0 beside a dgrad runner that shares dY/d0/d1: dW_l, db_l from (h_{l-1} | x, delta_l) into `slab` (flat layout
 // of one net).  Executes n_steps barriers.
 template <int HT, int SP>
 __device__ __forceinline__ void chain_wgrad_run(const NetShape sh, const float *x, int ldx, const float *hbuf, const float *dY, int ldy,
                                                 const float *d0, const float *d1, float *__restrict__ slab, bool accumulate, int ldh,
-                                                int n_steps, int sub, int lane_) {
+                                                int n_steps, int sub, int lane_, unsigned long long *dbg = nullptr) {
   constexpr int H = 16 * HT, CT = HT / SP;
   const int T = 16 * ldh;
   const int L = sh.L;
+#define DBG_STAMP(i)                                                                 \
+  if (dbg && lane_ == 0) {                                                           \
+    unsigned long long t_;                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+    dbg[i] = t_;                                                                     \
+  }
   float *gW = slab + (sh.K_in * H + H) + (L - 2) * (H * H + H);   // layer L-1
 #pragma nounroll
   for (int l = L - 1; l >= 0; --l) {
@@ -567,25 +666,38 @@ __device__ __forceinline__ void chain_wgrad_run(const NetShape sh, const float *
     const float *hp = (l == 0) ? x : hbuf + (l - 1) * T;
     const int ldp = (l == 0) ? ldx : ldh;
     float *gb = gW + K * N;
+    if (l == L - 2) { DBG_STAMP(0); }
     if (out_layer) {
-      const int k0 = sub * 16 * CT;  // split the H rows of dW over the SP waves
-      if (N <= 16) wave_dense_wgrad<CT, 1>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, lane, accumulate);
-      else gen_dense_wgrad(hp, ldp, k0, k0 + 16 * CT, delta, ldd, 0, N, gW, N, lane, accumulate);
-      if (sub == 0) wave_dense_bgrad(delta, ldd, N, gb, lane, accumulate);
+      const int k0 = sub * 16 * CT;  // split the H rows of dW over the SP waves; wave 0 also forms db
+      if (N <= 16) {
+        if (sub == 0) wgrad_tile_fast<CT, 1, true>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, gb, lane, accumulate);
+        else wgrad_tile_fast<CT, 1, false>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, gb, lane, accumulate);
+      } else {
+        gen_dense_wgrad(hp, ldp, k0, k0 + 16 * CT, delta, ldd, 0, N, gW, N, lane, accumulate);
+        if (sub == 0) wave_dense_bgrad(delta, ldd, N, gb, lane, accumulate);
+      }
     } else {
       const int c0 = sub * 16 * CT;
-      if (l > 0) wave_dense_wgrad<HT, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane, accumulate);
-      else if (K <= 16) wave_dense_wgrad<1, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane, accumulate);
-      else gen_dense_wgrad(hp, ldp, 0, K, delta, ldd, c0, c0 + 16 * CT, gW, N, lane, accumulate);
-      wave_dense_bgrad(delta + c0, ldd, 16 * CT, gb + c0, lane, accumulate);
+      if (l > 0) {
+        wgrad_tile_fast<HT, CT, true>(hp, ldp, H, delta + c0, ldd, 16 * CT, gW + c0, N, gb + c0, lane, accumulate);
+      } else if (K <= 16) {
+        wgrad_tile_fast<1, CT, true>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, gb + c0, lane, accumulate);
+      } else {
+        gen_dense_wgrad(hp, ldp, 0, K, delta, ldd, c0, c0 + 16 * CT, gW, N, lane, accumulate);
+        wave_dense_bgrad(delta + c0, ldd, 16 * CT, gb + c0, lane, accumulate);
+      }
+      if (l == L - 2) { DBG_STAMP(1); }
     }
+    if (l == L - 2) { DBG_STAMP(2); }
     __syncthreads();
+    if (l == L - 2) { DBG_STAMP(3); }
     gW -= (l - 1 == 0) ? (sh.K_in * H + H) : (H * H + H);
   }
 #pragma nounroll
   for (int l = L; l < n_steps; ++l) __syncthreads();
 }
 
+#undef DBG_STAMP
 __device__ __forceinline__ void chain_idle_run(int n_steps) {
 #pragma nounroll
   for (int l = 0; l < n_steps; ++l) __syncthreads();

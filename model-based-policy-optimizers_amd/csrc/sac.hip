@@ -51,14 +51,24 @@ extern "C" int mbpo_debug_set_stamps(void *buf) {
 struct ActSample {
   float z, a, sigma, lp;
 };
+// The elementwise sections run on ONE wave while 15 wait at the barrier, and a lone wave issues one instruction per 4 cycles:
+// libm's expf/log1pf/tanhf/logf (~30-60 instructions each) made one sample cost ~1400 cycles.  These forms use the hardware
+// v_exp_f32 / v_log_f32 / v_rcp_f32 (~1 ulp each); absolute errors stay ~1e-7, far inside the parity tolerances.
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(1.44269504088896340736f * x); }
+__device__ __forceinline__ float flog(float x) { return 0.69314718055994530942f * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fsoftplus(float x) { return fmaxf(x, 0.0f) + flog(1.0f + fexp(-fabsf(x))); }
+__device__ __forceinline__ float ftanh(float x) {
+  const float e = fexp(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
+  return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+}
 __device__ __forceinline__ ActSample normal_tanh_sample(float loc, float raw, float eps) {
   ActSample o;
-  o.sigma = softplus_f(raw) + 0.001f;
+  o.sigma = fsoftplus(raw) + 0.001f;
   o.z = loc + o.sigma * eps;
-  o.a = tanhf(o.z);
+  o.a = ftanh(o.z);
   // log N(z; loc, sigma) with (z-loc)/sigma == eps, minus Tanh.forward_log_det_jacobian(z)
-  const float ldj = 2.0f * (LOG_2 - o.z - softplus_f(-2.0f * o.z));
-  o.lp = -0.5f * eps * eps - logf(o.sigma) - LOG_SQRT_2PI - ldj;
+  const float ldj = 2.0f * (LOG_2 - o.z - fsoftplus(-2.0f * o.z));
+  o.lp = -0.5f * eps * eps - flog(o.sigma) - LOG_SQRT_2PI - ldj;
   return o;
 }
 
@@ -90,9 +100,9 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
   const int T = 16 * ld_h;  // one hidden tile
 
   // ---- LDS carve (every region a multiple of 4 floats: rows stay 16-byte aligned) ----
-  float *s_row = smem;                      // [16][D4]
-  const int D4 = (D + 3) & ~3;
-  float *s_sn = s_row + 16 * D4;            // [16][ld_x]   normalised obs
+  float *s_row = smem;                      // [16][D] (flat copy of the tile's transitions)
+  const int D4 = D;
+  float *s_sn = s_row + 16 * ((D + 3) & ~3);  // [16][ld_x]   normalised obs
   float *s_sn2 = s_sn + 16 * ld_x;          // [16][ld_x]   normalised next obs
   float *s_qin = s_sn2 + 16 * ld_x;         // [16][ld_xu]  [sn, a]
   float *s_qin2 = s_qin + 16 * ld_xu;       // [16][ld_xu]  [s'n, a']
@@ -114,9 +124,10 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
     const int tid = tid_;
     SAC_STAMP(0);
   }
-  const float alpha = expf(A.log_alpha[0]);
+  // requested now, consumed after the first layer phase: the two scalar loads overlap the tile load instead of preceding it
+  const float log_alpha_v = A.log_alpha[0];
+  const float step_count_v = A.step_count[0];
   const float invB = 1.0f / (float)B;
-  const unsigned long long rng_off = A.offset + (unsigned long long)A.step_count[0];
   const float *pi_p = A.pi.params, *q1_p = A.q.params, *q2_p = A.q.params + A.q.net_stride;
   const float *t1_p = A.qt.params, *t2_p = A.qt.params + A.qt.net_stride;
   const int QL = A.q.n_layers, PL = A.pi.n_layers;
@@ -152,7 +163,8 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
       else if (mode == CH_DGRAD)
         chain_dgrad_run<HT, SP>(sh, cparams, P(cy), ld_y, P(czb), P(cpp0), P(cpp1), P(cdx), ld_xu, ld_h, len, sub, lane, R);
       else if (mode == CH_WGRAD)
-        chain_wgrad_run<HT, SP>(sh, P(cx), cldx, P(chb), P(cy), ld_y, P(cpp0), P(cpp1), cslab, false, ld_h, len, sub, lane);
+        chain_wgrad_run<HT, SP>(sh, P(cx), cldx, P(chb), P(cy), ld_y, P(cpp0), P(cpp1), cslab, false, ld_h, len, sub, lane,
+                                (A.stamps && tile == 0 && role == 0 && sub == 0 && chain == 2) ? A.stamps + 48 : nullptr);
       else
         chain_idle_run(len);
     }
@@ -209,12 +221,10 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
     if (ph == -1) {
       // load the tile's transitions; normalise observations (q and policy both preprocess obs: sac/networks.py:76-78,96-98).
       // Every global load of this section is independent: one latency, one barrier.
-      for (int idx = tid; idx < 16 * D; idx += nthreads) {
-        int r = idx / D, cc = idx - r * D;
-        s_row[r * D4 + cc] = (row0 + r < B) ? A.batch[(long long)(row0 + r) * D + cc] : 0.f;
-      }
+      const long long nvalid = (long long)(B - row0 < 16 ? B - row0 : 16) * D;
+      for (int idx = tid; idx < 16 * D; idx += nthreads) s_row[idx] = idx < nvalid ? A.batch[(long long)row0 * D + idx] : 0.f;
       for (int idx = tid; idx < 16 * X; idx += nthreads) {
-        int r = idx / X, cc = idx - r * X;
+        const int r = idx & 15, cc = idx >> 4;
         float o = 0.f, o2 = 0.f;
         if (row0 + r < B) {
           o = A.batch[(long long)(row0 + r) * D + cc];
@@ -232,16 +242,20 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
       }
       if (role == 0) {
         for (int idx = tid; idx < 16 * U; idx += nthreads) {
-          int r = idx / U, d = idx - r * U;
+          const int r = idx & 15, d = idx >> 4;
           s_qin[r * ld_xu + X + d] = (row0 + r < B) ? A.batch[(long long)(row0 + r) * D + X + d] : 0.f;  // transitions.action
         }
       }
+    }
+    const float alpha = expf(log_alpha_v);
+    const unsigned long long rng_off = A.offset + (unsigned long long)step_count_v;
+    if (ph == -1) {
     } else if (role == 0) {
       // ============================== CRITIC (sac/losses.py:74-110) ==============================
       if (ph == 0) {
         // next_action ~ policy(next_observation); next_log_prob (:80-87)
-        for (int idx = tid; idx < 16 * U; idx += nthreads) {
-          int r = idx / U, d = idx - r * U;
+        for (int i2 = tid; i2 < 16 * U; i2 += nthreads) {
+          const int r = i2 & 15, d = i2 >> 4, idx = r * U + d;
           long long nidx = (long long)(row0 + r) * U + d;
           float eps = 0.f;
           if (row0 + r < B)
@@ -280,25 +294,31 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
     } else {
       // ============================== ACTOR + ALPHA (sac/losses.py:61-72, 112-125) ==============================
       if (ph == 0) {
-        for (int idx = tid; idx < 16 * U; idx += nthreads) {
-          int r = idx / U, d = idx - r * U;
+        // two independent samples per element: the first half of the workgroup draws the actor-loss sample, the second half
+        // the alpha-loss sample (different waves: the two instruction streams run side by side)
+        const int half = nthreads / 2;
+        const bool second = tid >= half;
+        for (int i2 = second ? tid - half : tid; i2 < 16 * U; i2 += half) {
+          const int r = i2 & 15, d = i2 >> 4, idx = r * U + d;
           long long nidx = (long long)(row0 + r) * U + d;
           const bool ok = row0 + r < B;
           const float loc = y_pi[r * ld_y + d], raw = y_pi[r * ld_y + U + d];
-          float e_al = 0.f, e_ac = 0.f;
-          if (ok) {
-            e_al = A.noise_alpha ? A.noise_alpha[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ALPHA, (unsigned long long)nidx);
-            e_ac = A.noise_actor ? A.noise_actor[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ACTOR, (unsigned long long)nidx);
+          if (second) {
+            float e_al = 0.f;
+            if (ok) e_al = A.noise_alpha ? A.noise_alpha[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ALPHA, (unsigned long long)nidx);
+            ActSample sal = normal_tanh_sample(loc, raw, e_al);   // alpha loss sample (:66-68)
+            s_lpa[idx] = sal.lp;
+          } else {
+            float e_ac = 0.f;
+            if (ok) e_ac = A.noise_actor ? A.noise_actor[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ACTOR, (unsigned long long)nidx);
+            ActSample sac = normal_tanh_sample(loc, raw, e_ac);   // actor loss sample (:117-119)
+            s_lp[idx] = sac.lp;
+            s_eps[idx] = e_ac;
+            s_a[idx] = sac.a;
+            s_sig[idx] = sac.sigma;
+            s_raw[idx] = raw;
+            s_qin[r * ld_xu + X + d] = sac.a;  // postprocess(action) (:120)
           }
-          ActSample sal = normal_tanh_sample(loc, raw, e_al);   // alpha loss sample (:66-68)
-          ActSample sac = normal_tanh_sample(loc, raw, e_ac);   // actor loss sample (:117-119)
-          s_lp[idx] = sac.lp;
-          s_lpa[idx] = sal.lp;
-          s_eps[idx] = e_ac;
-          s_a[idx] = sac.a;
-          s_sig[idx] = sac.sigma;
-          s_raw[idx] = raw;
-          s_qin[r * ld_xu + X + d] = sac.a;  // postprocess(action) (:120)
         }
       } else if (ph == 1) {
         if (tid < 16) {
@@ -325,8 +345,8 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
           s_dy[(16 + r) * ld_y] = g1;
         }
       } else if (ph == 2) {
-        for (int idx = tid; idx < 16 * U; idx += nthreads) {
-          int r = idx / U, d = idx - r * U;
+        for (int i2 = tid; i2 < 16 * U; i2 += nthreads) {
+          const int r = i2 & 15, d = i2 >> 4, idx = r * U + d;
           const bool ok = row0 + r < B;
           const float a = s_a[idx], sg = s_sig[idx], eps = s_eps[idx], raw = s_raw[idx];
           const float dLda = s_dx[r * ld_xu + X + d] + s_dx[(16 + r) * ld_xu + X + d];
@@ -334,7 +354,7 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
           const float gz = dLda * (1.f - a * a) + alpha * invB * 2.f * a;
           const float gsig = gz * eps - alpha * invB / sg;
           s_dy[r * ld_y + d] = ok ? gz : 0.f;                              // d/dloc
-          s_dy[r * ld_y + U + d] = ok ? gsig * sigmoid_f(raw) : 0.f;       // d/draw = d/dsigma * softplus'(raw)
+          s_dy[r * ld_y + U + d] = ok ? gsig * fast_sigmoid(raw) : 0.f;    // d/draw = d/dsigma * softplus'(raw)
         }
       } else {
         if (tid == 0) {
@@ -477,13 +497,129 @@ __global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+
+// ------------------------------------------------------------------------------------------------
+// Single-rank fast path: k_sac_reduce + k_sac_apply in ONE launch (a kernel boundary costs ~4.5 us here, the two kernels'
+// work ~2 us).  The global gradient norms need every block's partial before any block applies, so the blocks meet at a
+// device-scope arrival counter (all n_red <= ~1000 blocks of 256 threads are co-resident on 256 CUs).  The spin is bounded:
+// if the barrier is not reached the update is skipped and metrics[0] is set to NaN instead of hanging the GPU.
+struct SacFusedArgs {
+  SacReduceArgs R;
+  SacApplyArgs Ap;
+  unsigned int *sync;   // [0] arrivals at the norm barrier, [1] arrivals at the end (both return to 0)
+  float *step_count;
+};
+
+__global__ void __launch_bounds__(256) k_sac_reduce_apply(SacFusedArgs F) {
+  __shared__ float s_scale[3];
+  __shared__ int s_ok;
+  const SacReduceArgs &A = F.R;
+  const SacApplyArgs &Ap = F.Ap;
+  const int tid = threadIdx.x;
+  const int NP = A.P + A.Q2 + 1;
+  const int i = blockIdx.x * 256 + tid;
+  const int nblocks = gridDim.x;
+  const float count = F.step_count[0] + 1.0f;   // every block reads the old count before it arrives anywhere
+  float g = 0.f;
+  if (i < A.P) {
+    for (int t = 0; t < A.n_tiles; ++t) g += A.slab_pi[(long long)t * A.P + i];
+  } else if (i < A.P + A.Q2) {
+    const int j = i - A.P;
+    for (int t = 0; t < A.n_tiles; ++t) g += A.slab_q[(long long)t * A.Q2 + j];
+  } else if (i == NP - 1) {
+    float ce = 0.f, ac = 0.f, al = 0.f;
+    for (int t = 0; t < A.n_tiles; ++t) {
+      ce += A.slab_ex[t * 4 + 0];
+      ac += A.slab_ex[t * 4 + 1];
+      al += A.slab_ex[t * 4 + 2];
+    }
+    const float invB = 1.0f / (float)A.B;
+    g = al * invB;
+    A.metrics[0] = 0.5f * ce * (0.5f * invB);
+    A.metrics[1] = ac * invB;
+    A.metrics[2] = al * invB;
+    if (A.metrics_accum) {
+      A.metrics_accum[0] += A.metrics[0];
+      A.metrics_accum[1] += A.metrics[1];
+      A.metrics_accum[2] += A.metrics[2];
+      A.metrics_accum[4] += 1.0f;
+    }
+  }
+  if (i < NP) A.grads[i] = g;
+  group_sumsq(g, i, A.P, A.Q2, NP, A.ss_part);   // writes this block's three partials (ends in a __syncthreads + store by tid < 3)
+  __syncthreads();
+  // ---- device-wide meeting point ----
+  if (tid == 0) {
+    __threadfence();                                                               // partials visible device-wide
+    __hip_atomic_fetch_add(&F.sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+      if (__hip_atomic_load(&F.sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)nblocks) {
+        ok = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __threadfence();
+    s_ok = ok;
+  }
+  __syncthreads();
+  const bool ok = s_ok != 0;
+  {
+    const int w = tid >> 6, lane = tid & 63;
+    if (w < 3) {
+      float ss = 0.f;
+      for (int p = lane; p < nblocks; p += 64) ss += __hip_atomic_load(&A.ss_part[p * 3 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ss = wave_sum64(ss);
+      if (lane == 0) s_scale[w] = sqrtf(ss) * Ap.grad_scale;
+    }
+  }
+  __syncthreads();
+  if (ok && i < NP) {
+    const int grp = (i < A.P) ? 0 : (i < A.P + A.Q2 ? 1 : 2);
+    const float gnorm = s_scale[grp];
+    g = g * Ap.grad_scale;
+    if (!(gnorm < Ap.max_norm)) g = (g / gnorm) * Ap.max_norm;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const float mu = b1 * Ap.adam_m[i] + 0.1f * g;
+    const float nu = b2 * Ap.adam_v[i] + 0.001f * (g * g);
+    Ap.adam_m[i] = mu;
+    Ap.adam_v[i] = nu;
+    const float mu_hat = mu / (1.f - powf(b1, count));
+    const float nu_hat = nu / (1.f - powf(b2, count));
+    float upd = mu_hat / (sqrtf(nu_hat) + eps);
+    const float p = Ap.params[i];
+    upd = upd + Ap.wd[grp] * p;
+    const float pn = p + (-Ap.lr[grp]) * upd;
+    Ap.params[i] = pn;
+    if (grp == 1) {
+      const int j = i - A.P;
+      Ap.target_q[j] = Ap.target_q[j] * Ap.one_minus_tau + pn * Ap.tau;
+    } else if (grp == 2) {
+      Ap.metrics[3] = expf(pn);
+      if (Ap.metrics_accum) Ap.metrics_accum[3] += Ap.metrics[3];
+    }
+  }
+  // ---- last block out advances the optimizer count and re-arms the counters ----
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(&F.sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == (unsigned)nblocks - 1u) {
+      if (ok) F.step_count[0] = count;
+      else A.metrics[0] = NAN;
+      __hip_atomic_store(&F.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&F.sync[1], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 struct SacPlan {
   MlpDev pi, q, qt;
   int P, Q, NP, n_tiles, H, LH, n_red;
   size_t lds;
   int ld_x, ld_xu, ld_h, ld_y;
   // workspace offsets (floats)
-  long long off_slab_pi, off_slab_q, off_slab_ex, off_ss, total;
+  long long off_slab_pi, off_slab_q, off_slab_ex, off_ss, off_sync, total;
 };
 
 static int same_hidden(const int *dims, int n_layers) {
@@ -549,7 +685,8 @@ static int sac_plan(const mbpo_sac_desc *d, SacPlan *pl, bool need_ptrs) {
   pl->off_slab_q = pl->off_slab_pi + (long long)pl->n_tiles * pl->P;
   pl->off_slab_ex = pl->off_slab_q + (long long)pl->n_tiles * 2 * pl->Q;
   pl->off_ss = pl->off_slab_ex + (long long)pl->n_tiles * 4;
-  pl->total = pl->off_ss + (long long)pl->n_red * 3;
+  pl->off_sync = (pl->off_ss + (long long)pl->n_red * 3 + 3) & ~3LL;   // 2 x uint32 grid-barrier counters (zero between launches)
+  pl->total = pl->off_sync + 4;
   if (need_ptrs) {
     MBPO_REQUIRE(d->params && d->target_q && d->adam_m && d->adam_v && d->step_count && d->grads && d->workspace && d->metrics,
                  MBPO_ERR_ARG, "sac: null state pointer");
@@ -640,5 +777,29 @@ extern "C" int mbpo_sac_apply(const mbpo_sac_desc *d, void *stream) {
   A.max_norm = d->max_grad_norm; A.tau = d->tau; A.one_minus_tau = (float)(1.0 - (double)d->tau); A.grad_scale = d->grad_scale;
   hipLaunchKernelGGL(k_sac_apply, dim3(pl.n_red), dim3(256), 0, (hipStream_t)stream, A);
   MBPO_CHECK_LAUNCH("sac_apply");
+  return MBPO_OK;
+}
+
+extern "C" int mbpo_sac_reduce_apply(const mbpo_sac_desc *d, void *stream) {
+  SacPlan pl;
+  int rc = sac_plan(d, &pl, true);
+  if (rc != MBPO_OK) return rc;
+  SacFusedArgs F;
+  F.R.slab_pi = d->workspace + pl.off_slab_pi; F.R.slab_q = d->workspace + pl.off_slab_q; F.R.slab_ex = d->workspace + pl.off_slab_ex;
+  F.R.n_tiles = pl.n_tiles; F.R.P = pl.P; F.R.Q2 = 2 * pl.Q; F.R.B = d->batch_size;
+  F.R.grads = d->grads; F.R.metrics = d->metrics; F.R.metrics_accum = d->metrics_accum; F.R.ss_part = d->workspace + pl.off_ss;
+  F.R.step_count = d->step_count;
+  SacApplyArgs &A = F.Ap;
+  A.params = d->params; A.target_q = d->target_q; A.adam_m = d->adam_m; A.adam_v = d->adam_v; A.grads = d->grads;
+  A.metrics = d->metrics; A.metrics_accum = d->metrics_accum; A.step_count = d->step_count; A.ss_part = d->workspace + pl.off_ss;
+  A.n_parts = pl.n_red; A.P = pl.P; A.Q2 = 2 * pl.Q;
+  A.lr[0] = d->lr_policy; A.lr[1] = d->lr_q; A.lr[2] = d->lr_alpha;
+  A.wd[0] = d->wd_policy; A.wd[1] = d->wd_q; A.wd[2] = d->wd_alpha;
+  A.max_norm = d->max_grad_norm; A.tau = d->tau; A.one_minus_tau = (float)(1.0 - (double)d->tau); A.grad_scale = d->grad_scale;
+  F.sync = reinterpret_cast<unsigned int *>(d->workspace + pl.off_sync);
+  F.step_count = d->step_count;
+  MBPO_REQUIRE(pl.n_red <= 2048, MBPO_ERR_UNSUPPORTED, "sac_reduce_apply: %d blocks cannot be assumed co-resident; use grads + apply", pl.n_red);
+  hipLaunchKernelGGL(k_sac_reduce_apply, dim3(pl.n_red), dim3(256), 0, (hipStream_t)stream, F);
+  MBPO_CHECK_LAUNCH("sac_reduce_apply");
   return MBPO_OK;
 }

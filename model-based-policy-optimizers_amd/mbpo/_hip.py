@@ -183,7 +183,7 @@ def _bind_optional(lib: C.CDLL) -> None:
         if fn is not None:
             fn.restype = C.c_int
             fn.argtypes = argtypes
-    for name in ("mbpo_sac_grads", "mbpo_sac_grad_norms", "mbpo_sac_apply"):
+    for name in ("mbpo_sac_grads", "mbpo_sac_grad_norms", "mbpo_sac_apply", "mbpo_sac_reduce_apply"):
         fn = getattr(lib, name, None)
         if fn is not None:
             fn.restype = C.c_int

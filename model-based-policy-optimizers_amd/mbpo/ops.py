@@ -259,9 +259,13 @@ class SacUpdater:
                  reward_scaling: float = 1.0, target_entropy: Optional[float] = None, tau: float = 0.005,
                  lr_policy: float = 1e-4, lr_q: float = 1e-4, lr_alpha: float = 1e-4, wd_policy: float = 0.0,
                  wd_q: float = 0.0, wd_alpha: float = 0.0, max_grad_norm: float = 1e5, seed: int = 0,
-                 all_reduce=None, world_size: int = 1):
+                 all_reduce=None, world_size: int = 1, fused_apply: bool = False):
         self.lib = load()
         self.x_dim, self.u_dim, self.batch_size = x_dim, u_dim, batch_size
+        # single rank: slab reduction + optimizer in ONE launch (mbpo_sac_reduce_apply).  Off by default: measured on MI355X the
+        # in-kernel device-wide meeting point (cross-XCD atomics + L2 write-back) costs more than the kernel boundary it removes
+        # (48 vs 40 us per sgd_step).
+        self.fused_apply = fused_apply
         self.policy_spec = MlpSpec(list(policy_dims), policy_activation, 1)
         self.q_spec = MlpSpec(list(q_dims), q_activation, 2)
         self.P, self.Q = self.policy_spec.n_params, self.q_spec.n_params
@@ -332,6 +336,11 @@ class SacUpdater:
         d.noise_alpha, d.noise_critic, d.noise_actor = ptr(noise_alpha), ptr(noise_critic), ptr(noise_actor)
         d.offset = offset
         st = current_stream_ptr()
+        if self.all_reduce is None and self.fused_apply:
+            # single rank: fwd/bwd, then ONE launch for slab reduction + norms + clip + AdamW + Polyak
+            check(self.lib.mbpo_sac_grads_phase(C.byref(d), 1, st), "mbpo_sac_grads_phase")
+            check(self.lib.mbpo_sac_reduce_apply(C.byref(d), st), "mbpo_sac_reduce_apply")
+            return
         check(self.lib.mbpo_sac_grads(C.byref(d), st), "mbpo_sac_grads")
         if self.all_reduce is not None:
             self.all_reduce(self.grads)

@@ -156,3 +156,32 @@ def test_sac_bad_args(dev):
         ops.SacUpdater(x_dim=3, u_dim=1, policy_dims=[3, 64, 32, 2], q_dims=[4, 64, 32, 1], batch_size=32, device=dev)
     with pytest.raises(_hip.MbpoHipError):
         ops.SacUpdater(x_dim=3, u_dim=1, policy_dims=[3, 256, 256, 2], q_dims=[4, 256, 256, 1], batch_size=32, device=dev)
+
+
+def test_fused_reduce_apply_matches_two_launch_path(dev):
+    """mbpo_sac_reduce_apply (one launch, in-kernel device-wide meeting point for the clip norms) vs mbpo_sac_grads +
+    mbpo_sac_apply on the same state and batches: 6 chained steps, bit-identical state (same arithmetic, same order), with a
+    clip threshold low enough to be active."""
+    from mbpo import ops
+    X, U, B = 4, 1, 256
+    g = torch.Generator().manual_seed(3)
+    init = (torch.randn(ops.SacUpdater(x_dim=X, u_dim=U, policy_dims=[X, 64, 64, 64, 2 * U], q_dims=[X + U, 64, 64, 64, 1],
+                                        batch_size=B, device=dev).NP, generator=g) * 0.1)
+    ups = []
+    for fused in (True, False):
+        up = ops.SacUpdater(x_dim=X, u_dim=U, policy_dims=[X, 64, 64, 64, 2 * U], q_dims=[X + U, 64, 64, 64, 1], batch_size=B,
+                            device=dev, seed=5, max_grad_norm=0.05, lr_policy=1e-3, lr_q=1e-3, lr_alpha=1e-3, fused_apply=fused)
+        up.load_state(init.to(dev))
+        ups.append(up)
+    D = 2 * X + U + 3
+    for it in range(6):
+        batch = torch.randn(B, D, generator=g).to(dev)
+        batch[:, -1] = (torch.rand(B, generator=g) < 0.1).float().to(dev)
+        for up in ups:
+            up.sgd_step(batch)
+    torch.cuda.synchronize()
+    a, b = ups
+    assert float(a.step_count) == float(b.step_count) == 6
+    for name in ("params", "target_q", "adam_m", "adam_v", "grads", "metrics"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert int(a.workspace[-4:].view(torch.int32).abs().sum()) == 0      # counters re-armed
