@@ -178,8 +178,12 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # rehearsal only (one-GPU box): MBPO_BENCH_SHARE_GPU=1 puts every rank on cuda:0, MBPO_BENCH_BACKEND=gloo replaces RCCL
+    share_gpu = os.environ.get("MBPO_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("MBPO_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     pg = None
     force_pg = os.environ.get("MBPO_BENCH_FORCE_PG") == "1"      # exercise the RCCL path on a single rank
     if world > 1 or force_pg:
@@ -189,7 +193,7 @@ def main():
         if force_pg and world == 1:
             dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
         else:
-            dist.init_process_group(backend="nccl", device_id=device)
+            dist.init_process_group(backend=backend, **({"device_id": device} if backend == "nccl" else {}))
         pg = dist.group.WORLD
 
     log(f"building trainer on {device} (world={world})")
@@ -279,7 +283,10 @@ def main():
                                    "N=4096 envs/GPU, episode_length=5, S=5, B=256/GPU, G=64, nets 64x3, normalize_observations",
                        "n_envs_per_gpu": N_ENVS, "horizon": EPISODE_LEN, "env_steps_between_updates": S_STEPS,
                        "batch_size_per_gpu": BATCH, "grad_updates_per_step": GRAD_UPDATES, "ensemble": N_MEMBERS,
-                       "hipgraph": graph is not None, "parallelism": f"dp{world} (envs+minibatch sharded, flat grad all-reduce per sgd_step)"},
+                       "hipgraph": graph is not None, "parallelism": f"dp{world} (envs+minibatch sharded, flat grad all-reduce per sgd_step)",
+                       "grad_exchange": ("none" if world == 1 and pg is None else
+                                         "peer-memory one-shot (xGMI stores, csrc/p2p.hpp)" if getattr(trainer, "p2p", None) is not None
+                                         else "torch.distributed all_reduce")},
             "sac_updates_per_s": GRAD_UPDATES * args.steps / dt,
             "sac_update_samples_per_s": world * BATCH * GRAD_UPDATES * args.steps / dt,
             "params_finite": finite,

@@ -328,6 +328,37 @@ int mbpo_adamw_step(float *params, const float *grads, float *adam_m, float *ada
                     float wd, float grad_scale, int32_t apply_if_finite, float *target, float tau, float *grad_norm_out,
                     float *workspace, void *stream);
 
+/* ---- one-shot all-reduce over xGMI peer memory (multi-GPU SAC gradient exchange) ------------------------
+ * replaces: the live form of the reference's jax.lax.pmean(grad) (sac/utils.py:29-33) for vectors small enough that a
+ *           collective is pure latency.  Every rank owns an exchange REGION (mbpo_p2p_alloc -> 64-byte IPC handle, passed to
+ *           the other ranks out of band, mbpo_p2p_open there); a producer kernel stores its vector into slot[rank] of every
+ *           rank's region and publishes per-block arrival counts; the consumer waits for all ranks (bounded spin) and adds the
+ *           slots in rank order, so every rank holds bit-identical sums.  Regions are zero-initialised by mbpo_p2p_alloc.
+ * regions[r] : base of rank r's region as mapped in THIS process (regions[rank] is the own allocation);
+ * n_max      : floats per slot the region was sized for (mbpo_p2p_region_bytes).
+ * mbpo_p2p_all_reduce_sum: buf[0..n) <- sum over ranks, in place (3 small launches; every rank must call it the same number
+ *   of times).  On a consumer timeout buf is filled with NaN and mbpo_p2p_status reports 1 — nothing hangs.
+ */
+#define MBPO_P2P_MAX_RANKS 16
+typedef struct mbpo_p2p_desc {
+  int32_t world, rank;
+  int64_t n_max;
+  void *regions[MBPO_P2P_MAX_RANKS];
+} mbpo_p2p_desc;
+
+int64_t mbpo_p2p_region_bytes(int32_t world, int64_t n_max);
+int mbpo_p2p_alloc(int64_t bytes, void **ptr, void *handle64);
+int mbpo_p2p_open(const void *handle64, int32_t peer_device, void **ptr);   /* peer_device < 0: same device */
+int mbpo_p2p_close(void *ptr);
+int mbpo_p2p_free(void *ptr);
+int mbpo_p2p_all_reduce_sum(const mbpo_p2p_desc *d, float *buf, int64_t n, void *stream);
+/* SAC sgd_step over N ranks without a collective launch:  mbpo_sac_grads_p2p (= mbpo_sac_grads whose reduction kernel also
+ * stores the rank's gradient into every rank's exchange region)  ->  mbpo_sac_gather_p2p (waits for all ranks, grads <- sum
+ * over ranks in rank order, clip-norm partials)  ->  mbpo_sac_apply (grad_scale = 1/N).  n_max >= NP. */
+int mbpo_sac_grads_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream);
+int mbpo_sac_gather_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream);
+int mbpo_p2p_status(const mbpo_p2p_desc *d, int32_t *status_out);
+
 #ifdef __cplusplus
 }
 #endif

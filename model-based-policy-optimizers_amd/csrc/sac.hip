@@ -13,6 +13,8 @@
 // few fat launches and the slab scheme instead of a tree of small kernels.
 #include "common.hpp"
 #include "chain_run.hpp"
+#include "p2p.hpp"
+int mbpo_p2p_make_dev(const mbpo_p2p_desc *d, P2pDev *P);
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
 #define LOG_2 0.69314718055994530942f
@@ -28,6 +30,8 @@ struct SacArgs {
   float discounting, reward_scaling, target_entropy;
   float *slab_pi, *slab_q, *slab_ex;
   int ld_x, ld_xu, ld_h, ld_y, LH;
+  unsigned int *p2p_epoch;      // multi-GPU peer exchange: [0] += 1, [1] += p2p_blocks at the start of every step (or NULL)
+  unsigned int p2p_blocks;
   unsigned long long *stamps;   // measurement hook (mbpo_debug_set_stamps): [2 roles][16] s_memtime values of tile 0, or NULL
 };
 
@@ -123,6 +127,10 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
   {
     const int tid = tid_;
     SAC_STAMP(0);
+    if (A.p2p_epoch && blockIdx.x == 0 && tid == 0) {   // the exchange's epoch is stable while the reduce/gather kernels read it
+      A.p2p_epoch[0] = A.p2p_epoch[0] + 1u;
+      A.p2p_epoch[1] = A.p2p_epoch[1] + A.p2p_blocks;
+    }
   }
   // requested now, consumed after the first layer phase: the two scalar loads overlap the tile load instead of preceding it
   const float log_alpha_v = A.log_alpha[0];
@@ -435,6 +443,54 @@ __global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
   group_sumsq(g, i, A.P, A.Q2, NP, A.ss_part);
 }
 
+// multi-GPU: the reduced local gradient goes straight into every rank's exchange region (p2p.hpp) instead of a collective
+__global__ void __launch_bounds__(256) k_sac_reduce_push(SacReduceArgs A, P2pDev X) {
+  const int NP = A.P + A.Q2 + 1;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned epoch = X.epoch[0];
+  float g = 0.f;
+  if (i < A.P) {
+    for (int t = 0; t < A.n_tiles; ++t) g += A.slab_pi[(long long)t * A.P + i];
+  } else if (i < A.P + A.Q2) {
+    const int j = i - A.P;
+    for (int t = 0; t < A.n_tiles; ++t) g += A.slab_q[(long long)t * A.Q2 + j];
+  } else if (i == NP - 1) {
+    float ce = 0.f, ac = 0.f, al = 0.f;
+    for (int t = 0; t < A.n_tiles; ++t) {
+      ce += A.slab_ex[t * 4 + 0];
+      ac += A.slab_ex[t * 4 + 1];
+      al += A.slab_ex[t * 4 + 2];
+    }
+    const float invB = 1.0f / (float)A.B;
+    g = al * invB;
+    A.metrics[0] = 0.5f * ce * (0.5f * invB);
+    A.metrics[1] = ac * invB;
+    A.metrics[2] = al * invB;
+    if (A.metrics_accum) {
+      A.metrics_accum[0] += A.metrics[0];
+      A.metrics_accum[1] += A.metrics[1];
+      A.metrics_accum[2] += A.metrics[2];
+      A.metrics_accum[4] += 1.0f;
+    }
+    A.step_count[0] = A.step_count[0] + 1.0f;
+  }
+  p2p_push(X, epoch, i, NP, g);
+}
+
+// multi-GPU: wait for every rank's gradient, add the world slots in rank order, form the clip-norm partials
+__global__ void __launch_bounds__(256) k_sac_gather(P2pDev X, float *grads, int P, int Q2, float *ss_part) {
+  const int NP = P + Q2 + 1;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned epoch = X.epoch[0];
+  const bool ok = p2p_wait(X, X.epoch[1]);
+  float g = 0.f;
+  if (i < NP) {
+    g = ok ? p2p_sum(X, epoch, i) : NAN;
+    grads[i] = g;
+  }
+  group_sumsq(g, i, P, Q2, NP, ss_part);
+}
+
 __global__ void __launch_bounds__(256) k_sac_sumsq(const float *grads, int P, int Q2, float *ss_part) {
   const int NP = P + Q2 + 1;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -703,7 +759,7 @@ extern "C" int64_t mbpo_sac_workspace_floats(const mbpo_sac_desc *d) {
 
 constexpr int SP64 = 4;   // waves per chain at hidden width 64
 
-static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream) {
+static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, const mbpo_p2p_desc *xd = nullptr) {
   SacPlan pl;
   int rc = sac_plan(d, &pl, true);
   if (rc != MBPO_OK) return rc;
@@ -719,6 +775,16 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream) 
   A.noise_alpha = d->noise_alpha; A.noise_critic = d->noise_critic; A.noise_actor = d->noise_actor;
   A.seed = d->seed; A.offset = d->offset; A.step_count = d->step_count;
   A.stamps = g_sac_stamps;
+  P2pDev X;
+  A.p2p_epoch = nullptr;
+  A.p2p_blocks = (unsigned)pl.n_red;
+  if (xd) {
+    rc = mbpo_p2p_make_dev(xd, &X);
+    if (rc != MBPO_OK) return rc;
+    MBPO_REQUIRE(xd->n_max >= pl.NP, MBPO_ERR_ARG, "sac_grads_p2p: exchange regions hold %lld floats, the gradient has %d",
+                 (long long)xd->n_max, pl.NP);
+    A.p2p_epoch = X.epoch;
+  }
   A.discounting = d->discounting; A.reward_scaling = d->reward_scaling; A.target_entropy = d->target_entropy;
   A.slab_pi = d->workspace + pl.off_slab_pi; A.slab_q = d->workspace + pl.off_slab_q; A.slab_ex = d->workspace + pl.off_slab_ex;
   A.ld_x = pl.ld_x; A.ld_xu = pl.ld_xu; A.ld_h = pl.ld_h; A.ld_y = pl.ld_y; A.LH = pl.LH;
@@ -742,8 +808,27 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream) 
   R.slab_pi = A.slab_pi; R.slab_q = A.slab_q; R.slab_ex = A.slab_ex;
   R.n_tiles = pl.n_tiles; R.P = pl.P; R.Q2 = 2 * pl.Q; R.B = d->batch_size;
   R.grads = d->grads; R.metrics = d->metrics; R.metrics_accum = d->metrics_accum; R.ss_part = d->workspace + pl.off_ss; R.step_count = d->step_count;
-  hipLaunchKernelGGL(k_sac_reduce, dim3(pl.n_red), dim3(256), 0, st, R);
+  if (xd) hipLaunchKernelGGL(k_sac_reduce_push, dim3(pl.n_red), dim3(256), 0, st, R, X);
+  else hipLaunchKernelGGL(k_sac_reduce, dim3(pl.n_red), dim3(256), 0, st, R);
   MBPO_CHECK_LAUNCH("sac_grads");
+  return MBPO_OK;
+}
+
+extern "C" int mbpo_sac_grads_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream) {
+  MBPO_REQUIRE(x, MBPO_ERR_ARG, "sac_grads_p2p: null exchange descriptor");
+  return sac_grads_impl(d, 3, stream, x);
+}
+
+extern "C" int mbpo_sac_gather_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream) {
+  SacPlan pl;
+  int rc = sac_plan(d, &pl, true);
+  if (rc != MBPO_OK) return rc;
+  P2pDev X;
+  rc = mbpo_p2p_make_dev(x, &X);
+  if (rc != MBPO_OK) return rc;
+  MBPO_REQUIRE(x->n_max >= pl.NP, MBPO_ERR_ARG, "sac_gather_p2p: exchange regions too small");
+  hipLaunchKernelGGL(k_sac_gather, dim3(pl.n_red), dim3(256), 0, (hipStream_t)stream, X, d->grads, pl.P, 2 * pl.Q, d->workspace + pl.off_ss);
+  MBPO_CHECK_LAUNCH("sac_gather_p2p");
   return MBPO_OK;
 }
 

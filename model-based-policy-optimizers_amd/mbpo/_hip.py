@@ -22,6 +22,11 @@ REWARD_PENDULUM, REWARD_QUADRATIC = 0, 1
 _LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libmbpo_hip.so"
 
 
+class P2pDesc(C.Structure):
+    """mbpo_p2p_desc"""
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("n_max", C.c_int64), ("regions", C.c_void_p * 16)]
+
+
 class MbpoHipError(RuntimeError):
     pass
 
@@ -201,6 +206,18 @@ def _bind_optional(lib: C.CDLL) -> None:
     if fn is not None:
         fn.restype = C.c_int64
         fn.argtypes = [i32, i32, vp, i64]
+    # one-shot peer-memory all-reduce (csrc/p2p.hip)
+    lib.mbpo_p2p_region_bytes.restype = C.c_int64
+    lib.mbpo_p2p_region_bytes.argtypes = [i32, i64]
+    for name, argtypes in (("mbpo_p2p_alloc", [i64, C.POINTER(C.c_void_p), vp]), ("mbpo_p2p_open", [vp, i32, C.POINTER(C.c_void_p)]),
+                           ("mbpo_p2p_close", [vp]), ("mbpo_p2p_free", [vp]),
+                           ("mbpo_p2p_all_reduce_sum", [C.POINTER(P2pDesc), vp, i64, vp]),
+                           ("mbpo_p2p_status", [C.POINTER(P2pDesc), C.POINTER(C.c_int32)]),
+                           ("mbpo_sac_grads_p2p", [C.POINTER(SacDesc), C.POINTER(P2pDesc), vp]),
+                           ("mbpo_sac_gather_p2p", [C.POINTER(SacDesc), C.POINTER(P2pDesc), vp])):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = argtypes
     fn = getattr(lib, "mbpo_bptt_actor_grads", None)
     if fn is not None:
         fn.restype = C.c_int

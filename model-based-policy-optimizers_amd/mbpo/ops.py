@@ -259,7 +259,7 @@ class SacUpdater:
                  reward_scaling: float = 1.0, target_entropy: Optional[float] = None, tau: float = 0.005,
                  lr_policy: float = 1e-4, lr_q: float = 1e-4, lr_alpha: float = 1e-4, wd_policy: float = 0.0,
                  wd_q: float = 0.0, wd_alpha: float = 0.0, max_grad_norm: float = 1e5, seed: int = 0,
-                 all_reduce=None, world_size: int = 1, fused_apply: bool = False):
+                 all_reduce=None, world_size: int = 1, fused_apply: bool = False, p2p=None):
         self.lib = load()
         self.x_dim, self.u_dim, self.batch_size = x_dim, u_dim, batch_size
         # single rank: slab reduction + optimizer in ONE launch (mbpo_sac_reduce_apply).  Off by default: measured on MI355X the
@@ -275,6 +275,7 @@ class SacUpdater:
         self.params, self.target_q, self.adam_m, self.adam_v = f(self.NP), f(2 * self.Q), f(self.NP), f(self.NP)
         self.step_count, self.grads, self.metrics, self.metrics_accum = f(1), f(self.NP), f(4), f(5)
         self.all_reduce, self.world_size = all_reduce, world_size
+        self.p2p = p2p      # mbpo.parallel.P2PExchange: gradient exchange through peer memory instead of `all_reduce`
         d = _hip.SacDesc()
         d.x_dim, d.u_dim = x_dim, u_dim
         d.policy_layers, d.q_layers = len(policy_dims) - 1, len(q_dims) - 1
@@ -340,6 +341,11 @@ class SacUpdater:
             # single rank: fwd/bwd, then ONE launch for slab reduction + norms + clip + AdamW + Polyak
             check(self.lib.mbpo_sac_grads_phase(C.byref(d), 1, st), "mbpo_sac_grads_phase")
             check(self.lib.mbpo_sac_reduce_apply(C.byref(d), st), "mbpo_sac_reduce_apply")
+            return
+        if self.p2p is not None:
+            check(self.lib.mbpo_sac_grads_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_grads_p2p")
+            check(self.lib.mbpo_sac_gather_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_gather_p2p")
+            check(self.lib.mbpo_sac_apply(C.byref(d), st), "mbpo_sac_apply")
             return
         check(self.lib.mbpo_sac_grads(C.byref(d), st), "mbpo_sac_grads")
         if self.all_reduce is not None:

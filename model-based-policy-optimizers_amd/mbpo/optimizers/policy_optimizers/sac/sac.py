@@ -183,6 +183,16 @@ class SAC:
             discounting=discounting, reward_scaling=reward_scaling, target_entropy=target_entropy, tau=tau,
             lr_policy=lr_policy, lr_q=lr_q, lr_alpha=lr_alpha, wd_policy=wd_policy, wd_q=wd_q, wd_alpha=wd_alpha,
             max_grad_norm=max_grad_norm, all_reduce=all_reduce, world_size=self.world_size)
+        # Multi-GPU: exchange the flat gradient (and the normaliser's sums) through peer memory over xGMI instead of a
+        # library collective (csrc/p2p.hpp) — plain kernels, graph-capturable.  create() validates the regions against
+        # torch.distributed.all_reduce on every rank and returns None (keep RCCL) if anything is off.
+        self.p2p = None
+        if self.dp.group is not None and self.world_size > 1:
+            from mbpo.parallel import P2PExchange
+            self.p2p = P2PExchange.create(self.dp, self.updater.NP, self.device)
+            if self.p2p is not None:
+                self.updater.p2p = self.p2p
+                self._all_reduce = self.p2p.all_reduce_sum
         # SAC's own buffer of model transitions (sac.py:191-205): rows carry state_extras.truncation
         z = lambda n: torch.zeros(n, device=self.device)
         dummy_transition = Transition(observation=z(self.x_dim), action=z(self.u_dim), reward=z(1), discount=z(1),
@@ -305,7 +315,7 @@ class SAC:
         n = self.num_training_steps_per_epoch
         env_steps_per = self.env_steps_per_actor_step * self.num_env_steps_between_updates
         done_steps = 0
-        if self.use_graph and n >= 3 and self._all_reduce is None:
+        if self.use_graph and n >= 3 and (self.dp.group is None or self.p2p is not None):
             k1, k2 = K.split(key)
             training_state, env_state, buffer_state = self.training_step(training_state, env_state, buffer_state, k1)
             done_steps = 1

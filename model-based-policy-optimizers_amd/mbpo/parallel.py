@@ -10,6 +10,8 @@ live form: parallel envs, the model-replay shard and the minibatch are per rank;
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -58,3 +60,118 @@ class DataParallel:
             raise ValueError(f"{n} units do not shard evenly over {self.world_size} ranks")
         per = n // self.world_size
         return range(self.rank * per, (self.rank + 1) * per)
+
+
+class P2PExchange:
+    """Peer-memory exchange regions for the one-shot all-reduce (csrc/p2p.hpp): every rank allocates a region, the 64-byte IPC
+    handles travel through the process group (all_gather_object), every rank maps every peer's region.
+
+    `create` returns None (the caller then keeps the RCCL all-reduce) when the regions cannot be set up, when
+    MBPO_P2P_ALLREDUCE=0, or when the self-check — one exchange of a rank-dependent vector compared with
+    torch.distributed.all_reduce — does not reproduce the library's result on every rank."""
+
+    def __init__(self, dp: "DataParallel", n_max: int, device: torch.device):
+        from mbpo import _hip
+        self.lib = _hip.load()
+        self._hip = _hip
+        self.dp, self.n_max, self.device = dp, int(n_max), device
+        self.own = C.c_void_p()
+        self.peers = {}
+        self.desc = None
+
+    @classmethod
+    def create(cls, dp: "DataParallel", n_max: int, device) -> Optional["P2PExchange"]:
+        if dp.group is None or dp.world_size < 2 or os.environ.get("MBPO_P2P_ALLREDUCE", "1") == "0":
+            return None
+        import torch.distributed as dist
+        device = torch.device(device)
+        ex = cls(dp, n_max, device)
+        ok = 1
+        try:
+            ex._setup()
+        except Exception as e:      # noqa: BLE001 — any failure means: use the library collective
+            ok = 0
+            ex._err = repr(e)
+        flag = torch.tensor([ok], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=dp.group)
+        if int(flag) == 0:
+            ex.close()
+            return None
+        ok = 1 if ex._self_check() else 0
+        flag = torch.tensor([ok], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=dp.group)
+        if int(flag) == 0:
+            ex.close()
+            return None
+        return ex
+
+    def _setup(self):
+        import torch.distributed as dist
+        _hip, lib, dp = self._hip, self.lib, self.dp
+        nbytes = lib.mbpo_p2p_region_bytes(dp.world_size, self.n_max)
+        if nbytes < 0:
+            _hip.check(int(nbytes), "mbpo_p2p_region_bytes")
+        handle = (C.c_ubyte * 64)()
+        _hip.check(lib.mbpo_p2p_alloc(nbytes, C.byref(self.own), handle), "mbpo_p2p_alloc")
+        mine = (bytes(handle), torch.cuda.current_device() if self.device.index is None else self.device.index, os.getpid())
+        gathered = [None] * dp.world_size
+        dist.all_gather_object(gathered, mine, group=dp.group)
+        d = _hip.P2pDesc()
+        d.world, d.rank, d.n_max = dp.world_size, dp.rank, self.n_max
+        my_dev = mine[1]
+        for r, (h, dev_idx, _pid) in enumerate(gathered):
+            if r == dp.rank:
+                d.regions[r] = self.own.value
+                continue
+            p = C.c_void_p()
+            hb = (C.c_ubyte * 64).from_buffer_copy(h)
+            _hip.check(lib.mbpo_p2p_open(hb, -1 if dev_idx == my_dev else dev_idx, C.byref(p)), "mbpo_p2p_open")
+            self.peers[r] = p
+            d.regions[r] = p.value
+        self.desc = d
+        dist.barrier(group=dp.group)
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place SUM of a contiguous fp32 device tensor (numel <= n_max) over the ranks."""
+        _hip = self._hip
+        _hip.require_device_tensor(t, "t")
+        if t.numel() > self.n_max:
+            raise ValueError(f"tensor has {t.numel()} elements, the exchange regions hold {self.n_max}")
+        _hip.check(self.lib.mbpo_p2p_all_reduce_sum(C.byref(self.desc), t.data_ptr(), t.numel(), _hip.current_stream_ptr()),
+                   "mbpo_p2p_all_reduce_sum")
+        return t
+
+    def status(self) -> int:
+        v = C.c_int32(0)
+        self._hip.check(self.lib.mbpo_p2p_status(C.byref(self.desc), C.byref(v)), "mbpo_p2p_status")
+        return int(v.value)
+
+    def _self_check(self) -> bool:
+        import torch.distributed as dist
+        n = min(self.n_max, 4099)
+        for it in range(3):      # three exchanges: both slot parities and a re-use
+            g = torch.Generator().manual_seed(1000 * it + self.dp.rank)
+            x = torch.randn(n, generator=g).to(self.device)
+            ref = x.clone()
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.dp.group)
+            self.all_reduce_sum(x)
+            torch.cuda.synchronize()
+            if self.status() != 0 or not bool(torch.isfinite(x).all()):
+                return False
+            if not torch.allclose(x, ref, rtol=1e-5, atol=1e-5):
+                return False
+        return True
+
+    def close(self):
+        for p in self.peers.values():
+            try:
+                self.lib.mbpo_p2p_close(p)
+            except Exception:       # noqa: BLE001
+                pass
+        self.peers = {}
+        if self.own.value:
+            try:
+                self.lib.mbpo_p2p_free(self.own)
+            except Exception:       # noqa: BLE001
+                pass
+            self.own = C.c_void_p()

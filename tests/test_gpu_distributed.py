@@ -87,3 +87,98 @@ def test_single_rank_rccl_group(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(1, port, "nccl", str(tmp_path)), nprocs=1, join=True)
     assert (tmp_path / "ok0").exists()
+
+
+def _p2p_worker(rank, world, port, tmpdir):
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mbpo.parallel import DataParallel, P2PExchange
+        dp = DataParallel(dist.group.WORLD)
+        n = 26309
+        ex = P2PExchange.create(dp, n, dev)
+        assert ex is not None, "exchange regions / self-check failed"
+        for it in range(5):
+            g = torch.Generator().manual_seed(7 * it + rank)
+            x = torch.randn(n, generator=g).to(dev)
+            # expected: slots added in rank order, fp32
+            exp = torch.zeros(n)
+            for r in range(world):
+                exp = exp + torch.randn(n, generator=torch.Generator().manual_seed(7 * it + r))
+            ex.all_reduce_sum(x)
+            torch.cuda.synchronize()
+            assert ex.status() == 0
+            assert torch.equal(x.cpu(), exp), f"iteration {it}"
+        ex.close()
+        (Path(tmpdir) / f"p2p_ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_p2p_all_reduce_two_ranks_one_gpu(tmp_path):
+    """The one-shot peer-memory all-reduce (csrc/p2p.hpp) between two processes that share the box's GPU: regions exchanged by
+    IPC handle, five exchanges, bit-exact rank-ordered fp32 sums on both ranks.  (Across GPUs the same stores travel over xGMI;
+    P2PExchange.create re-validates against the library all-reduce at start-up and falls back to it otherwise.)"""
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_p2p_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"p2p_ok{r}").exists() for r in range(world))
+
+
+def _p2p_sac_worker(rank, world, port, tmpdir):
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mbpo.parallel import DataParallel, P2PExchange
+        dp = DataParallel(dist.group.WORLD)
+        B = 32
+        cfg, st, batch, noise = _make(world, B)
+        sl = slice(rank * B, (rank + 1) * B)
+        up = _updater(cfg, B, dev, world_size=world)
+        ex = P2PExchange.create(dp, up.NP, dev)
+        assert ex is not None
+        up.p2p = ex
+        ref_rccl = _updater(cfg, B, dev, all_reduce=dp.all_reduce_fn(), world_size=world)     # library-collective path (gloo here)
+        ref = _updater(cfg, world * B, dev)                                                   # single process, global minibatch
+        for u in (up, ref_rccl, ref):
+            u.load_state(st.params.to(dev))
+        for it in range(3):       # three chained steps: both slot parities, re-armed flags
+            g = torch.Generator().manual_seed(100 + it)
+            D = batch.shape[1]
+            b = torch.randn(world * B, D, generator=g)
+            b[:, cfg.x_dim + cfg.u_dim + 1] = 1.0
+            b[:, D - 1] = (torch.rand(world * B, generator=g) < 0.2).float()
+            nz = [torch.randn(world * B, cfg.u_dim, generator=g) for _ in range(3)]
+            up.sgd_step(b[sl].to(dev), None, None, *[n[sl].to(dev) for n in nz])
+            ref_rccl.sgd_step(b[sl].to(dev), None, None, *[n[sl].to(dev) for n in nz])
+            ref.sgd_step(b.to(dev), None, None, *[n.to(dev) for n in nz])
+            torch.cuda.synchronize()
+            assert ex.status() == 0
+            # identical to the collective path up to the summation order of two numbers (commutative: bit-exact for world 2)
+            assert torch.equal(up.grads, ref_rccl.grads) and torch.equal(up.params, ref_rccl.params), it
+            torch.testing.assert_close(up.params, ref.params, atol=5e-6, rtol=0)
+        ex.close()
+        (Path(tmpdir) / f"p2psac_ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_sac_sgd_step_over_peer_memory_two_ranks(tmp_path):
+    """mbpo_sac_grads_p2p -> mbpo_sac_gather_p2p -> mbpo_sac_apply on two ranks (half a minibatch each) equals the
+    all-reduce path bit for bit and the single-process step on the whole minibatch within fp32 rounding."""
+    world = 2
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_p2p_sac_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"p2psac_ok{r}").exists() for r in range(world))
