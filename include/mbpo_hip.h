@@ -170,6 +170,11 @@ int mbpo_gae_scan(const float *truncation, const float *termination, const float
                   float lam, int32_t time_major, void *stream);
 int mbpo_lambda_return_scan(const float *rewards, const float *next_values, float *returns, int64_t B, int32_t T,
                             float gamma, float lam, int32_t time_major, void *stream);
+/* N1: GAE with a per-element discount array (same layout as rewards) — the non_equidistant_time form of compute_gae
+ * (ppo/losses_new.py:181-226): gamma is replaced element-wise in deltas, in the scan coefficient and in the advantages. */
+int mbpo_gae_scan_discounts(const float *truncation, const float *termination, const float *rewards, const float *values,
+                            const float *bootstrap, const float *discounts, float *vs, float *advantages, int64_t B,
+                            int32_t T, float lam, int32_t time_major, void *stream);
 
 /* ---- S3-S8: SAC sgd_step (sac/sac.py:227-281) -------------------------------------------------
  * replaces: SAC.sgd_step = alpha_update + critic_update + actor_update (all three evaluated at the OLD
@@ -211,6 +216,10 @@ typedef struct mbpo_sac_desc {
   float discounting, reward_scaling, target_entropy, tau;
   float lr_policy, lr_q, lr_alpha, wd_policy, wd_q, wd_alpha, max_grad_norm;
   float grad_scale;                          /* 1/world_size when grads were all-reduced with SUM, else 1 */
+  /* N1 (sac/losses.py:90-98): per-sample discount exp(-continuous_discounting * t), t = the switch time encoded in the last
+   * action component, affinely mapped to [min,max]_time_between_switches and floored to a multiple of env_dt */
+  int32_t non_equidistant_time;
+  float continuous_discounting, min_time_between_switches, max_time_between_switches, env_dt;
 } mbpo_sac_desc;
 
 int64_t mbpo_sac_workspace_floats(const mbpo_sac_desc *d);

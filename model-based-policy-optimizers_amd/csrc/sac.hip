@@ -28,6 +28,8 @@ struct SacArgs {
   unsigned long long seed, offset;
   const float *step_count;
   float discounting, reward_scaling, target_entropy;
+  int neq;                      // non_equidistant_time (losses.py:90-98)
+  float neq_cd, neq_tl, neq_tu, neq_dt;
   float *slab_pi, *slab_q, *slab_ex;
   int ld_x, ld_xu, ld_h, ld_y, LH;
   unsigned int *p2p_epoch;      // multi-GPU peer exchange: [0] += 1, [1] += p2p_blocks at the start of every step (or NULL)
@@ -49,6 +51,14 @@ static unsigned long long *g_sac_stamps = nullptr;
 extern "C" int mbpo_debug_set_stamps(void *buf) {
   g_sac_stamps = (unsigned long long *)buf;
   return MBPO_OK;
+}
+
+// jnp.floor_divide for floats ([3P] jax.numpy: remainder-based, then rounded): x1 // x2
+__device__ __forceinline__ float floor_divide_f(float x1, float x2) {
+  const float mod = fmodf(x1, x2);
+  float div = (x1 - mod) / x2;
+  if (mod != 0.0f && ((x2 < 0.0f) != (mod < 0.0f))) div -= 1.0f;
+  return roundf(div);
 }
 
 // per action-dim pieces of NormalTanh (sac/parametric_distribution.py:66-73,117-120)
@@ -285,7 +295,14 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
           const float nq = fminf(y_q1[r * ld_y], y_q2[r * ld_y]);
           const float next_v = nq - alpha * nlp;                                                   // :89
           const float rew = s_row[r * D4 + X + U], disc = s_row[r * D4 + X + U + 1];
-          const float target = rew * A.reward_scaling + disc * A.discounting * next_v;             // :101-103
+          float gamma = A.discounting;
+          if (A.neq) {                                                                             // :90-96
+            const float pseudo = s_row[r * D4 + X + U - 1];                                        // transitions.action[..., -1]
+            float tfa = (A.neq_tu - A.neq_tl) / 2.0f * pseudo + (A.neq_tu + A.neq_tl) / 2.0f;
+            tfa = floor_divide_f(tfa, A.neq_dt) * A.neq_dt;
+            gamma = expf(-A.neq_cd * tfa);
+          }
+          const float target = rew * A.reward_scaling + disc * gamma * next_v;                     // :101-103
           const float trunc = s_row[r * D4 + D - 1];
           const float err = ok ? (s_scal[32 + tid] - target) * (1.f - trunc) : 0.f;               // q_error :104-108
           s_scal[tid] = err * err;
@@ -786,6 +803,9 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
     A.p2p_epoch = X.epoch;
   }
   A.discounting = d->discounting; A.reward_scaling = d->reward_scaling; A.target_entropy = d->target_entropy;
+  A.neq = d->non_equidistant_time; A.neq_cd = d->continuous_discounting; A.neq_tl = d->min_time_between_switches;
+  A.neq_tu = d->max_time_between_switches; A.neq_dt = d->env_dt;
+  MBPO_REQUIRE(!A.neq || A.neq_dt > 0.f, MBPO_ERR_ARG, "sac: non_equidistant_time needs env_dt > 0");
   A.slab_pi = d->workspace + pl.off_slab_pi; A.slab_q = d->workspace + pl.off_slab_q; A.slab_ex = d->workspace + pl.off_slab_ex;
   A.ld_x = pl.ld_x; A.ld_xu = pl.ld_xu; A.ld_h = pl.ld_h; A.ld_y = pl.ld_y; A.LH = pl.LH;
   hipStream_t st = (hipStream_t)stream;

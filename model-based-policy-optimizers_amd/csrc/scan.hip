@@ -16,6 +16,7 @@
 
 struct ScanArgs {
   const float *trunc, *term, *rew, *val, *boot;  // GAE inputs; lambda: rew, val = next_values
+  const float *disc;                             // GAE: optional per-element discount (non-equidistant time, losses_new.py:105-226)
   float *out0, *out1;                            // GAE: vs, adv;  lambda: returns
   long long B;
   int T;
@@ -36,7 +37,7 @@ __global__ void __launch_bounds__(256) k_scan_time_major(ScanArgs A) {
         const long long i = (long long)t * B + b;
         const float tr = A.trunc[i], te = A.term[i], r = A.rew[i], v = A.val[i];
         const float m = 1.f - tr;
-        const float g1 = A.gamma * (1.f - te);
+        const float g1 = (A.disc ? A.disc[i] : A.gamma) * (1.f - te);
         const float delta = (r + g1 * v_next - v) * m;        // :157-158
         acc = delta + g1 * m * A.lam * acc;                   // :166
         const float vs = acc + v;                             // :176
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(256) k_scan_batch_major(ScanArgs A) {
           v = A.val[i];
           const float v_next = (t == T - 1) ? boot : A.val[i + 1];
           m = 1.f - tr;
-          g1 = A.gamma * (1.f - te);
+          g1 = (A.disc ? A.disc[i] : A.gamma) * (1.f - te);
           d = (r + g1 * v_next - v) * m;
           c = g1 * m * A.lam;
         } else {
@@ -166,8 +167,19 @@ extern "C" int mbpo_gae_scan(const float *truncation, const float *termination, 
   if (B == 0 || T == 0) return MBPO_OK;
   MBPO_REQUIRE(truncation && termination && rewards && values && bootstrap && vs && advantages, MBPO_ERR_ARG,
                "gae_scan: null pointer");
-  ScanArgs A{truncation, termination, rewards, values, bootstrap, vs, advantages, B, T, gamma, lam};
+  ScanArgs A{truncation, termination, rewards, values, bootstrap, nullptr, vs, advantages, B, T, gamma, lam};
   return launch_scan<MODE_GAE>(A, time_major, (hipStream_t)stream, "gae_scan");
+}
+
+extern "C" int mbpo_gae_scan_discounts(const float *truncation, const float *termination, const float *rewards, const float *values,
+                                       const float *bootstrap, const float *discounts, float *vs, float *advantages, int64_t B,
+                                       int32_t T, float lam, int32_t time_major, void *stream) {
+  MBPO_REQUIRE(B >= 0 && T >= 0, MBPO_ERR_ARG, "gae_scan_discounts: negative size");
+  if (B == 0 || T == 0) return MBPO_OK;
+  MBPO_REQUIRE(truncation && termination && rewards && values && bootstrap && discounts && vs && advantages, MBPO_ERR_ARG,
+               "gae_scan_discounts: null pointer");
+  ScanArgs A{truncation, termination, rewards, values, bootstrap, discounts, vs, advantages, B, T, 0.f, lam};
+  return launch_scan<MODE_GAE>(A, time_major, (hipStream_t)stream, "gae_scan_discounts");
 }
 
 extern "C" int mbpo_lambda_return_scan(const float *rewards, const float *next_values, float *returns, int64_t B, int32_t T,
@@ -175,6 +187,6 @@ extern "C" int mbpo_lambda_return_scan(const float *rewards, const float *next_v
   MBPO_REQUIRE(B >= 0 && T >= 0, MBPO_ERR_ARG, "lambda_return_scan: negative size");
   if (B == 0 || T == 0) return MBPO_OK;
   MBPO_REQUIRE(rewards && next_values && returns, MBPO_ERR_ARG, "lambda_return_scan: null pointer");
-  ScanArgs A{nullptr, nullptr, rewards, next_values, nullptr, returns, nullptr, B, T, gamma, lam};
+  ScanArgs A{nullptr, nullptr, rewards, next_values, nullptr, nullptr, returns, nullptr, B, T, gamma, lam};
   return launch_scan<MODE_LAMBDA>(A, time_major, (hipStream_t)stream, "lambda_return_scan");
 }

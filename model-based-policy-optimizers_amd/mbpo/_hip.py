@@ -99,6 +99,8 @@ class SacDesc(C.Structure):
         ("lr_policy", C.c_float), ("lr_q", C.c_float), ("lr_alpha", C.c_float),
         ("wd_policy", C.c_float), ("wd_q", C.c_float), ("wd_alpha", C.c_float), ("max_grad_norm", C.c_float),
         ("grad_scale", C.c_float),
+        ("non_equidistant_time", C.c_int32), ("continuous_discounting", C.c_float), ("min_time_between_switches", C.c_float),
+        ("max_time_between_switches", C.c_float), ("env_dt", C.c_float),
     ]
 
 
@@ -179,6 +181,7 @@ def _bind_optional(lib: C.CDLL) -> None:
         "mbpo_running_stats_reduce": [vp, i64, i32, i32, i32, vp, vp, vp, i32, vp],
         "mbpo_running_stats_apply": [vp, vp, i32, f32, f32, vp],
         "mbpo_gae_scan": [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp],
+        "mbpo_gae_scan_discounts": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
         "mbpo_lambda_return_scan": [vp, vp, vp, i64, i32, f32, f32, i32, vp],
         "mbpo_critic_grads": [vp, i32, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp],
         "mbpo_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, i32, vp, f32, vp, vp, vp],

@@ -217,8 +217,9 @@ def running_stats_apply(stats: torch.Tensor, sums: torch.Tensor, x_dim: int, std
 
 
 # ------------------------------------------------------------------------------------------------ scans (P4, B2)
-def gae_scan(truncation, termination, rewards, values, bootstrap, gamma: float, lam: float, time_major: bool = False):
-    """compute_gae (ppo/losses.py:128-184).  Arrays [B,T] (time_major=False) or [T,B]; bootstrap [B]."""
+def gae_scan(truncation, termination, rewards, values, bootstrap, gamma, lam: float, time_major: bool = False):
+    """compute_gae (ppo/losses.py:128-184).  Arrays [B,T] (time_major=False) or [T,B]; bootstrap [B].
+    `gamma` may be a tensor shaped like `rewards`: the per-step discount of non_equidistant_time (ppo/losses_new.py:181-226)."""
     lib = load()
     for t, nm in ((truncation, "truncation"), (termination, "termination"), (rewards, "rewards"), (values, "values"),
                   (bootstrap, "bootstrap")):
@@ -228,6 +229,14 @@ def gae_scan(truncation, termination, rewards, values, bootstrap, gamma: float, 
         raise ValueError("bootstrap must be [B]")
     vs = torch.empty_like(values)
     adv = torch.empty_like(values)
+    if isinstance(gamma, torch.Tensor):
+        _req(gamma, "gamma")
+        if gamma.shape != values.shape:
+            raise ValueError("a per-element discount must have the shape of rewards/values")
+        check(lib.mbpo_gae_scan_discounts(truncation.data_ptr(), termination.data_ptr(), rewards.data_ptr(), values.data_ptr(),
+                                          bootstrap.data_ptr(), gamma.data_ptr(), vs.data_ptr(), adv.data_ptr(), B, T, lam,
+                                          int(time_major), current_stream_ptr()), "mbpo_gae_scan_discounts")
+        return vs, adv
     check(lib.mbpo_gae_scan(truncation.data_ptr(), termination.data_ptr(), rewards.data_ptr(), values.data_ptr(),
                             bootstrap.data_ptr(), vs.data_ptr(), adv.data_ptr(), B, T, gamma, lam, int(time_major),
                             current_stream_ptr()), "mbpo_gae_scan")
@@ -259,7 +268,9 @@ class SacUpdater:
                  reward_scaling: float = 1.0, target_entropy: Optional[float] = None, tau: float = 0.005,
                  lr_policy: float = 1e-4, lr_q: float = 1e-4, lr_alpha: float = 1e-4, wd_policy: float = 0.0,
                  wd_q: float = 0.0, wd_alpha: float = 0.0, max_grad_norm: float = 1e5, seed: int = 0,
-                 all_reduce=None, world_size: int = 1, fused_apply: bool = False, p2p=None):
+                 all_reduce=None, world_size: int = 1, fused_apply: bool = False, p2p=None,
+                 non_equidistant_time: bool = False, continuous_discounting: float = 0.0, min_time_between_switches: float = 0.0,
+                 max_time_between_switches: float = 0.0, env_dt: float = 0.0):
         self.lib = load()
         self.x_dim, self.u_dim, self.batch_size = x_dim, u_dim, batch_size
         # single rank: slab reduction + optimizer in ONE launch (mbpo_sac_reduce_apply).  Off by default: measured on MI355X the
@@ -290,6 +301,9 @@ class SacUpdater:
         d.lr_policy, d.lr_q, d.lr_alpha = lr_policy, lr_q, lr_alpha
         d.wd_policy, d.wd_q, d.wd_alpha, d.max_grad_norm = wd_policy, wd_q, wd_alpha, max_grad_norm
         d.grad_scale = 1.0 / world_size
+        d.non_equidistant_time = int(non_equidistant_time)          # N1 (sac/losses.py:90-98)
+        d.continuous_discounting, d.env_dt = continuous_discounting, env_dt
+        d.min_time_between_switches, d.max_time_between_switches = min_time_between_switches, max_time_between_switches
         d.seed, d.offset = seed, 0
         nws = self.lib.mbpo_sac_workspace_floats(C.byref(d))
         if nws < 0:

@@ -126,8 +126,8 @@ class SAC:
                  ):
         if min_replay_size >= num_timesteps:
             raise ValueError('No training will happen because min_replay_size >= num_timesteps')     # sac.py:100-102
-        if non_equidistant_time:
-            raise NotImplementedError("non_equidistant_time (sac/losses.py:90-98) is a SURVEY §8f 'next' row (N1)")
+        if non_equidistant_time and not env_dt > 0:
+            raise ValueError("non_equidistant_time needs env_dt > 0 (sac/losses.py:95 floors the switch time to multiples of it)")
         if wandb_logging:
             raise NotImplementedError("wandb is not available in this environment")
         self.eval_key_fixed = eval_key_fixed
@@ -182,7 +182,9 @@ class SAC:
             device=self.device, policy_activation=policy_activation, q_activation=critic_activation,
             discounting=discounting, reward_scaling=reward_scaling, target_entropy=target_entropy, tau=tau,
             lr_policy=lr_policy, lr_q=lr_q, lr_alpha=lr_alpha, wd_policy=wd_policy, wd_q=wd_q, wd_alpha=wd_alpha,
-            max_grad_norm=max_grad_norm, all_reduce=all_reduce, world_size=self.world_size)
+            max_grad_norm=max_grad_norm, all_reduce=all_reduce, world_size=self.world_size,
+            non_equidistant_time=non_equidistant_time, continuous_discounting=continuous_discounting,
+            min_time_between_switches=min_time_between_switches, max_time_between_switches=max_time_between_switches, env_dt=env_dt)
         # Multi-GPU: exchange the flat gradient (and the normaliser's sums) through peer memory over xGMI instead of a
         # library collective (csrc/p2p.hpp) — plain kernels, graph-capturable.  create() validates the regions against
         # torch.distributed.all_reduce on every rank and returns None (keep RCCL) if anything is off.

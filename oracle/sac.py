@@ -24,6 +24,16 @@ import torch
 from . import nets
 
 
+def floor_divide(x1: torch.Tensor, x2: float) -> torch.Tensor:
+    """[3P] jnp.floor_divide on floats (the `//` of losses.py:95): remainder-based division, then rounded."""
+    x2t = torch.as_tensor(x2, dtype=x1.dtype)
+    mod = torch.fmod(x1, x2t)
+    div = (x1 - mod) / x2t
+    ind = (mod != 0) & ((x2t < 0) != (mod < 0))
+    div = torch.where(ind, div - 1, div)
+    return torch.round(div)
+
+
 @dataclass
 class SacConfig:
     x_dim: int
@@ -43,6 +53,11 @@ class SacConfig:
     wd_q: float = 0.0
     wd_alpha: float = 0.0
     max_grad_norm: float = 1e5
+    non_equidistant_time: bool = False          # losses.py:39-59, 90-98
+    continuous_discounting: float = 0.0
+    min_time_between_switches: float = 0.0
+    max_time_between_switches: float = 0.0
+    env_dt: float = 0.0
 
     @property
     def P(self):
@@ -92,7 +107,15 @@ def losses(cfg: SacConfig, params: torch.Tensor, target_q: torch.Tensor, batch: 
     na = nets.postprocess(nz)
     next_q = nets.q_forward(target_q, cfg.q_dims, nobs, na, cfg.q_act)
     next_v = next_q.min(dim=-1).values - alpha_c * nlp
-    target = (t["reward"] * cfg.reward_scaling + t["discount"] * cfg.discounting * next_v).detach()
+    if cfg.non_equidistant_time:                                                      # losses.py:90-96
+        pseudo = t["action"][..., -1]
+        t_lower, t_upper = cfg.min_time_between_switches, cfg.max_time_between_switches
+        tfa = (t_upper - t_lower) / 2 * pseudo + (t_upper + t_lower) / 2
+        tfa = floor_divide(tfa, cfg.env_dt) * cfg.env_dt
+        discounting = torch.exp(-cfg.continuous_discounting * tfa)
+    else:
+        discounting = cfg.discounting
+    target = (t["reward"] * cfg.reward_scaling + t["discount"] * discounting * next_v).detach()
     q_error = (q_old - target[:, None]) * (1 - t["truncation"])[:, None]
     critic_loss = 0.5 * (q_error ** 2).mean()
 

@@ -16,6 +16,8 @@ def compute_gae(truncation, termination, rewards, values, bootstrap_value, disco
     values = np.asarray(values, dtype)
     bootstrap_value = np.asarray(bootstrap_value, dtype)
     T = truncation.shape[0]
+    discounting = np.asarray(discounting, dtype)                                         # scalar, or [T,B]: the per-step discount
+    per_step = discounting.ndim > 0                                                      # of non_equidistant_time (losses_new.py:181-226)
     truncation_mask = 1 - truncation                                                     # :153
     values_t_plus_1 = np.concatenate([values[1:], bootstrap_value[None]], axis=0)       # :155-156
     deltas = rewards + discounting * (1 - termination) * values_t_plus_1 - values       # :157
@@ -23,7 +25,8 @@ def compute_gae(truncation, termination, rewards, values, bootstrap_value, disco
     acc = np.zeros_like(bootstrap_value)                                                 # :160
     vs_minus_v_xs = np.zeros_like(values)
     for t in range(T - 1, -1, -1):                                                       # reverse scan :169-174
-        acc = deltas[t] + discounting * (1 - termination[t]) * truncation_mask[t] * gae_lambda * acc   # :166
+        disc_t = discounting[t] if per_step else discounting
+        acc = deltas[t] + disc_t * (1 - termination[t]) * truncation_mask[t] * gae_lambda * acc   # :166
         vs_minus_v_xs[t] = acc
     vs = vs_minus_v_xs + values                                                          # :176
     vs_t_plus_1 = np.concatenate([vs[1:], bootstrap_value[None]], axis=0)               # :178-179

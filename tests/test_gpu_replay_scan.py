@@ -187,3 +187,22 @@ def test_gae_full_size_properties(dev):
     v_next = np.concatenate([val[1:], boot[None]], 0)
     td = (rew + 0.99 * (1 - term) * v_next - val) * (1 - trunc) + val
     np.testing.assert_allclose(vs0.cpu().numpy().T, td, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("T,B,time_major", [(5, 37, False), (40, 130, False), (5, 300, True), (100, 9, False)])
+def test_gae_per_element_discount_parity(dev, T, B, time_major):
+    """N1: compute_gae with a per-step discount array (ppo/losses_new.py:181-226) vs the numpy restatement (1e-5)."""
+    from mbpo import ops
+    from oracle import scans
+    rng = np.random.default_rng(T * 1000 + B)
+    trunc = (rng.random((T, B)) < 0.1).astype(np.float32)
+    term = ((rng.random((T, B)) < 0.05) * (1 - trunc)).astype(np.float32)
+    rew, val = rng.standard_normal((T, B)).astype(np.float32), rng.standard_normal((T, B)).astype(np.float32)
+    boot = rng.standard_normal(B).astype(np.float32)
+    disc = np.exp(-0.9 * 0.05 * rng.integers(1, 16, (T, B))).astype(np.float32)
+    vs_ref, adv_ref = scans.compute_gae(trunc, term, rew, val, boot, disc.astype(np.float64), 0.95)
+    lay = (lambda a: torch.from_numpy(a).to(dev).contiguous()) if time_major else (lambda a: torch.from_numpy(a.T.copy()).to(dev))
+    vs, adv = ops.gae_scan(lay(trunc), lay(term), lay(rew), lay(val), torch.from_numpy(boot).to(dev), lay(disc), 0.95, time_major)
+    back = (lambda t: t.cpu().numpy()) if time_major else (lambda t: t.cpu().numpy().T)
+    np.testing.assert_allclose(back(vs), vs_ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(back(adv), adv_ref, rtol=1e-5, atol=1e-5)

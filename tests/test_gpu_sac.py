@@ -185,3 +185,25 @@ def test_fused_reduce_apply_matches_two_launch_path(dev):
     for name in ("params", "target_q", "adam_m", "adam_v", "grads", "metrics"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert int(a.workspace[-4:].view(torch.int32).abs().sum()) == 0      # counters re-armed
+
+
+def test_sac_non_equidistant_time_target(dev):
+    """N1 (sac/losses.py:90-98): the critic target's discount is exp(-continuous_discounting * t) per sample, t decoded from the
+    last action component, affinely mapped to [min, max]_time_between_switches and floored to multiples of env_dt."""
+    X, U, B = 4, 2, 96
+    kw = dict(non_equidistant_time=True, continuous_discounting=0.9, min_time_between_switches=0.05, max_time_between_switches=0.75,
+              env_dt=0.05)
+    cfg, st, batch, noise, nm, ns = _make(X, U, (64, 64, 64), B, 4, True, reward_scaling=1.5, lr_policy=3e-4, lr_q=3e-4,
+                                           lr_alpha=3e-4, **kw)
+    g_ref, (cl, ac, al) = osac.grads(cfg, st.params, st.target_q, batch, *noise, nm, ns)
+    cfg_eq = osac.SacConfig(**{**cfg.__dict__, "non_equidistant_time": False})
+    g_eq, _ = osac.grads(cfg_eq, st.params, st.target_q, batch, *noise, nm, ns)
+    P, Q = cfg.P, cfg.Q
+    assert float((g_ref[P:P + 2 * Q] - g_eq[P:P + 2 * Q]).abs().max()) > 1e-4          # the option really changes the critic loss
+    up = _updater(dev, cfg, B, **kw)
+    up.load_state(st.params.to(dev), st.target_q.to(dev))
+    up.sgd_step(batch.to(dev), nm.to(dev), ns.to(dev), *[n.to(dev) for n in noise])
+    torch.cuda.synchronize()
+    g = up.grads.cpu()
+    torch.testing.assert_close(g, g_ref, atol=2e-6, rtol=2e-4)
+    np.testing.assert_allclose(up.metrics.cpu().tolist()[:3], [cl, ac, al], rtol=5e-5, atol=2e-6)
