@@ -8,7 +8,7 @@
 // LDS and written to HBM as one contiguous block per step.
 // Per (env, step) HBM traffic is one row write (row_len*4 B) — the kernel is MFMA/latency bound by design.
 #include "common.hpp"
-#include "wave_mlp.hpp"
+#include "chain_run.hpp"
 #include <string.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -437,6 +437,321 @@ __global__ void __launch_bounds__(512) k_model_rollout(RolloutArgs A) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// H == 64: the rollout on phase runners (chain_run.hpp).  16 waves per 16-env tile:
+//   policy phase   waves 0..3 walk the policy chain in lockstep (SP = 4), one barrier per layer;
+//   model phase    waves 2e, 2e+1 walk member e's chain (SP = 2), up to 8 members side by side, one barrier per layer —
+//                  5 members x 64 MFMAs per layer is 2560 MFMA cycles per SIMD and layer: this phase is fp32-MFMA-throughput
+//                  bound on the CU, everything else is arranged to stay out of its way;
+//   next-layer weights are requested one step ahead (first layers before the preceding bookkeeping section);
+//   bookkeeping sections index with r = idx & 15 (no integer division), use the hardware transcendentals for the NormalTanh
+//   sample, and the transition rows are double-buffered so a step's write-out overlaps the next step's first section.
+// Barriers per env step (action_repeat 1): policy layers + model layers + 4.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ro_fexp(float x) { return __builtin_amdgcn_exp2f(1.44269504088896340736f * x); }
+__device__ __forceinline__ float ro_flog(float x) { return 0.69314718055994530942f * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float ro_fsoftplus(float x) { return fmaxf(x, 0.0f) + ro_flog(1.0f + ro_fexp(-fabsf(x))); }
+__device__ __forceinline__ float ro_ftanh(float x) {
+  const float e = ro_fexp(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
+  return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+struct RolloutArgs64 {
+  RolloutArgs a;
+  NetShape sh_pi, sh_dyn;
+  unsigned long long *stamps;   // measurement hook (mbpo_debug_set_rollout_stamps): s_memtime at the section boundaries of tile 0, step 1
+};
+
+static unsigned long long *g_ro_stamps = nullptr;
+extern "C" int mbpo_debug_set_rollout_stamps(void *buf) {
+  g_ro_stamps = (unsigned long long *)buf;
+  return MBPO_OK;
+}
+#define RO_STAMP(i)                                                                  \
+  if (AA.stamps && blockIdx.x == 0 && s == 1 && tid_ == 0) {                           \
+    unsigned long long t_;                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+    AA.stamps[i] = t_;                                                               \
+  }
+
+__global__ void __launch_bounds__(1024) k_model_rollout64(RolloutArgs64 AA) {
+  extern __shared__ __align__(16) float smem[];
+  const RolloutArgs &A = AA.a;
+  constexpr int HT = 4;
+  constexpr int MAXC = 8;   // member chains side by side (2 waves each)
+  const int tid_ = threadIdx.x, nthreads = 1024;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+  const int X = A.x_dim, U = A.u_dim, D = A.row_len;
+  const int E = (A.system_kind == MBPO_SYS_ENSEMBLE) ? A.dyn.n_nets : 0;
+  const long long N = A.n_envs;
+  const int AR = A.action_repeat;
+  const int ld_x = A.ld_x, ld_xu = A.ld_xu, ld_h = A.ld_h, ld_y = A.ld_y;
+  const int T = 16 * ld_h;
+  const int PL = A.actions ? 0 : AA.sh_pi.L, DL = AA.sh_dyn.L;
+
+  // ---- LDS carve (floats) ----
+  float *s_obs = smem;                           // [16][ld_x]  current raw obs
+  float *s_first = s_obs + 16 * ld_x;            // [16][ld_x]
+  float *s_pin = s_first + 16 * ld_x;            // [16][ld_x]  normalised obs (policy input)
+  float *s_xu = s_pin + 16 * ld_x;               // [16][ld_xu] dynamics input [x,u]
+  float *s_pp = s_xu + 16 * ld_xu;               // [n_chains][2] hidden tiles (ping-pong per chain)
+  float *s_y = s_pp + A.n_chains * 2 * T;        // [n_out][16][ld_y]
+  const int D4 = (D + 3) & ~3;
+  float *s_rows = s_y + A.n_out * 16 * ld_y;     // [2][16][D]  transition rows, double-buffered over steps
+  float *s_steps = s_rows + 2 * 16 * D4;         // [2][16]     double-buffered over steps
+  float *s_done = s_steps + 32;                  // [16]
+  float *s_rew = s_done + 16;                    // [16]
+  float *s_scr = s_rew + 16;                     // [16 * max(X, U)] scratch: next state / per-dim log-prob
+  const int SC = X > U ? X : U;
+  (void)SC;
+
+  const unsigned long long rng_off = A.offset + (A.offset_dev ? (unsigned long long)A.offset_dev[0] : 0ull);
+  const long long n_tiles = (N + 15) >> 4;
+  const int mchain = wave >> 1, msub = wave & 1;   // member-phase role of this wave
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long long env0 = tile * 16;
+    {
+      const int tid = opaque(tid_);
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        const int r = idx & 15, c = idx >> 4;
+        const long long env = env0 + r;
+        float o = 0.f, f = 0.f;
+        if (env < N) {
+          o = A.obs[env * X + c];
+          f = A.first_obs[env * X + c];
+        }
+        s_obs[r * ld_x + c] = o;
+        s_first[r * ld_x + c] = f;
+      }
+      if (tid < 16) {
+        const long long env = env0 + tid;
+        s_steps[tid] = env < N ? A.steps[env] : 0.f;
+        s_done[tid] = env < N ? A.done[env] : 0.f;
+      }
+    }
+    __syncthreads();
+
+#pragma nounroll
+    for (int s = 0; s < A.n_steps; ++s) {
+      const int tid = opaque(tid_), lane = tid & 63;
+      float *s_row = s_rows + (s & 1) * 16 * D4;
+      float *steps_cur = s_steps + (s & 1) * 16, *steps_nxt = s_steps + ((s + 1) & 1) * 16;
+      WSet<HT, 4> Rp;
+      WSet<HT, 2> Rm;
+      RO_STAMP(0);
+      // ---- section A: policy input, obs into the dynamics input and the row; open-loop actions ----
+      if (!A.actions && wave < 4) chain_fwd_prefetch<HT, 4>(Rp, AA.sh_pi, A.policy.params, wave, lane);
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        const int r = idx & 15, c = idx >> 4;
+        const float o = s_obs[r * ld_x + c];
+        s_pin[r * ld_x + c] = A.norm_mean ? (o - A.norm_mean[c]) / A.norm_std[c] : o;   // running_statistics.normalize
+        s_xu[r * ld_xu + c] = o;
+        s_row[r * D + c] = o;                                                            // Transition.observation (acting.py:47)
+      }
+      if (A.actions) {
+        // open-loop actions (rollout_actions, optimizer_utils.py:26-38): no policy
+        for (int idx = tid; idx < 16 * U; idx += nthreads) {
+          const int r = idx & 15, d = idx >> 4;
+          const long long env = env0 + r;
+          const float a = env < N ? A.actions[((long long)s * N + env) * U + d] : 0.f;
+          s_xu[r * ld_xu + X + d] = a;
+          s_row[r * D + X + d] = a;
+        }
+      }
+      __syncthreads();
+      RO_STAMP(1);
+      // ---- policy chain -> logits in s_y[0] ----
+      if (!A.actions) {
+        if (wave < 4) chain_fwd_run<HT, 4>(AA.sh_pi, A.policy.params, s_pin, ld_x, s_pp, s_pp + T, nullptr, nullptr, s_y, ld_y, ld_h, PL, wave, lane, Rp);
+        else chain_idle_run(PL);
+      }
+      RO_STAMP(2);
+      const bool mactive = (E > 0) && (mchain < A.n_chains) && (mchain < E);
+      if (mactive) chain_fwd_prefetch<HT, 2>(Rm, AA.sh_dyn, A.dyn.params + (long long)mchain * A.dyn.net_stride, msub, lane);
+      // ---- section B: NormalTanh sample (parametric_distribution.py:97-124) + AutoReset pre-step (training.py:119-124) ----
+      if (!A.actions) {
+        for (int idx = tid; idx < 16 * U; idx += nthreads) {
+          const int r = idx & 15, d = idx >> 4;
+          const long long env = env0 + r;
+          const float loc = s_y[r * ld_y + d], raw = s_y[r * ld_y + U + d];
+          const float sigma = ro_fsoftplus(raw) + 0.001f;
+          float eps = 0.f;
+          if (!A.deterministic && env < N) {
+            const long long nidx = ((long long)s * N + env) * U + d;
+            eps = A.policy_noise ? A.policy_noise[nidx]
+                                 : philox_normal(A.seed, rng_off, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
+          }
+          const float z = loc + sigma * eps;
+          float a = ro_ftanh(z);
+          if (A.action_clip > 0.f) a = fminf(fmaxf(a, -A.action_clip), A.action_clip);
+          s_xu[r * ld_xu + X + d] = a;
+          s_row[r * D + X + d] = a;
+          if (A.ppo_extras) {
+            // log N(z; loc, sigma) - log|d tanh/dz|, per action dim; summed in section D
+            const float lp = -0.5f * eps * eps - ro_flog(sigma) - 0.91893853320467274178f;
+            const float ldj = 2.0f * (0.69314718055994530942f - z - ro_fsoftplus(-2.0f * z));
+            s_row[r * D + 2 * X + U + 2 + 1 + d] = z;               // raw_action
+            s_scr[16 * X + r * U + d] = lp - ldj;                   // per-dim log-prob (behind the next-state scratch)
+          }
+        }
+      }
+      if (tid < 16) {
+        // AutoReset: steps <- 0 where previously done; done <- 0
+        if (s_done[tid] != 0.f) steps_cur[tid] = 0.f;
+        s_done[tid] = 0.f;
+        s_rew[tid] = 0.f;
+      }
+      __syncthreads();
+      RO_STAMP(3);
+
+      // ---- EpisodeWrapper inner scan over action_repeat (training.py:91-97) ----
+#pragma nounroll
+      for (int ar = 0; ar < AR; ++ar) {
+        if (E > 0) {
+#pragma nounroll
+          for (int e0 = 0; e0 < E; e0 += A.n_chains) {
+            const int e = e0 + mchain;
+            const bool act = (mchain < A.n_chains) && (e < E);
+            if (act && (e0 > 0 || ar > 0))
+              chain_fwd_prefetch<HT, 2>(Rm, AA.sh_dyn, A.dyn.params + (long long)e * A.dyn.net_stride, msub, lane);
+            if (act)
+              chain_fwd_run<HT, 2>(AA.sh_dyn, A.dyn.params + (long long)e * A.dyn.net_stride, s_xu, ld_xu, s_pp + mchain * 2 * T,
+                                   s_pp + mchain * 2 * T + T, nullptr, nullptr, s_y + e * 16 * ld_y, ld_y, ld_h, DL, msub, lane, Rm);
+            else
+              chain_idle_run(DL);
+          }
+        }
+        RO_STAMP(4);
+        // ---- section C: reward on the pre-step (x, u); next state into the scratch ----
+        if (tid < 16) {
+          const int r = tid;
+          const float *xr = s_xu + r * ld_xu;
+          float rew;
+          if (A.reward_kind == MBPO_REWARD_PENDULUM) {
+            rew = pendulum_reward(xr, xr[X], A.reward_params);
+          } else {
+            const float *tp = A.reward_params, *qp = tp + X, *rp = qp + X;
+            float cx = 0.f, cu = 0.f;
+            for (int c = 0; c < X; ++c) { float dd = xr[c] - tp[c]; cx += qp[c] * (dd * dd); }
+            for (int d = 0; d < U; ++d) { float uu = xr[X + d]; cu += rp[d] * (uu * uu); }
+            rew = -cx - cu;
+          }
+          s_rew[r] += rew;
+          if (A.system_kind == MBPO_SYS_PENDULUM) {
+            float xn[3];
+            pendulum_step(xr, xr[X], A.sys_params, xn);
+            s_scr[r * X + 0] = xn[0];
+            s_scr[r * X + 1] = xn[1];
+            s_scr[r * X + 2] = xn[2];
+          }
+        }
+        if (A.system_kind != MBPO_SYS_PENDULUM) {
+          for (int idx = tid; idx < 16 * X; idx += nthreads) {
+            const int r = idx & 15, c = idx >> 4;
+            const long long env = env0 + r;
+            const float base = A.ens_predict_delta ? s_xu[r * ld_xu + c] : 0.f;
+            float v;
+            if (A.ens_mode == MBPO_ENS_MEAN) {
+              float acc = 0.f;
+              for (int e = 0; e < E; ++e) acc += s_y[(e * 16 + r) * ld_y + c];
+              v = base + acc / (float)E;
+            } else {
+              int mem = 0;
+              const long long eidx = ((long long)s * AR + ar) * N + env;
+              if (env < N) {
+                if (A.ens_mode == MBPO_ENS_TSINF) mem = (int)(env % E);
+                else mem = A.member_idx ? A.member_idx[eidx]
+                                        : philox_randint(A.seed, rng_off, MBPO_STREAM_MEMBER, (unsigned long long)eidx, 0, E);
+              }
+              const float mu = s_y[(mem * 16 + r) * ld_y + c];
+              v = base + mu;
+              if (A.ens_sample_noise && env < N) {
+                const float sg = softplus_f(s_y[(mem * 16 + r) * ld_y + X + c]) + A.ens_min_std;
+                const long long nidx = eidx * X + c;
+                const float eps = A.model_noise ? A.model_noise[nidx]
+                                                : philox_normal(A.seed, rng_off, MBPO_STREAM_MODEL_NOISE, (unsigned long long)nidx);
+                v += sg * eps;
+              }
+            }
+            s_scr[r * X + c] = v;
+          }
+        }
+        __syncthreads();
+        if (ar + 1 < AR) {   // the next inner step starts from the new state
+          for (int idx = tid; idx < 16 * X; idx += nthreads) {
+            const int r = idx & 15, c = idx >> 4;
+            s_xu[r * ld_xu + c] = s_scr[r * X + c];
+          }
+          __syncthreads();
+        }
+      }
+
+      RO_STAMP(5);
+      // ---- section D: EpisodeWrapper / AutoReset post-step (training.py:98-107, 126-137) + Transition (acting.py:46-55) ----
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        const int r = idx & 15, c = idx >> 4;
+        const float st = steps_cur[r] + (float)AR;
+        const bool dn = st >= (float)A.episode_length;
+        const float v = dn ? s_first[r * ld_x + c] : s_scr[r * X + c];
+        s_obs[r * ld_x + c] = v;
+        s_row[r * D + X + U + 2 + c] = v;  // next_observation = nstate.obs (post auto-reset)
+      }
+      if (tid < 16) {
+        const int r = tid;
+        const float st = steps_cur[r] + (float)AR;
+        const float sys_done = 0.f;  // SystemState.done default (base_systems.py:25)
+        const float dn = (st >= (float)A.episode_length) ? 1.f : sys_done;
+        const float trunc = (st >= (float)A.episode_length) ? (1.f - sys_done) : 0.f;
+        steps_nxt[r] = st;
+        s_done[r] = dn;
+        s_row[r * D + X + U] = s_rew[r];
+        s_row[r * D + X + U + 1] = 1.f - dn;
+        s_row[r * D + D - 1] = trunc;
+        if (A.ppo_extras) {
+          float lp = 0.f;
+          for (int d = 0; d < U; ++d) lp += s_scr[16 * X + r * U + d];
+          s_row[r * D + 2 * X + U + 2] = lp;  // log_prob (summed over action dims)
+        }
+      }
+      __syncthreads();
+      RO_STAMP(6);
+      // ---- write the tile's 16 rows (the next step's section A works on the other row buffer) ----
+      if (A.env_major) {
+        for (int r = wave; r < 16; r += 16) {
+          const long long env = env0 + r;
+          if (env < N)
+            for (int c = lane; c < D; c += 64) A.transitions[(env * A.n_steps + s) * D + c] = s_row[r * D + c];
+        }
+      } else {
+        const long long nvalid = (N - env0 < 16 ? N - env0 : 16) * D;
+        float *dst = A.transitions + ((long long)s * N + env0) * D;
+        for (int idx = tid; idx < nvalid; idx += nthreads) dst[idx] = s_row[idx];
+      }
+      RO_STAMP(7);
+    }
+    __syncthreads();
+    // ---- write back env state ----
+    {
+      const int tid = opaque(tid_);
+      const float *steps_fin = s_steps + (A.n_steps & 1) * 16;
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        const int r = idx & 15, c = idx >> 4;
+        const long long env = env0 + r;
+        if (env < N) A.obs[env * X + c] = s_obs[r * ld_x + c];
+      }
+      if (tid < 16) {
+        const long long env = env0 + tid;
+        if (env < N) {
+          A.steps[env] = steps_fin[tid];
+          A.done[env] = s_done[tid];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   MBPO_REQUIRE(d, MBPO_ERR_ARG, "model_rollout: null descriptor");
   MBPO_REQUIRE(d->x_dim > 0 && d->u_dim > 0, MBPO_ERR_ARG, "model_rollout: x_dim/u_dim must be positive");
@@ -515,7 +830,9 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   A.ld_h = H + 4;
   int ymax = 2 * U > dyn_out ? 2 * U : dyn_out;
   A.ld_y = up4(ymax) + 4;
-  const size_t fixed_f = 3ull * 16 * A.ld_x + 16ull * A.ld_xu + (size_t)A.n_out * 16 * A.ld_y + 16ull * up4(d->row_len) + 48;
+  const int scr = 16 * (X + U) + 16;
+  const size_t fixed_f = 3ull * 16 * A.ld_x + 16ull * A.ld_xu + (size_t)A.n_out * 16 * A.ld_y + 2ull * 16 * up4(d->row_len) + 80 +
+                         (size_t)up4(scr);
   A.n_chains = pick_chains(E, fixed_f, A.ld_h);
   MBPO_REQUIRE(A.n_chains >= 1, MBPO_ERR_UNSUPPORTED, "model_rollout: shapes do not fit 160 KiB of LDS");
   size_t lds = (fixed_f + 2ull * A.n_chains * 16 * A.ld_h) * sizeof(float);
@@ -529,7 +846,21 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
     if (rc != MBPO_OK) return rc;                                            \
     hipLaunchKernelGGL(k_model_rollout<HH>, dim3(grid), dim3(n_waves * 64), lds, st, A); \
   }
-  if (H == 64) LAUNCH_RO(64) else if (H == 128) LAUNCH_RO(128) else LAUNCH_RO(256)
+  if (H == 64) {
+    RolloutArgs64 AA;
+    AA.a = A;
+    AA.stamps = g_ro_stamps;
+    if (has_policy) AA.sh_pi = NetShape{A.policy.dims[0], A.policy.n_layers, A.policy.dims[A.policy.n_layers], A.policy.act};
+    else AA.sh_pi = NetShape{X, 0, 2 * U, 0};
+    if (E > 0) AA.sh_dyn = NetShape{A.dyn.dims[0], A.dyn.n_layers, A.dyn.dims[A.dyn.n_layers], A.dyn.act};
+    else AA.sh_dyn = NetShape{X + U, 0, X, 0};
+    if (AA.a.n_chains > 8) AA.a.n_chains = 8;   // 16 waves = 8 member chains of 2 waves
+    if (AA.a.n_chains < 1) AA.a.n_chains = 1;
+    lds = (fixed_f + 2ull * (AA.a.n_chains > 1 ? AA.a.n_chains : 1) * 16 * A.ld_h) * sizeof(float);
+    rc = mbpo_ensure_lds<k_model_rollout64>(lds, "model_rollout");
+    if (rc != MBPO_OK) return rc;
+    hipLaunchKernelGGL(k_model_rollout64, dim3(grid), dim3(1024), lds, st, AA);
+  } else if (H == 128) LAUNCH_RO(128) else LAUNCH_RO(256)
 #undef LAUNCH_RO
   MBPO_CHECK_LAUNCH("model_rollout");
   return MBPO_OK;
