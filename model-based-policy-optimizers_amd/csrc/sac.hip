@@ -427,15 +427,31 @@ __device__ __forceinline__ void group_sumsq(float g, int i, int P, int Q2, int N
   if (tid < 3) ss_part[blockIdx.x * 3 + tid] = s_ss[tid][0] + s_ss[tid][1] + s_ss[tid][2] + s_ss[tid][3];
 }
 
+// sum over the tiles' slabs in tile order, the loads of 8 tiles in flight at a time (a plain `g += slab[t]` loop with a runtime
+// trip count issues load, wait, add, load, ...: 16 dependent HBM/L2 round trips)
+__device__ __forceinline__ float slab_sum(const float *slab, long long stride, int n_tiles, int i) {
+  float g = 0.f;
+  int t = 0;
+  for (; t + 8 <= n_tiles; t += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = slab[(long long)(t + k) * stride + i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g += v[k];
+  }
+  for (; t < n_tiles; ++t) g += slab[(long long)t * stride + i];
+  return g;
+}
+
 __global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
   const int NP = A.P + A.Q2 + 1;
   const int i = blockIdx.x * 256 + threadIdx.x;
   float g = 0.f;
   if (i < A.P) {
-    for (int t = 0; t < A.n_tiles; ++t) g += A.slab_pi[(long long)t * A.P + i];
+    g = slab_sum(A.slab_pi, A.P, A.n_tiles, i);
   } else if (i < A.P + A.Q2) {
     const int j = i - A.P;
-    for (int t = 0; t < A.n_tiles; ++t) g += A.slab_q[(long long)t * A.Q2 + j];
+    g = slab_sum(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
     float ce = 0.f, ac = 0.f, al = 0.f;
     for (int t = 0; t < A.n_tiles; ++t) {
@@ -467,10 +483,10 @@ __global__ void __launch_bounds__(256) k_sac_reduce_push(SacReduceArgs A, P2pDev
   const unsigned epoch = X.epoch[0];
   float g = 0.f;
   if (i < A.P) {
-    for (int t = 0; t < A.n_tiles; ++t) g += A.slab_pi[(long long)t * A.P + i];
+    g = slab_sum(A.slab_pi, A.P, A.n_tiles, i);
   } else if (i < A.P + A.Q2) {
     const int j = i - A.P;
-    for (int t = 0; t < A.n_tiles; ++t) g += A.slab_q[(long long)t * A.Q2 + j];
+    g = slab_sum(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
     float ce = 0.f, ac = 0.f, al = 0.f;
     for (int t = 0; t < A.n_tiles; ++t) {
@@ -526,6 +542,13 @@ struct SacApplyArgs {
 __global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
   __shared__ float s_scale[3];
   const int tid = threadIdx.x;
+  // the element's own operands are requested first: their latency overlaps the norm reduction below
+  const int NP_ = A.P + A.Q2 + 1;
+  const int i_ = blockIdx.x * 256 + tid;
+  const bool in_ = i_ < NP_;
+  const float g_in = in_ ? A.grads[i_] : 0.f, m_in = in_ ? A.adam_m[i_] : 0.f, v_in = in_ ? A.adam_v[i_] : 0.f,
+              p_in = in_ ? A.params[i_] : 0.f;
+  const float count_in = A.step_count[0];
   {
     // wave w < 3 reduces optimizer group w's sum-of-squares partials (fixed shuffle tree -> deterministic)
     const int w = tid >> 6, lane = tid & 63;
@@ -543,20 +566,20 @@ __global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
   if (i >= NP) return;
   const int grp = (i < A.P) ? 0 : (i < A.P + A.Q2 ? 1 : 2);
   const float gnorm = s_scale[grp];
-  float g = A.grads[i] * A.grad_scale;
+  float g = g_in * A.grad_scale;
   if (!(gnorm < A.max_norm)) g = (g / gnorm) * A.max_norm;
   // [3P optax.adamw] scale_by_adam(b1=.9,b2=.999,eps=1e-8) -> add_decayed_weights(wd) -> scale(-lr)
   const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-  const float count = A.step_count[0];  // already incremented for this step
+  const float count = count_in;  // already incremented for this step
   // optax forms (1 - decay) in Python double and only then casts: f32(0.1), f32(0.001) — not 1.f - 0.999f
-  const float mu = b1 * A.adam_m[i] + 0.1f * g;
-  const float nu = b2 * A.adam_v[i] + 0.001f * (g * g);
+  const float mu = b1 * m_in + 0.1f * g;
+  const float nu = b2 * v_in + 0.001f * (g * g);
   A.adam_m[i] = mu;
   A.adam_v[i] = nu;
   const float mu_hat = mu / (1.f - powf(b1, count));
   const float nu_hat = nu / (1.f - powf(b2, count));
   float upd = mu_hat / (sqrtf(nu_hat) + eps);
-  const float p = A.params[i];
+  const float p = p_in;
   upd = upd + A.wd[grp] * p;
   const float pn = p + (-A.lr[grp]) * upd;  // optax.apply_updates: p + u, u = -lr * upd
   A.params[i] = pn;
@@ -595,10 +618,10 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacFusedArgs F) {
   const float count = F.step_count[0] + 1.0f;   // every block reads the old count before it arrives anywhere
   float g = 0.f;
   if (i < A.P) {
-    for (int t = 0; t < A.n_tiles; ++t) g += A.slab_pi[(long long)t * A.P + i];
+    g = slab_sum(A.slab_pi, A.P, A.n_tiles, i);
   } else if (i < A.P + A.Q2) {
     const int j = i - A.P;
-    for (int t = 0; t < A.n_tiles; ++t) g += A.slab_q[(long long)t * A.Q2 + j];
+    g = slab_sum(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
     float ce = 0.f, ac = 0.f, al = 0.f;
     for (int t = 0; t < A.n_tiles; ++t) {
