@@ -9,7 +9,7 @@
 //  * a lone wave issues ~1 instruction per 4-5 cycles, so a layer step costs what its instruction count costs:
 //    32 MFMAs are 1024 cycles, everything else has to stay in the low hundreds of instructions.
 // So: shapes are kernel-argument scalars (NetShape), the wave's role comes from readfirstlane, each runner is ONE loop whose
-// body holds each layer routine once, weights are requested one layer ahead (WPre, wave_mlp.hpp), and a kernel calls each
+// body holds each layer routine once, weights are requested one layer ahead (WSet, below), and a kernel calls each
 // runner from a single call site.  Waves of different chains run different runners between the same barriers: every
 // runner executes exactly `n_steps` workgroup barriers.
 #pragma once
@@ -27,14 +27,6 @@ struct NetShape {
 __device__ __forceinline__ int opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
-}
-
-__device__ __forceinline__ NetShape net_shape(const MlpDev &m) { return NetShape{m.dims[0], m.n_layers, m.dims[m.n_layers], m.act}; }
-
-// floats of layer l's weight+bias block, and the flat offset of layer l (hidden width H)
-__device__ __forceinline__ int layer_floats(const NetShape &s, int H, int l) {
-  const int K = l == 0 ? s.K_in : H, N = l == s.L - 1 ? s.N_out : H;
-  return K * N + N;
 }
 
 // ------------------------------------------------------------------------------------------------ weight prefetch

@@ -710,455 +710,5 @@ __device__ __forceinline__ void gen_dense_wgrad(const float *x, int ldx, int k_l
   }
 }
 
-// =================================================================================================
-// Weight prefetch, one layer ahead.  A workgroup touches every weight exactly once per tile and the L2 is cold at kernel
-// start (the optimizer kernel just rewrote the parameters), so each layer's first weight load is an Infinity-Cache/HBM
-// round trip (~550-900 cycles) and the bias load in the epilogue a second one: with ~16 dependent layers per sgd_step
-// that was more than half of the kernel's time.  Here the lane's whole share of the NEXT layer's weight slice and bias
-// (KS*CT + CT registers: 34 at H=64, SP=2) is requested before the current layer's MFMAs are issued; plain global loads
-// stay in flight across __syncthreads() (cdna_hip_programming.md §5 "Pipelining across barriers").
-// One register image serves the forward (w[s][t], k-step major) and the dgrad (w[t][n], output-tile major) shapes.
-// Shapes without a prefetch form (kind WP_NONE) fall back to the self-loading wave_dense_* paths.
-// =================================================================================================
-enum { WP_SKIP = -1, WP_NONE = 0, WP_IN = 1, WP_FULL = 2, WP_OUT1 = 3, WP_OUT2 = 4, WP_OUT4 = 5, WP_DX1 = 6 };
-
-template <int HT, int SP>
-struct WPre {
-  static constexpr int KS = 4 * HT, CT = HT / SP;
-  static constexpr bool ON = (KS * CT <= 64);   // wider layers would not fit two images in 256 VGPRs: they self-load (WP_NONE)
-  float w[ON ? KS * CT : 1];
-  float b[CT];
-  int kind;
-};
-
-template <int NV>
-__device__ __forceinline__ void ldg_vec(const float *p, float *v) {
-  if constexpr (NV % 4 == 0) {
-#pragma unroll
-    for (int c = 0; c < NV / 4; ++c) {
-      f4u t = *reinterpret_cast<const f4u *>(p + 4 * c);
-      v[4 * c + 0] = t[0]; v[4 * c + 1] = t[1]; v[4 * c + 2] = t[2]; v[4 * c + 3] = t[3];
-    }
-  } else if constexpr (NV == 2) {
-    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-    f2u t = *reinterpret_cast<const f2u *>(p);
-    v[0] = t[0]; v[1] = t[1];
-  } else {
-#pragma unroll
-    for (int c = 0; c < NV; ++c) v[c] = p[c];
-  }
-}
-
-// ---- forward ---------------------------------------------------------------------------------------------------
-template <int HT, int SP, int NTL>
-__device__ __forceinline__ void fwd_load_out(WPre<HT, SP> &R, const float *__restrict__ W, const float *__restrict__ bias, int N,
-                                             int lane) {
-  constexpr int KS = 4 * HT;
-  const int r = lane & 15, g = lane >> 4;
-  int ncol[NTL];
-#pragma unroll
-  for (int t = 0; t < NTL; ++t) ncol[t] = (NTL * r + t < N) ? NTL * r + t : 0;
-#pragma unroll
-  for (int s = 0; s < KS; ++s)
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) R.w[s * NTL + t] = W[(g * KS + s) * N + ncol[t]];
-#pragma unroll
-  for (int t = 0; t < NTL; ++t) R.b[t] = bias[ncol[t]];
-}
-
-template <int HT, int SP>
-__device__ __forceinline__ void fwd_prefetch(WPre<HT, SP> &R, const MlpDev &m, const float *__restrict__ params, int l, int sub,
-                                             int lane) {
-  constexpr int KS = 4 * HT, CT = HT / SP;
-  R.kind = WP_SKIP;
-  if (l >= m.n_layers) return;
-  if constexpr (!WPre<HT, SP>::ON) {
-    R.kind = (l < m.n_layers - 1 || sub == 0) ? WP_NONE : WP_SKIP;
-    return;
-  }
-  const int r = lane & 15, g = lane >> 4;
-  const int K = m.dims[l], N = m.dims[l + 1];
-  const float *W = params + m.w_off[l], *bias = params + m.b_off[l];
-  if (l < m.n_layers - 1) {
-    const int c0 = sub * 16 * CT;
-    if (K == 16 * HT) {
-      R.kind = WP_FULL;
-      const float *wr = W + (g * KS) * N + c0 + CT * r;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) ldg_vec<CT>(wr + s * N, &R.w[s * CT]);
-      ldg_vec<CT>(bias + c0 + CT * r, R.b);
-    } else if (K <= 32) {
-      R.kind = WP_IN;
-      const int kc = (K + 3) >> 2;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const int k = g * kc + s;
-        const int kk = ((s < kc) && (k < K)) ? k : 0;
-        ldg_vec<CT>(W + kk * N + c0 + CT * r, &R.w[s * CT]);
-      }
-      ldg_vec<CT>(bias + c0 + CT * r, R.b);
-    } else {
-      R.kind = WP_NONE;
-    }
-  } else if (sub == 0) {
-    R.kind = WP_NONE;
-    if (K == 16 * HT) {
-      if (N <= 16) {
-        R.kind = WP_OUT1;
-        fwd_load_out<HT, SP, 1>(R, W, bias, N, lane);
-      } else if (N <= 32 && CT >= 2) {
-        if constexpr (CT >= 2) {
-          R.kind = WP_OUT2;
-          fwd_load_out<HT, SP, 2>(R, W, bias, N, lane);
-        }
-      } else if (N <= 64 && CT >= 4) {
-        if constexpr (CT >= 4) {
-          R.kind = WP_OUT4;
-          fwd_load_out<HT, SP, 4>(R, W, bias, N, lane);
-        }
-      }
-    }
-  }
-}
-
-template <int HT, int SP, int NTL>
-__device__ __forceinline__ void fwd_compute_out(const WPre<HT, SP> &R, const float *x, int ldx, int N, float *y, int ldy,
-                                                int lane) {
-  constexpr int KS = 4 * HT;
-  const int r = lane & 15, g = lane >> 4;
-  f32x4 acc[NTL];
-#pragma unroll
-  for (int t = 0; t < NTL; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float *xr = x + r * ldx + g * KS;
-#pragma unroll
-  for (int q = 0; q < KS / 4; ++q) {
-    float av[4];
-    load_vec_lds<4>(xr + 4 * q, av);
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], R.w[(4 * q + u) * NTL + t], acc[t], 0, 0, 0);
-  }
-#pragma unroll
-  for (int t = 0; t < NTL; ++t) {
-    const int n = NTL * r + t;
-    if (n < N) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) y[(4 * g + i) * ldy + n] = acc[t][i] + R.b[t];
-    }
-  }
-}
-
-// hidden-layer slice (kinds WP_FULL / WP_IN): y = act(x W + b) for this wave's 16*CT columns
-template <int HT, int SP>
-__device__ __forceinline__ void fwd_compute_hidden(const WPre<HT, SP> &R, const float *x, int ldx, int K, float *h_out, float *z_out,
-                                                   int ldo, int act, int lane) {
-  constexpr int KS = 4 * HT, CT = HT / SP;
-  const int r = lane & 15, g = lane >> 4;
-  f32x4 acc[CT];
-#pragma unroll
-  for (int t = 0; t < CT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (R.kind == WP_FULL) {
-    const float *xr = x + r * ldx + g * KS;
-#pragma unroll
-    for (int q = 0; q < KS / 4; ++q) {
-      float av[4];
-      load_vec_lds<4>(xr + 4 * q, av);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], R.w[(4 * q + u) * CT + t], acc[t], 0, 0, 0);
-    }
-  } else {
-    const int kc = (K + 3) >> 2;
-    float av[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int k = g * kc + s;
-      const bool ok = (s < kc) && (k < K);
-      av[s] = x[r * ldx + (ok ? k : 0)];
-      av[s] = ok ? av[s] : 0.f;
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-      for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], R.w[s * CT + t], acc[t], 0, 0, 0);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float zv[CT];
-#pragma unroll
-    for (int t = 0; t < CT; ++t) zv[t] = acc[t][i] + R.b[t];
-    const int o = (4 * g + i) * ldo + CT * r;
-    if (z_out) store_vec_lds<CT>(z_out + o, zv);
-    if (act >= 0) act_apply_vec<CT>(zv, act);
-    store_vec_lds<CT>(h_out + o, zv);
-  }
-}
-
-// One forward layer of a lockstep chain with the NEXT layer's weights requested first.  R must hold layer l (from
-// fwd_prefetch(R, ..., l, ...)); on return it holds layer l+1.
-template <int HT, int SP>
-__device__ __forceinline__ void group_fwd_step_p(const FwdChain &c, int l, int ldh, int ldy, int sub, int lane, WPre<HT, SP> &R) {
-  constexpr int CT = HT / SP;
-  const MlpDev &m = *c.m;
-  if (l >= m.n_layers) return;
-  WPre<HT, SP> Nx;
-  fwd_prefetch<HT, SP>(Nx, m, c.params, l + 1, sub, lane);
-  const int tile = 16 * ldh;
-  const float *cur;
-  int ldc;
-  if (l == 0) {
-    cur = c.x;
-    ldc = c.ldx;
-  } else {
-    cur = c.hbuf ? c.hbuf + (l - 1) * tile : (((l - 1) & 1) ? c.pp1 : c.pp0);
-    ldc = ldh;
-  }
-  float *ho = c.hbuf ? c.hbuf + l * tile : ((l & 1) ? c.pp1 : c.pp0);
-  float *zo = c.zbuf ? c.zbuf + l * tile : nullptr;
-  const int c0 = sub * 16 * CT;
-  if constexpr (WPre<HT, SP>::ON) {
-    if (R.kind == WP_FULL || R.kind == WP_IN) {
-      fwd_compute_hidden<HT, SP>(R, cur, ldc, m.dims[l], ho + c0, zo ? zo + c0 : nullptr, ldh, m.act, lane);
-    } else if (R.kind == WP_OUT1) {
-      fwd_compute_out<HT, SP, 1>(R, cur, ldc, m.dims[l + 1], c.y, ldy, lane);
-    } else if (R.kind == WP_OUT2) {
-      if constexpr (CT >= 2) fwd_compute_out<HT, SP, 2>(R, cur, ldc, m.dims[l + 1], c.y, ldy, lane);
-    } else if (R.kind == WP_OUT4) {
-      if constexpr (CT >= 4) fwd_compute_out<HT, SP, 4>(R, cur, ldc, m.dims[l + 1], c.y, ldy, lane);
-    }
-  }
-  if (R.kind == WP_NONE) {
-    if constexpr (WPre<HT, SP>::ON) {
-      const int K = m.dims[l], N = m.dims[l + 1];
-      const float *W = c.params + m.w_off[l], *bias = c.params + m.b_off[l];
-      if (l < m.n_layers - 1) gen_dense_fwd(cur, ldc, K, W, N, bias, c0, c0 + 16 * CT, ho, zo, ldh, m.act, lane);
-      else gen_dense_fwd(cur, ldc, K, W, N, bias, 0, N, c.y, nullptr, ldy, -1, lane);
-    } else {
-      group_fwd_layer<HT, SP>(m, c.params, l, cur, ldc, ho, zo, ldh, c.y, ldy, sub, lane);
-    }
-  }
-  R = Nx;
-}
-
-// ---- dgrad -----------------------------------------------------------------------------------------------------
-// Layer l's dgrad needs W_l: kinds WP_FULL (delta of a hidden layer, N == 16*HT), WP_OUT1 (delta of the output layer,
-// N <= 32) for l > 0, and WP_DX1 (l == 0, input gradient wanted, K <= 16, wave 0).
-template <int HT, int SP>
-__device__ __forceinline__ void dgrad_prefetch(WPre<HT, SP> &R, const MlpDev &m, const float *__restrict__ params, int l, bool want_dx,
-                                               int sub, int lane) {
-  constexpr int NS = 4 * HT, CT = HT / SP;
-  R.kind = WP_SKIP;
-  if (l < 0) return;
-  if constexpr (!WPre<HT, SP>::ON) {
-    R.kind = (l > 0 || (want_dx && sub == 0)) ? WP_NONE : WP_SKIP;
-    return;
-  }
-  const int r = lane & 15, g = lane >> 4;
-  const int K = m.dims[l], N = m.dims[l + 1];
-  const float *W = params + m.w_off[l];
-  if (l > 0) {
-    const int k0 = sub * 16 * CT;   // K == 16*HT
-    if (N == 16 * HT) {
-      R.kind = WP_FULL;
-#pragma unroll
-      for (int t = 0; t < CT; ++t) ldg_vec<NS>(W + (k0 + CT * r + t) * N + g * NS, &R.w[t * NS]);
-    } else if (N <= 32) {
-      R.kind = WP_OUT1;
-      const int nc = (N + 3) >> 2;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const int n = g * nc + s;
-        const int nn = ((s < nc) && (n < N)) ? n : 0;
-#pragma unroll
-        for (int t = 0; t < CT; ++t) R.w[s * CT + t] = W[(k0 + CT * r + t) * N + nn];
-      }
-    } else {
-      R.kind = WP_NONE;
-    }
-  } else if (want_dx && sub == 0) {
-    if (N == 16 * HT && K <= 16) {
-      R.kind = WP_DX1;
-      ldg_vec<NS>(W + ((r < K) ? r : 0) * N + g * NS, R.w);
-    } else {
-      R.kind = WP_NONE;
-    }
-  }
-}
-
-template <int HT, int SP>
-__device__ __forceinline__ void group_bwd_dgrad_layer_p(const MlpDev &m, const float *params, int l, const float *delta, int ldd,
-                                                        const float *zbuf, int ldh, float *dprev, float *dX, int ldx_in, int sub,
-                                                        int lane, WPre<HT, SP> &R) {
-  constexpr int NS = 4 * HT, CT = HT / SP;
-  WPre<HT, SP> Nx;
-  dgrad_prefetch<HT, SP>(Nx, m, params, l - 1, dX != nullptr, sub, lane);
-  const int r = lane & 15, g = lane >> 4;
-  if constexpr (WPre<HT, SP>::ON) {
-  if (R.kind == WP_FULL || R.kind == WP_OUT1) {
-    const int N = m.dims[l + 1];
-    const int k0 = sub * 16 * CT;
-    f32x4 acc[CT];
-#pragma unroll
-    for (int t = 0; t < CT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (R.kind == WP_FULL) {
-      const float *dr = delta + r * ldd + g * NS;
-#pragma unroll
-      for (int q = 0; q < NS / 4; ++q) {
-        float av[4];
-        load_vec_lds<4>(dr + 4 * q, av);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], R.w[t * NS + 4 * q + u], acc[t], 0, 0, 0);
-      }
-    } else {
-      const int nc = (N + 3) >> 2;
-      float av[8];
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const int n = g * nc + s;
-        const bool ok = (s < nc) && (n < N);
-        av[s] = delta[r * ldd + (ok ? n : 0)];
-        av[s] = ok ? av[s] : 0.f;
-      }
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], R.w[s * CT + t], acc[t], 0, 0, 0);
-    }
-    const float *zp = zbuf + (l - 1) * 16 * ldh + k0;
-    float *dx = dprev + k0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = 4 * g + i;
-      float ov[CT], zv[CT];
-#pragma unroll
-      for (int t = 0; t < CT; ++t) ov[t] = acc[t][i];
-      load_vec_lds<CT>(zp + row * ldh + CT * r, zv);
-      act_grad_mul_vec<CT>(ov, zv, m.act);
-      store_vec_lds<CT>(dx + row * ldh + CT * r, ov);
-    }
-  } else if (R.kind == WP_DX1) {
-    const int K = m.dims[0];
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float *dr = delta + r * ldd + g * NS;
-#pragma unroll
-    for (int q = 0; q < NS / 4; ++q) {
-      float av[4];
-      load_vec_lds<4>(dr + 4 * q, av);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], R.w[4 * q + u], acc, 0, 0, 0);
-    }
-    if (r < K) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dX[(4 * g + i) * ldx_in + r] = acc[i];
-    }
-  }
-  }
-  if (R.kind == WP_NONE) {
-    if constexpr (WPre<HT, SP>::ON) {
-      const int K = m.dims[l], N = m.dims[l + 1];
-      const float *W = params + m.w_off[l];
-      const int k0 = sub * 16 * CT;
-      if (l > 0) gen_dense_dgrad(delta, ldd, N, W, N, k0, k0 + 16 * CT, zbuf + (l - 1) * 16 * ldh, ldh, m.act, dprev, ldh, lane);
-      else gen_dense_dgrad(delta, ldd, N, W, N, 0, K, nullptr, 0, 0, dX, ldx_in, lane);
-    } else {
-      group_bwd_dgrad_layer<HT, SP>(m, params, l, delta, ldd, zbuf, ldh, dprev, dX, ldx_in, sub, lane);
-    }
-  }
-  R = Nx;
-}
-
-// =================================================================================================
-// Chain engine.  A kernel built from per-phase copies of the layer routines was 270-290 KB of straight-line code against a
-// 64 KB instruction cache (shared by two CUs): every layer step was a cold instruction stream, and in-kernel s_memtime stamps
-// showed even a 40-instruction section between two barriers costing ~3000 cycles (scripts/probes/icache_probe.hip: cold code
-// streams at ~1.1 B/cycle; the I$ survives kernel boundaries).  So a kernel describes what each wave does in a phase with
-// a `Chain` and runs ALL phases through ONE chain_step call site inside ONE loop: each layer routine exists once and stays
-// I$-resident across the steps of a launch and across launches.
-// =================================================================================================
+// phase kinds of a wave inside a kernel built on chain_run.hpp
 enum { CH_IDLE = 0, CH_FWD = 1, CH_DGRAD = 2, CH_WGRAD = 3 };
-
-// LDS operands are OFFSETS (in floats) from the kernel's dynamic-LDS base, -1 = none: a struct of generic pointers that is
-// re-assigned inside a loop defeats hipcc's address-space inference and every tile access becomes a flat_* instruction
-// (which also forces vmcnt(0)/lgkmcnt(0) waits and so kills the weight prefetch).
-struct Chain {
-  int mode;
-  int net;          // index into the kernel's LDS table of MlpDev
-  const float *params;
-  int x;            // network input tile (FWD; WGRAD layer 0)
-  int ldx;
-  int pp0, pp1;     // FWD: ping-pong hidden tiles when hbuf < 0;  DGRAD/WGRAD: ping-pong delta tiles
-  int zbuf, hbuf;   // per-layer stores (FWD writes; DGRAD reads zbuf; WGRAD reads hbuf)
-  int y;            // FWD: output tile;  DGRAD/WGRAD: dY, the delta of the output layer
-  int ldy;
-  int dX;           // DGRAD: input-gradient tile or -1
-  int ld_dx;
-  float *slab;      // WGRAD: this net's gradient slab (global)
-  int accumulate;
-};
-
-__device__ __forceinline__ float *lds_at(float *smem, int off) { return off < 0 ? nullptr : smem + off; }
-
-template <int HT, int SP>
-__device__ __forceinline__ void chain_prefetch(const Chain &c, const MlpDev *nets, WPre<HT, SP> &R, int sub, int lane) {
-  R.kind = WP_SKIP;
-  if (c.mode == CH_FWD) fwd_prefetch<HT, SP>(R, nets[c.net], c.params, 0, sub, lane);
-  else if (c.mode == CH_DGRAD) dgrad_prefetch<HT, SP>(R, nets[c.net], c.params, nets[c.net].n_layers - 1, c.dX >= 0, sub, lane);
-}
-
-// wgrad half of backward layer l with the common shapes specialised (network input <= 16 wide, output <= 16 wide, hidden
-// square) and everything else on the generic routine.
-template <int HT, int SP>
-__device__ __forceinline__ void group_bwd_wgrad_layer_c(const MlpDev &m, int l, const float *x_in, int ldx_in, const float *hbuf,
-                                                        int ldh, const float *delta, int ldd, float *slab, int sub, int lane,
-                                                        bool accumulate) {
-  if constexpr (!WPre<HT, SP>::ON) {
-    group_bwd_wgrad_layer<HT, SP>(m, l, x_in, ldx_in, hbuf, ldh, delta, ldd, slab, sub, lane, accumulate);
-  } else {
-    constexpr int CT = HT / SP;
-    const int K = m.dims[l], N = m.dims[l + 1];
-    const float *hp = (l == 0) ? x_in : hbuf + (l - 1) * 16 * ldh;
-    const int ldp = (l == 0) ? ldx_in : ldh;
-    float *gW = slab + m.w_off[l], *gb = slab + m.b_off[l];
-    if (l == m.n_layers - 1) {
-      const int k0 = sub * 16 * CT;  // split the K = 16*HT rows of dW over the SP waves
-      if (N <= 16) wave_dense_wgrad<CT, 1>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, lane, accumulate);
-      else gen_dense_wgrad(hp, ldp, k0, k0 + 16 * CT, delta, ldd, 0, N, gW, N, lane, accumulate);
-      if (sub == 0) wave_dense_bgrad(delta, ldd, N, gb, lane, accumulate);
-    } else {
-      const int c0 = sub * 16 * CT;  // N == 16*HT: column slice
-      if (l > 0) wave_dense_wgrad<HT, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane, accumulate);
-      else if (K <= 16) wave_dense_wgrad<1, CT>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, lane, accumulate);
-      else gen_dense_wgrad(hp, ldp, 0, K, delta, ldd, c0, c0 + 16 * CT, gW, N, lane, accumulate);
-      wave_dense_bgrad(delta + c0, ldd, 16 * CT, gb + c0, lane, accumulate);
-    }
-  }
-}
-
-// step i of the phase: FWD walks layers 0..L-1, DGRAD/WGRAD walk L-1..0.  The caller places one barrier after it.
-template <int HT, int SP>
-__device__ __forceinline__ void chain_step(const Chain &c, float *smem, const MlpDev *nets, int i, int ldh, int sub, int lane,
-                                           WPre<HT, SP> &R) {
-  if (c.mode == CH_IDLE) return;
-  const MlpDev &m = nets[c.net];
-  const int L = m.n_layers;
-  if (i >= L) return;
-  if (c.mode == CH_FWD) {
-    FwdChain fc{&m, c.params, lds_at(smem, c.x), c.ldx, lds_at(smem, c.pp0), lds_at(smem, c.pp1), lds_at(smem, c.zbuf),
-                lds_at(smem, c.hbuf), lds_at(smem, c.y)};
-    group_fwd_step_p<HT, SP>(fc, i, ldh, c.ldy, sub, lane, R);
-  } else {
-    const int l = L - 1 - i;
-    const float *delta = lds_at(smem, (l == L - 1) ? c.y : (((l + 1) & 1) ? c.pp1 : c.pp0));
-    const int ldd = (l == L - 1) ? c.ldy : ldh;
-    float *dn = lds_at(smem, (l & 1) ? c.pp1 : c.pp0);
-    if (c.mode == CH_DGRAD)
-      group_bwd_dgrad_layer_p<HT, SP>(m, c.params, l, delta, ldd, lds_at(smem, c.zbuf), ldh, dn, lds_at(smem, c.dX), c.ld_dx, sub, lane, R);
-    else
-      group_bwd_wgrad_layer_c<HT, SP>(m, l, lds_at(smem, c.x), c.ldx, lds_at(smem, c.hbuf), ldh, delta, ldd, c.slab, sub, lane,
-                                      c.accumulate != 0);
-  }
-}
