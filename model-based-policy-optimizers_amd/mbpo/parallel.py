@@ -81,6 +81,125 @@ class P2PExchange:
 
     @classmethod
     def create(cls, dp: "DataParallel", n_max: int, device) -> Optional["P2PExchange"]:
+        """Collective over dp.group.  Every step that can fail locally is followed by an agreement (MIN all-reduce of an ok
+        flag) before the next collective, so one rank's failure turns into `None` on every rank instead of a deadlock."""
+        if dp.group is None or dp.world_size < 2 or os.environ.get("MBPO_P2P_ALLREDUCE", "1") == "0":
+            return None
+        import torch.distributed as dist
+        device = torch.device(device)
+        ex = cls(dp, n_max, device)
+
+        def agree(ok: bool) -> bool:
+            flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=dp.group)
+            return int(flag) == 1
+
+        # 1. own region + IPC handle (local)
+        handle = None
+        try:
+            handle = ex._alloc()
+        except Exception as e:      # noqa: BLE001 — any failure means: use the library collective
+            ex._err = repr(e)
+        if not agree(handle is not None):
+            ex.close()
+            return None
+        # 2. exchange the handles (collective), map the peers (local)
+        mine = (handle, torch.cuda.current_device() if device.index is None else device.index, os.getpid())
+        gathered = [None] * dp.world_size
+        dist.all_gather_object(gathered, mine, group=dp.group)
+        ok = True
+        try:
+            ex._open_peers(gathered, mine[1])
+        except Exception as e:      # noqa: BLE001
+            ok = False
+            ex._err = repr(e)
+        if not agree(ok):
+            ex.close()
+            return None
+        # 3. three exchanges against the library all-reduce
+        ok = True
+        try:
+            ok = ex._self_check()
+        except Exception as e:      # noqa: BLE001
+            ok = False
+            ex._err = repr(e)
+        if not agree(ok):
+            ex.close()
+            return None
+        return ex
+
+    def _alloc(self) -> bytes:
+        _hip, lib, dp = self._hip, self.lib, self.dp
+        nbytes = lib.mbpo_p2p_region_bytes(dp.world_size, self.n_max)
+        if nbytes < 0:
+            _hip.check(int(nbytes), "mbpo_p2p_region_bytes")
+        handle = (C.c_ubyte * 64)()
+        _hip.check(lib.mbpo_p2p_alloc(nbytes, C.byref(self.own), handle), "mbpo_p2p_alloc")
+        return bytes(handle)
+
+    def _open_peers(self, gathered, my_dev: int):
+        _hip, lib, dp = self._hip, self.lib, self.dp
+        d = _hip.P2pDesc()
+        d.world, d.rank, d.n_max = dp.world_size, dp.rank, self.n_max
+        for r, (h, dev_idx, _pid) in enumerate(gathered):
+            if r == dp.rank:
+                d.regions[r] = self.own.value
+                continue
+            p = C.c_void_p()
+            hb = (C.c_ubyte * 64).from_buffer_copy(h)
+            _hip.check(lib.mbpo_p2p_open(hb, -1 if dev_idx == my_dev else dev_idx, C.byref(p)), "mbpo_p2p_open")
+            self.peers[r] = p
+            d.regions[r] = p.value
+        self.desc = d
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place SUM over ranks (no-op without a group)."""
+        if self.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_reduce_fn(self):
+        """Callable for ops.SacUpdater / ops.running_stats_update, or None when there is nothing to reduce."""
+        return self.all_reduce_sum if self.group is not None else None
+
+    def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        if self.group is not None:
+            import torch.distributed as dist
+            dist.broadcast(t, src=src, group=self.group)
+        return t
+
+    def rank_key(self, key: int) -> int:
+        """Per-rank key for everything that must DIFFER across ranks (env resets, rollout noise, replay sampling)."""
+        return K.split(key, self.world_size)[self.rank] if self.world_size > 1 else key
+
+    def shard(self, n: int) -> range:
+        """Contiguous shard of `n` units (envs) owned by this rank; n must divide evenly."""
+        if n % self.world_size:
+            raise ValueError(f"{n} units do not shard evenly over {self.world_size} ranks")
+        per = n // self.world_size
+        return range(self.rank * per, (self.rank + 1) * per)
+
+
+class P2PExchange:
+    """Peer-memory exchange regions for the one-shot all-reduce (csrc/p2p.hpp): every rank allocates a region, the 64-byte IPC
+    handles travel through the process group (all_gather_object), every rank maps every peer's region.
+
+    `create` returns None (the caller then keeps the RCCL all-reduce) when the regions cannot be set up, when
+    MBPO_P2P_ALLREDUCE=0, or when the self-check — one exchange of a rank-dependent vector compared with
+    torch.distributed.all_reduce — does not reproduce the library's result on every rank."""
+
+    def __init__(self, dp: "DataParallel", n_max: int, device: torch.device):
+        from mbpo import _hip
+        self.lib = _hip.load()
+        self._hip = _hip
+        self.dp, self.n_max, self.device = dp, int(n_max), device
+        self.own = C.c_void_p()
+        self.peers = {}
+        self.desc = None
+
+    @classmethod
+    def create(cls, dp: "DataParallel", n_max: int, device) -> Optional["P2PExchange"]:
         if dp.group is None or dp.world_size < 2 or os.environ.get("MBPO_P2P_ALLREDUCE", "1") == "0":
             return None
         import torch.distributed as dist
@@ -149,18 +268,16 @@ class P2PExchange:
     def _self_check(self) -> bool:
         import torch.distributed as dist
         n = min(self.n_max, 4099)
-        for it in range(3):      # three exchanges: both slot parities and a re-use
+        ok = True
+        for it in range(3):      # three exchanges: both slot parities and a re-use; every rank runs all of them
             g = torch.Generator().manual_seed(1000 * it + self.dp.rank)
             x = torch.randn(n, generator=g).to(self.device)
             ref = x.clone()
             dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.dp.group)
             self.all_reduce_sum(x)
             torch.cuda.synchronize()
-            if self.status() != 0 or not bool(torch.isfinite(x).all()):
-                return False
-            if not torch.allclose(x, ref, rtol=1e-5, atol=1e-5):
-                return False
-        return True
+            ok = ok and self.status() == 0 and bool(torch.isfinite(x).all()) and torch.allclose(x, ref, rtol=1e-5, atol=1e-5)
+        return ok
 
     def close(self):
         for p in self.peers.values():
