@@ -11,7 +11,7 @@
 //   k_ppo_apply     optax.adamw(lr, wd) (no clipping in this variant, ppo.py:128).                         [HBM]
 // Algorithmic work per sample: 3*(2P + 2V) FLOP fwd+bwd (+2V for the value pre-pass), 4*(2x+2u+4) B of row data.
 #include "common.hpp"
-#include "wave_mlp.hpp"
+#include "chain_run.hpp"
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
 #define LOG_2 0.69314718055994530942f
@@ -19,6 +19,7 @@
 
 struct PpoArgs {
   MlpDev pi, v;
+  NetShape sh_pi, sh_v;
   int X, U, B, T, D;
   const float *data, *norm_mean, *norm_std, *ent_noise;
   unsigned long long seed, offset;
@@ -36,17 +37,22 @@ template <int H>
 __global__ void __launch_bounds__(256) k_ppo_values(PpoArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid_ = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   const int X = A.X, U = A.U, D = A.D, T = A.T;
   const long long M = (long long)A.B * T, rows = M + A.B;     // samples, then one bootstrap row per trajectory
   float *s_x = smem;                         // [16][ld_x]
   float *s_pp = s_x + 16 * A.ld_x;           // 2 hidden tiles
   float *s_y = s_pp + 2 * 16 * A.ld_h;       // [16][ld_y]
   const long long n_tiles = (rows + 15) >> 4;
+#pragma nounroll
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int tid = opaque(tid_), lane = tid & 63;
     const long long r0 = tile * 16;
-    for (int idx = tid; idx < 16 * X; idx += blockDim.x) {
-      const int r = idx / X, c = idx - r * X;
+    WSet<HT, 4> R;
+    chain_fwd_prefetch<HT, 4>(R, A.sh_v, A.v.params, wave, lane);
+    for (int idx = tid; idx < 16 * X; idx += 256) {
+      const int r = idx & 15, c = idx >> 4;
       const long long i = r0 + r;
       float o = 0.f;
       if (i < M) o = A.data[i * D + c];                                                   // observation
@@ -65,11 +71,8 @@ __global__ void __launch_bounds__(256) k_ppo_values(PpoArgs A) {
       }
     }
     __syncthreads();
-    FwdChain fc{&A.v, A.v.params, s_x, A.ld_x, s_pp, s_pp + 16 * A.ld_h, nullptr, nullptr, s_y};
-    for (int l = 0; l < A.v.n_layers; ++l) {
-      group_fwd_step<HT, 4>(fc, l, A.ld_h, A.ld_y, wave, lane);
-      __syncthreads();
-    }
+    chain_fwd_run<HT, 4>(A.sh_v, A.v.params, s_x, A.ld_x, s_pp, s_pp + 16 * A.ld_h, nullptr, nullptr, s_y, A.ld_y, A.ld_h, A.sh_v.L,
+                         wave, lane, R);
     if (tid < 16) {
       const long long i = r0 + tid;
       if (i < M) A.baseline[i] = s_y[tid * A.ld_y];
@@ -113,19 +116,19 @@ __global__ void k_moments_final(const float *partial, int n_parts, long long n, 
 }
 
 // ------------------------------------------------------------------------------------------------ loss fwd/bwd
-template <int H>
-__global__ void __launch_bounds__(512) k_ppo_fwd_bwd(PpoArgs A) {
+template <int H, int SP>   // 4 chains x SP waves
+__global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
-  constexpr int SP = 2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int tid_ = threadIdx.x, nthreads = 256 * SP;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   const int chain = wave / SP, sub = wave % SP;
   const int X = A.X, U = A.U, D = A.D;
   const long long M = (long long)A.B * A.T;
   const int ld_x = A.ld_x, ld_h = A.ld_h, ld_y = A.ld_y, LH = A.LH;
   const int TT = 16 * ld_h;
   const int D4 = (D + 3) & ~3;
-  float *s_row = smem;                       // [16][D4]
+  float *s_row = smem;                       // [16][D] flat copy of the tile's rows (16*D4 floats reserved)
   float *s_x = s_row + 16 * D4;              // [16][ld_x]   normalised obs
   float *s_store = s_x + 16 * ld_x;          // 4*LH tiles: policy z,h | value z,h
   float *s_pp = s_store + 4 * LH * TT;       // 4 tiles: delta ping-pong (policy, value)
@@ -145,36 +148,42 @@ __global__ void __launch_bounds__(512) k_ppo_fwd_bwd(PpoArgs A) {
   float loss_pol = 0.f, loss_v = 0.f, loss_ent = 0.f;     // thread 0..15 partials, reduced at the end
   const long long n_tiles = (M + 15) >> 4;
   bool first = true;
+  const int net = chain & 1;   // 0 = policy, 1 = value
+  const NetShape sh = net ? A.sh_v : A.sh_pi;
+  const float *nparams = net ? A.v.params : A.pi.params;
+  const int H1 = 16 * HT;
+#pragma nounroll
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, first = false) {
+    const int tid = opaque(tid_), lane = tid & 63;
     const long long r0 = tile * 16;
-    for (int idx = tid; idx < 16 * D; idx += nthreads) {
-      const int r = idx / D, c = idx - r * D;
-      s_row[r * D4 + c] = (r0 + r < M) ? A.data[(r0 + r) * D + c] : 0.f;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 16 * X; idx += nthreads) {
-      const int r = idx / X, c = idx - r * X;
-      float o = s_row[r * D4 + c];
-      if (A.norm_mean) o = (o - A.norm_mean[c]) / A.norm_std[c];
-      s_x[r * ld_x + c] = o;
+    WSet<HT, SP> R;
+    if (chain < 2) chain_fwd_prefetch<HT, SP>(R, sh, nparams, sub, lane);
+    {
+      const long long nvalid = (M - r0 < 16 ? M - r0 : 16) * D;
+      for (int idx = tid; idx < 16 * D; idx += nthreads) {   // flat copy, row stride D (no padding, no division)
+        s_row[idx] = idx < nvalid ? A.data[r0 * D + idx] : 0.f;
+      }
+      for (int idx = tid; idx < 16 * X; idx += nthreads) {
+        const int r = idx & 15, c = idx >> 4;
+        float o = (r0 + r < M) ? A.data[(r0 + r) * D + c] : 0.f;
+        if (A.norm_mean) o = (o - A.norm_mean[c]) / A.norm_std[c];
+        s_x[r * ld_x + c] = o;
+      }
     }
     __syncthreads();
     // ---- forward: policy logits (:80) and value baseline (:82), both stored for the backward
-    {
-      FwdChain fc;
-      if (chain == 0) fc = FwdChain{&A.pi, A.pi.params, s_x, ld_x, nullptr, nullptr, zp, hp, y_pi};
-      else fc = FwdChain{&A.v, A.v.params, s_x, ld_x, nullptr, nullptr, zv, hv, y_v};
-      for (int l = 0; l < Lmax; ++l) {
-        if (chain < 2) group_fwd_step<HT, SP>(fc, l, ld_h, ld_y, sub, lane);
-        __syncthreads();
-      }
-    }
+    if (chain < 2)
+      chain_fwd_run<HT, SP>(sh, nparams, s_x, ld_x, nullptr, nullptr, net ? zv : zp, net ? hv : hp, net ? y_v : y_pi, ld_y, ld_h, Lmax,
+                            sub, lane, R);
+    else
+      chain_idle_run(Lmax);
+    if (chain < 2) chain_dgrad_prefetch<HT, SP>(R, sh, nparams, sub, lane);
     // ---- per-sample loss terms and output gradients
     if (tid < 16) {
       const int r = tid;
       const long long i = r0 + r;
       const bool ok = i < M;
-      const float *row = s_row + r * D4;
+      const float *row = s_row + r * D;
       const float lp_b = row[2 * X + U + 2];                       // behaviour log-prob (policy_extras.log_prob)
       const float adv = ok ? (A.adv[i] - adv_mean) * adv_istd : 0.f;
       const float vs = ok ? A.vs[i] : 0.f;
@@ -229,26 +238,16 @@ __global__ void __launch_bounds__(512) k_ppo_fwd_bwd(PpoArgs A) {
     __syncthreads();
     // ---- backward: chains 0/1 push delta down (policy / value), chains 2/3 accumulate dW/db into this WG's slab
     {
-      const int net = chain & 1;
-      const MlpDev &m = net ? A.v : A.pi;
-      const float *zb = net ? zv : zp, *hb = net ? hv : hp;
       float *d0 = s_pp + (2 * net) * TT, *d1 = d0 + TT;
-      const float *dcur = s_dy + net * 16 * ld_y;
-      int ldc = ld_y;
-      for (int l = Lmax - 1; l >= 0; --l) {
-        float *dn = (l & 1) ? d1 : d0;
-        if (l < m.n_layers) {
-          if (chain < 2) group_bwd_dgrad_layer<HT, SP>(m, m.params, l, dcur, ldc, zb, ld_h, dn, nullptr, ld_x, sub, lane);
-          else group_bwd_wgrad_layer<HT, SP>(m, l, s_x, ld_x, hb, ld_h, dcur, ldc, net ? slab_v : slab_pi, sub, lane, !first);
-        }
-        __syncthreads();
-        if (l < m.n_layers) {
-          dcur = dn;
-          ldc = ld_h;
-        }
-      }
+      if (chain < 2)
+        chain_dgrad_run<HT, SP>(sh, nparams, s_dy + net * 16 * ld_y, ld_y, net ? zv : zp, d0, d1, nullptr, ld_x, ld_h, Lmax, sub, lane, R);
+      else
+        chain_wgrad_run<HT, SP>(sh, s_x, ld_x, net ? hv : hp, s_dy + net * 16 * ld_y, ld_y, d0, d1, net ? slab_v : slab_pi, !first, ld_h,
+                                Lmax, sub, lane);
     }
   }
+  (void)H1;
+  const int tid = tid_;
   // ---- loss partials of this workgroup (fixed order)
   if (tid < 16) {
     s_scal[tid] = loss_pol;
@@ -430,6 +429,8 @@ extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
   float *ws = d->workspace;
   PpoArgs A;
   A.pi = pl.pi; A.v = pl.v;
+  A.sh_pi = NetShape{pl.pi.dims[0], pl.pi.n_layers, pl.pi.dims[pl.pi.n_layers], pl.pi.act};
+  A.sh_v = NetShape{pl.v.dims[0], pl.v.n_layers, pl.v.dims[pl.v.n_layers], pl.v.act};
   A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.T = d->unroll_length; A.D = d->row_len;
   A.data = d->data; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std; A.ent_noise = d->entropy_noise;
   A.seed = d->seed; A.offset = d->offset; A.step_count = d->step_count;
@@ -468,13 +469,13 @@ extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
   }
   // 4. loss forward/backward
   if (pl.H == 64) {
-    rc = mbpo_ensure_lds<k_ppo_fwd_bwd<64>>(pl.lds_fb, "ppo_grads");
+    rc = mbpo_ensure_lds<k_ppo_fwd_bwd<64, 4>>(pl.lds_fb, "ppo_grads");
     if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL(k_ppo_fwd_bwd<64>, dim3(pl.n_slabs), dim3(512), pl.lds_fb, st, A);
+    hipLaunchKernelGGL((k_ppo_fwd_bwd<64, 4>), dim3(pl.n_slabs), dim3(1024), pl.lds_fb, st, A);
   } else {
-    rc = mbpo_ensure_lds<k_ppo_fwd_bwd<128>>(pl.lds_fb, "ppo_grads");
+    rc = mbpo_ensure_lds<k_ppo_fwd_bwd<128, 2>>(pl.lds_fb, "ppo_grads");
     if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL(k_ppo_fwd_bwd<128>, dim3(pl.n_slabs), dim3(512), pl.lds_fb, st, A);
+    hipLaunchKernelGGL((k_ppo_fwd_bwd<128, 2>), dim3(pl.n_slabs), dim3(512), pl.lds_fb, st, A);
   }
   // 5. reduce
   PpoReduceArgs R;
