@@ -14,7 +14,7 @@
 // recomputation costs one extra forward (4x instead of 3x forward FLOPs) and keeps everything in LDS.
 // Algorithmic FLOP per (trajectory, step): 3*(2P) + 2*(2*E*M) + 2*(2*2V)  (SURVEY §8d).
 #include "common.hpp"
-#include "wave_mlp.hpp"
+#include "chain_run.hpp"
 #include <string.h>
 
 #define LOG_SQRT_2PI_B 0.91893853320467274178f
@@ -697,6 +697,7 @@ extern "C" int mbpo_bptt_actor_grads(const mbpo_bptt_desc *d, void *stream) {
 // ------------------------------------------------------------------------------------------------
 struct CriticArgs {
   MlpDev cr;
+  NetShape sh;
   int X, D;
   const float *transitions, *lambda_values, *s_mean, *s_std;
   const int *idx;
@@ -705,13 +706,15 @@ struct CriticArgs {
   int ld_x, ld_h, LH;
 };
 
-// 8 waves: forward = critic_1 | critic_2 (2 waves each, z and h kept); backward = 2 dgrad chains + 2 wgrad chains.
-template <int H>
-__global__ void __launch_bounds__(512) k_critic_fwd_bwd(CriticArgs A) {
+// 4 chains x SP waves on phase runners (chain_run.hpp): forward = critic_1 | critic_2 (z and h kept); backward = a dgrad and a
+// wgrad chain per net side by side; a workgroup walks tiles and accumulates into its slab.
+template <int H, int SP>
+__global__ void __launch_bounds__(256 * SP) k_critic_fwd_bwd(CriticArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
-  const int chain = wave >> 1, sub = wave & 1;
+  const int tid_ = threadIdx.x, nthreads = 256 * SP;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+  const int chain = wave / SP, sub = wave % SP;
   const int X = A.X, ld_x = A.ld_x, ld_h = A.ld_h, LH = A.LH;
   const int T = 16 * ld_h;
   float *s_x = smem;                    // [16][ld_x] normalised obs
@@ -721,18 +724,23 @@ __global__ void __launch_bounds__(512) k_critic_fwd_bwd(CriticArgs A) {
   float *s_ls = s_tg + 16;              // [32] loss partials
   float *s_st = s_ls + 32;              // 4*LH tiles: z1 h1 z2 h2
   float *s_pp = s_st + 4 * LH * T;      // 4 delta tiles
-  float *z1 = s_st, *h1 = s_st + LH * T, *z2 = s_st + 2 * LH * T, *h2 = s_st + 3 * LH * T;
-  const float *p1 = A.cr.params, *p2 = A.cr.params + A.cr.net_stride;
+  const int net = chain & 1;
+  float *zb = s_st + (2 * net) * LH * T, *hb = zb + LH * T;
+  const float *params = A.cr.params + (long long)net * A.cr.net_stride;
   const int CL = A.cr.n_layers;
   const float invB = 1.0f / (float)A.batch;
-  float *slab = A.slabs + (long long)blockIdx.x * 2 * A.cr.n_params;
+  float *slab = A.slabs + (long long)blockIdx.x * 2 * A.cr.n_params + (long long)net * A.cr.n_params;
   float loss = 0.f;
   bool first = true;
   const long long n_tiles = (A.batch + 15) >> 4;
+#pragma nounroll
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, first = false) {
+    const int tid = opaque(tid_), lane = tid & 63;
     const long long j0 = tile * 16;
+    WSet<HT, SP> R;
+    if (chain < 2) chain_fwd_prefetch<HT, SP>(R, A.sh, params, sub, lane);
     for (int idx = tid; idx < 16 * X; idx += nthreads) {
-      const int r = idx / X, c = idx - r * X;
+      const int r = idx & 15, c = idx >> 4;
       const long long j = j0 + r;
       float o = 0.f;
       if (j < A.batch) o = (A.transitions[(long long)A.idx[j] * A.D + c] - A.s_mean[c]) / A.s_std[c];   // traj.observation normalised (:399)
@@ -740,15 +748,9 @@ __global__ void __launch_bounds__(512) k_critic_fwd_bwd(CriticArgs A) {
     }
     if (tid < 16) s_tg[tid] = (j0 + tid < A.batch) ? A.lambda_values[A.idx[j0 + tid]] : 0.f;
     __syncthreads();
-    {
-      FwdChain fc;
-      if (chain == 0) fc = FwdChain{&A.cr, p1, s_x, ld_x, nullptr, nullptr, z1, h1, s_yv};
-      else fc = FwdChain{&A.cr, p2, s_x, ld_x, nullptr, nullptr, z2, h2, s_yv + 64};
-      for (int l = 0; l < CL; ++l) {
-        if (chain < 2) group_fwd_step<HT, 2>(fc, l, ld_h, 4, sub, lane);
-        __syncthreads();
-      }
-    }
+    if (chain < 2) chain_fwd_run<HT, SP>(A.sh, params, s_x, ld_x, nullptr, nullptr, zb, hb, s_yv + net * 64, 4, ld_h, CL, sub, lane, R);
+    else chain_idle_run(CL);
+    if (chain < 2) chain_dgrad_prefetch<HT, SP>(R, A.sh, params, sub, lane);
     if (tid < 32) {
       const int k = tid >> 4, r = tid & 15;
       const bool ok = j0 + r < A.batch;
@@ -760,23 +762,12 @@ __global__ void __launch_bounds__(512) k_critic_fwd_bwd(CriticArgs A) {
     if (tid == 0)
       for (int i = 0; i < 32; ++i) loss += s_ls[i];
     {
-      const int net = chain & 1;
-      const float *pp = net ? p2 : p1;
-      const float *zb = net ? z2 : z1, *hb = net ? h2 : h1;
       float *d0 = s_pp + (2 * net) * T, *d1 = d0 + T;
-      const float *dcur = s_dyv + net * 64;
-      int ldc = 4;
-      for (int l = CL - 1; l >= 0; --l) {
-        float *dn = (l & 1) ? d1 : d0;
-        if (chain < 2) group_bwd_dgrad_layer<HT, 2>(A.cr, pp, l, dcur, ldc, zb, ld_h, dn, nullptr, ld_x, sub, lane);
-        else group_bwd_wgrad_layer<HT, 2>(A.cr, l, s_x, ld_x, hb, ld_h, dcur, ldc, slab + (long long)net * A.cr.n_params, sub, lane, !first);
-        __syncthreads();
-        dcur = dn;
-        ldc = ld_h;
-      }
+      if (chain < 2) chain_dgrad_run<HT, SP>(A.sh, params, s_dyv + net * 64, 4, zb, d0, d1, nullptr, ld_x, ld_h, CL, sub, lane, R);
+      else chain_wgrad_run<HT, SP>(A.sh, s_x, ld_x, hb, s_dyv + net * 64, 4, d0, d1, slab, !first, ld_h, CL, sub, lane);
     }
   }
-  if (tid == 0) A.extras[blockIdx.x] = loss;
+  if (tid_ == 0) A.extras[blockIdx.x] = loss;
 }
 
 __global__ void __launch_bounds__(256) k_critic_reduce(const float *slabs, const float *extras, int n_slabs, int C2, long long batch,
@@ -836,10 +827,11 @@ extern "C" int mbpo_critic_grads(const float *critic_params, int32_t x_dim, int3
   A.cr.params = critic_params; A.cr.act = activation; A.cr.n_nets = 2; A.cr.net_stride = A.cr.n_params;
   A.X = x_dim; A.D = row_len; A.transitions = transitions; A.lambda_values = lambda_values; A.s_mean = state_mean; A.s_std = state_std;
   A.idx = idx; A.batch = batch; A.slabs = workspace; A.extras = workspace + (long long)ns * 2 * A.cr.n_params;
-  rc = mbpo_ensure_lds<k_critic_fwd_bwd<64>>(lds, "critic_grads");
+  A.sh = NetShape{x_dim, critic_layers, 1, activation};
+  rc = mbpo_ensure_lds<k_critic_fwd_bwd<64, 4>>(lds, "critic_grads");
   if (rc != MBPO_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_critic_fwd_bwd<64>, dim3(ns), dim3(512), lds, st, A);
+  hipLaunchKernelGGL((k_critic_fwd_bwd<64, 4>), dim3(ns), dim3(1024), lds, st, A);
   const int C2 = 2 * A.cr.n_params;
   hipLaunchKernelGGL(k_critic_reduce, dim3((C2 + 255) / 256), dim3(256), 0, st, (const float *)A.slabs, (const float *)A.extras, ns, C2,
                      (long long)batch, grads, metrics);
