@@ -14,14 +14,30 @@
 #include "common.hpp"
 #include "chain_run.hpp"
 #include "p2p.hpp"
+#include <string.h>
 int mbpo_p2p_make_dev(const mbpo_p2p_desc *d, P2pDev *P);
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
 #define LOG_2 0.69314718055994530942f
 
+// What one wave group walks in one phase, filled in by the host (sac_chain_table): the kernel fetches its entry with one
+// scalar load instead of ~200 scalar instructions of role/phase/chain case analysis per phase.
+struct SacChainDesc {
+  int mode;        // CH_*
+  int netid;       // 0 = policy shape, 1 = critic shape
+  int base_sel;    // parameters relative to: 0 = params, 1 = target_q
+  int param_off;   // floats
+  int x, ldx;      // LDS offsets (floats from the dynamic-LDS base), -1 = none
+  int pp0, pp1, zb, hb, y, dx;
+  int slab_sel;    // 0 none, 1 = policy slab, 2 = critic slab
+  int slab_off;    // floats inside the tile's slab
+  int pad0, pad1;
+};
+
 struct SacArgs {
   MlpDev pi, q, qt;
   NetShape sh_pi, sh_q;
+  SacChainDesc tab[2][5][4];   // [role][phase (index nph = idle)][chain]
   int X, U, B, D;
   const float *batch, *norm_mean, *norm_std, *log_alpha;
   const float *noise_alpha, *noise_critic, *noise_actor;
@@ -190,50 +206,21 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
     // ---- the chain this wave walks in the NEXT phase; its first layer's weights are requested now ----
     {
       const int nx = ph + 1;
-      mode = CH_IDLE;
-      czb = chb = cdx = cpp0 = cpp1 = -1;
-      const int net = chain & 1;
-      if (role == 0) {
-        if (nx == 0 && chain < 3) {
-          mode = CH_FWD;
-          if (chain == 0) {
-            netid = 0; cparams = pi_p; cx = o_sn2; cldx = ld_x; cpp0 = o_pp; cpp1 = o_pp + T; cy = o_y;
-          } else {
-            netid = 1; cparams = chain == 1 ? q1_p : q2_p; cx = o_qin; cldx = ld_xu;
-            czb = chain == 1 ? o_st0 : o_st2; chb = chain == 1 ? o_st1 : o_st3; cy = o_y + (chain == 1 ? 1 : 2) * 16 * ld_y;
-          }
-        } else if (nx == 1 && chain < 2) {
-          mode = CH_FWD;
-          netid = 1; cparams = chain == 0 ? t1_p : t2_p; cx = o_qin2; cldx = ld_xu;
-          cpp0 = o_pp + 2 * chain * T; cpp1 = cpp0 + T; cy = o_y + (chain + 1) * 16 * ld_y;
-        } else if (nx == 2) {
-          mode = chain < 2 ? CH_DGRAD : CH_WGRAD;
-          netid = 1; cparams = net ? q2_p : q1_p; cx = o_qin; cldx = ld_xu;
-          cpp0 = o_pp + 2 * net * T; cpp1 = cpp0 + T; czb = net ? o_st2 : o_st0; chb = net ? o_st3 : o_st1;
-          cy = o_dy + net * 16 * ld_y;
-          cslab = A.slab_q + (long long)tile * (2 * A.q.n_params) + (long long)net * A.q.net_stride;
-        }
-      } else {
-        if (nx == 0 && chain == 0) {
-          mode = CH_FWD;
-          netid = 0; cparams = pi_p; cx = o_sn; cldx = ld_x; czb = o_st0; chb = o_st1; cy = o_y;
-        } else if (nx == 1 && chain < 2) {
-          mode = CH_FWD;
-          netid = 1; cparams = chain == 0 ? q1_p : q2_p; cx = o_qin; cldx = ld_xu;
-          cpp0 = o_pp + 2 * chain * T; cpp1 = cpp0 + T; czb = chain == 0 ? o_st2 : o_st3; cy = o_y + (chain + 1) * 16 * ld_y;
-        } else if (nx == 2 && chain < 2) {
-          mode = CH_DGRAD;
-          netid = 1; cparams = net ? q2_p : q1_p; cpp0 = o_pp + 2 * net * T; cpp1 = cpp0 + T; czb = net ? o_st3 : o_st2;
-          cy = o_dy + net * 16 * ld_y; cdx = o_dx + net * 16 * ld_xu;
-        } else if (nx == 3 && chain < 2) {
-          mode = chain == 0 ? CH_DGRAD : CH_WGRAD;
-          netid = 0; cparams = pi_p; cx = o_sn; cldx = ld_x; cpp0 = o_pp; cpp1 = o_pp + T; czb = o_st0; chb = o_st1;
-          cy = o_dy; cslab = A.slab_pi + (long long)tile * A.pi.n_params;
-        }
-      }
+      const SacChainDesc &cd = A.tab[role][nx][chain];
+      mode = cd.mode;
+      netid = cd.netid;
+      cparams = (cd.base_sel ? A.qt.params : A.pi.params) + cd.param_off;
+      cx = cd.x; cldx = cd.ldx; cpp0 = cd.pp0; cpp1 = cd.pp1; czb = cd.zb; chb = cd.hb; cy = cd.y; cdx = cd.dx;
+      cslab = cd.slab_sel == 1 ? A.slab_pi + (long long)tile * A.pi.n_params + cd.slab_off
+                               : (cd.slab_sel == 2 ? A.slab_q + (long long)tile * (2 * A.q.n_params) + cd.slab_off : nullptr);
       const NetShape shn = netid == 0 ? A.sh_pi : A.sh_q;
       if (mode == CH_FWD) chain_fwd_prefetch<HT, SP>(R, shn, cparams, sub, lane);
       else if (mode == CH_DGRAD) chain_dgrad_prefetch<HT, SP>(R, shn, cparams, sub, lane);
+    }
+    if (A.stamps && tile == 0 && tid == 0 && ph == 1) {
+      unsigned long long t_;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+      A.stamps[role * 16 + 14] = t_;
     }
     // ---- elementwise section after phase ph ----
     if (ph == -1) {
@@ -799,6 +786,66 @@ extern "C" int64_t mbpo_sac_workspace_floats(const mbpo_sac_desc *d) {
 
 constexpr int SP64 = 4;   // waves per chain at hidden width 64
 
+// LDS offsets (floats) of the tiles the chains use; must mirror the carve at the top of k_sac_fwd_bwd
+static void sac_chain_table(const SacPlan &pl, int D, SacArgs *A) {
+  const int ld_x = pl.ld_x, ld_xu = pl.ld_xu, ld_h = pl.ld_h, ld_y = pl.ld_y, LH = pl.LH;
+  const int T = 16 * ld_h;
+  const int o_row = 0;
+  const int o_sn = o_row + 16 * ((D + 3) & ~3), o_sn2 = o_sn + 16 * ld_x, o_qin = o_sn2 + 16 * ld_x, o_qin2 = o_qin + 16 * ld_xu;
+  const int o_pp = o_qin2 + 16 * ld_xu, o_st0 = o_pp + 4 * T, o_y = o_st0 + 4 * LH * T, o_dy = o_y + 3 * 16 * ld_y, o_dx = o_dy + 2 * 16 * ld_y;
+  const int o_st1 = o_st0 + LH * T, o_st2 = o_st0 + 2 * LH * T, o_st3 = o_st0 + 3 * LH * T;
+  const int P = pl.P, Q = pl.Q;   // params = [policy | critic0 | critic1 | log_alpha]; target_q = [critic0 | critic1]
+  for (int role = 0; role < 2; ++role)
+    for (int ph = 0; ph < 5; ++ph)
+      for (int c = 0; c < 4; ++c) {
+        SacChainDesc d;
+        memset(&d, 0, sizeof(d));
+        d.mode = CH_IDLE;
+        d.x = d.pp0 = d.pp1 = d.zb = d.hb = d.y = d.dx = -1;
+        d.ldx = ld_x;
+        const int net = c & 1;
+        if (role == 0) {                       // critic role
+          if (ph == 0 && c < 3) {              // pi(s') || Q1(s,a) || Q2(s,a)
+            d.mode = CH_FWD;
+            if (c == 0) {
+              d.netid = 0; d.param_off = 0; d.x = o_sn2; d.ldx = ld_x; d.pp0 = o_pp; d.pp1 = o_pp + T; d.y = o_y;
+            } else {
+              d.netid = 1; d.param_off = P + (c - 1) * Q; d.x = o_qin; d.ldx = ld_xu;
+              d.zb = c == 1 ? o_st0 : o_st2; d.hb = c == 1 ? o_st1 : o_st3; d.y = o_y + c * 16 * ld_y;
+            }
+          } else if (ph == 1 && c < 2) {       // target critics on (s', a')
+            d.mode = CH_FWD;
+            d.netid = 1; d.base_sel = 1; d.param_off = c * Q; d.x = o_qin2; d.ldx = ld_xu;
+            d.pp0 = o_pp + 2 * c * T; d.pp1 = d.pp0 + T; d.y = o_y + (c + 1) * 16 * ld_y;
+          } else if (ph == 2) {                // critics backward: dgrad (c < 2) beside wgrad
+            d.mode = c < 2 ? CH_DGRAD : CH_WGRAD;
+            d.netid = 1; d.param_off = P + net * Q; d.x = o_qin; d.ldx = ld_xu;
+            d.pp0 = o_pp + 2 * net * T; d.pp1 = d.pp0 + T; d.zb = net ? o_st2 : o_st0; d.hb = net ? o_st3 : o_st1;
+            d.y = o_dy + net * 16 * ld_y;
+            d.slab_sel = 2; d.slab_off = net * Q;
+          }
+        } else {                               // actor + alpha role
+          if (ph == 0 && c == 0) {
+            d.mode = CH_FWD;
+            d.netid = 0; d.param_off = 0; d.x = o_sn; d.ldx = ld_x; d.zb = o_st0; d.hb = o_st1; d.y = o_y;
+          } else if (ph == 1 && c < 2) {
+            d.mode = CH_FWD;
+            d.netid = 1; d.param_off = P + c * Q; d.x = o_qin; d.ldx = ld_xu;
+            d.pp0 = o_pp + 2 * c * T; d.pp1 = d.pp0 + T; d.zb = c == 0 ? o_st2 : o_st3; d.y = o_y + (c + 1) * 16 * ld_y;
+          } else if (ph == 2 && c < 2) {
+            d.mode = CH_DGRAD;
+            d.netid = 1; d.param_off = P + net * Q; d.pp0 = o_pp + 2 * net * T; d.pp1 = d.pp0 + T; d.zb = net ? o_st3 : o_st2;
+            d.y = o_dy + net * 16 * ld_y; d.dx = o_dx + net * 16 * ld_xu;
+          } else if (ph == 3 && c < 2) {
+            d.mode = c == 0 ? CH_DGRAD : CH_WGRAD;
+            d.netid = 0; d.param_off = 0; d.x = o_sn; d.ldx = ld_x; d.pp0 = o_pp; d.pp1 = o_pp + T; d.zb = o_st0; d.hb = o_st1;
+            d.y = o_dy; d.slab_sel = 1; d.slab_off = 0;
+          }
+        }
+        A->tab[role][ph][c] = d;
+      }
+}
+
 static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, const mbpo_p2p_desc *xd = nullptr) {
   SacPlan pl;
   int rc = sac_plan(d, &pl, true);
@@ -809,6 +856,7 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
   A.pi = pl.pi; A.q = pl.q; A.qt = pl.qt;
   A.sh_pi = NetShape{pl.pi.dims[0], pl.pi.n_layers, pl.pi.dims[pl.pi.n_layers], pl.pi.act};
   A.sh_q = NetShape{pl.q.dims[0], pl.q.n_layers, pl.q.dims[pl.q.n_layers], pl.q.act};
+  sac_chain_table(pl, d->row_len, &A);
   A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.D = d->row_len;
   A.batch = d->batch; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std;
   A.log_alpha = d->params + pl.NP - 1;

@@ -23,7 +23,7 @@ for mode in ("warm (same params re-read)", "cold (params rewritten by apply)"):
         up.sgd_step(batch) if mode.startswith("cold") else up.grads_only(batch) if hasattr(up, "grads_only") else up.sgd_step(batch)
         torch.cuda.synchronize()
         if it >= 10:
-            s = stamps.cpu()[:32].reshape(2, 16).clone(); fine = stamps.cpu()[40:47].clone(); wg = stamps.cpu()[48:52].clone(); print('  wgrad hidden step (critic B2, chain 2 wave 0): wgrad %d  bgrad %d  barrier %d' % tuple(int(wg[i+1]-wg[i]) for i in range(3))); print('  fwd hidden step (actor F0, wave 0): request %d  compute %d  barrier %d | request %d  compute %d  barrier %d' % tuple(int(fine[i+1]-fine[i]) for i in range(6)))
+            s = stamps.cpu()[:32].reshape(2, 16).clone(); print('  section after phase 1: chain set-up + first-layer request %d / %d cycles (critic / actor role), rest of the section %d / %d' % (int(s[0,14]-s[0,5]), int(s[1,14]-s[1,5]), int(s[0,6]-s[0,14]), int(s[1,6]-s[1,14]))); fine = stamps.cpu()[40:47].clone(); wg = stamps.cpu()[48:52].clone(); print('  wgrad hidden step (critic B2, chain 2 wave 0): wgrad %d  bgrad %d  barrier %d' % tuple(int(wg[i+1]-wg[i]) for i in range(3))); print('  fwd hidden step (actor F0, wave 0): request %d  compute %d  barrier %d | request %d  compute %d  barrier %d' % tuple(int(fine[i+1]-fine[i]) for i in range(6)))
             acc = s if acc is None else acc + s
     lib.mbpo_debug_set_stamps(C.c_void_p(0))
     acc = acc.double() / 10
