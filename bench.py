@@ -290,11 +290,11 @@ def main():
             "sac_updates_per_s": GRAD_UPDATES * args.steps / dt,
             "sac_update_samples_per_s": world * BATCH * GRAD_UPDATES * args.steps / dt,
             "params_finite": finite,
-            "roofline": {"bound": "mfma", "kernel": "k_sac_fwd_bwd<64>", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "k_sac_fwd_bwd<64,4>", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "avg_launch_us": t_kernel * 1e6, "algorithmic_flop_per_launch": BATCH * flop_per_sample,
                          "launches_per_step": GRAD_UPDATES},
-            "rollout_kernel": {"kernel": "k_model_rollout<64>", "avg_launch_us": t_roll * 1e6,
+            "rollout_kernel": {"kernel": "k_model_rollout64", "avg_launch_us": t_roll * 1e6,
                                "transitions_per_s_alone": N_ENVS * S_STEPS / t_roll,
                                "achieved_tflops": N_ENVS * S_STEPS * flop_per_transition / t_roll / 1e12,
                                "frac_of_fp32_mfma_peak": N_ENVS * S_STEPS * flop_per_transition / t_roll / 1e12 / FP32_MFMA_PEAK_TFLOPS},
