@@ -337,6 +337,29 @@ int mbpo_adamw_step(float *params, const float *grads, float *adam_m, float *ada
                     float wd, float grad_scale, int32_t apply_if_finite, float *target, float tau, float *grad_norm_out,
                     float *workspace, void *stream);
 
+/* ---- N3: ensemble model learning (the step before the rollout path) ------------------------------------
+ * Not in the reference (its model would come from the external `bsm` package, setup.py:22).  Gradient of every member's
+ * Gaussian negative log-likelihood on its own minibatch of true transitions, with exactly the parameterisation the rollout
+ * kernel consumes: (mu, raw) = MLP_e([x, u]); mean = mu (+ x if predict_delta); sigma = softplus(raw) + min_std;
+ *   loss_e = mean_b sum_d [ 0.5 ((x'_d - mean_d)/sigma_d)^2 + log sigma_d ].
+ * rows: [R, row_len] transitions (x at column 0, u at x_dim, next_obs at next_obs_off); idx: [E, batch] row indices (one
+ * bootstrapped minibatch per member); grads [E * n_params] in the dynamics' flat layout; metrics [E] = loss_e.
+ * Apply with mbpo_adamw_step on the whole flat vector (members are independent, AdamW is elementwise).  Hidden width 64. */
+typedef struct mbpo_ens_train_desc {
+  int32_t x_dim, u_dim;
+  mbpo_mlp_desc dynamics;
+  const float *rows;
+  int32_t row_len, next_obs_off;
+  const int32_t *idx;
+  int64_t batch;
+  int32_t predict_delta;
+  float min_std;
+  float *grads, *metrics, *workspace;
+} mbpo_ens_train_desc;
+
+int64_t mbpo_ens_nll_workspace_floats(const mbpo_ens_train_desc *d);
+int mbpo_ens_nll_grads(const mbpo_ens_train_desc *d, void *stream);
+
 /* ---- one-shot all-reduce over xGMI peer memory (multi-GPU SAC gradient exchange) ------------------------
  * replaces: the live form of the reference's jax.lax.pmean(grad) (sac/utils.py:29-33) for vectors small enough that a
  *           collective is pure latency.  Every rank owns an exchange REGION (mbpo_p2p_alloc -> 64-byte IPC handle, passed to

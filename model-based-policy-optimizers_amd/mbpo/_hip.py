@@ -82,6 +82,13 @@ class RolloutDesc(C.Structure):
     ]
 
 
+class EnsTrainDesc(C.Structure):
+    """mbpo_ens_train_desc"""
+    _fields_ = [("x_dim", C.c_int32), ("u_dim", C.c_int32), ("dynamics", MlpDesc), ("rows", C.c_void_p), ("row_len", C.c_int32),
+                ("next_obs_off", C.c_int32), ("idx", C.c_void_p), ("batch", C.c_int64), ("predict_delta", C.c_int32),
+                ("min_std", C.c_float), ("grads", C.c_void_p), ("metrics", C.c_void_p), ("workspace", C.c_void_p)]
+
+
 class SacDesc(C.Structure):
     _fields_ = [
         ("x_dim", C.c_int32), ("u_dim", C.c_int32),
@@ -209,6 +216,10 @@ def _bind_optional(lib: C.CDLL) -> None:
     if fn is not None:
         fn.restype = C.c_int64
         fn.argtypes = [i32, i32, vp, i64]
+    lib.mbpo_ens_nll_workspace_floats.restype = C.c_int64
+    lib.mbpo_ens_nll_workspace_floats.argtypes = [C.POINTER(EnsTrainDesc)]
+    lib.mbpo_ens_nll_grads.restype = C.c_int
+    lib.mbpo_ens_nll_grads.argtypes = [C.POINTER(EnsTrainDesc), vp]
     # one-shot peer-memory all-reduce (csrc/p2p.hip)
     lib.mbpo_p2p_region_bytes.restype = C.c_int64
     lib.mbpo_p2p_region_bytes.argtypes = [i32, i64]

@@ -587,3 +587,41 @@ class AdamW:
                                        self.count.data_ptr(), self.n, self.lr, self.wd, grad_scale, int(self.apply_if_finite),
                                        ptr(target), tau, self.grad_norm.data_ptr(), self.workspace.data_ptr(),
                                        current_stream_ptr()), "mbpo_adamw_step")
+
+
+class EnsembleNllGrad:
+    """Drives mbpo_ens_nll_grads: per-member Gaussian NLL loss and gradient on per-member minibatches (N3)."""
+
+    def __init__(self, *, x_dim: int, u_dim: int, spec: MlpSpec, batch: int, device, predict_delta: bool = True, min_std: float = 1e-3):
+        self.lib = load()
+        self.x_dim, self.u_dim, self.spec, self.batch = x_dim, u_dim, spec, int(batch)
+        self.device = torch.device(device)
+        self.E, self.n_params = spec.n_nets, spec.n_params
+        d = _hip.EnsTrainDesc()
+        d.x_dim, d.u_dim, d.batch = x_dim, u_dim, self.batch
+        d.predict_delta, d.min_std = int(predict_delta), min_std
+        self.desc = d
+        self.grads = torch.zeros(self.E * self.n_params, device=self.device, dtype=torch.float32)
+        self.metrics = torch.zeros(self.E, device=self.device, dtype=torch.float32)
+        self.workspace = None
+
+    def __call__(self, params: torch.Tensor, rows: torch.Tensor, idx: torch.Tensor, next_obs_off: Optional[int] = None) -> torch.Tensor:
+        _req(params, "params"); _req(rows, "rows"); _req(idx, "idx", torch.int32)
+        if params.numel() != self.E * self.n_params:
+            raise ValueError("params must hold E * n_params floats")
+        if rows.dim() != 2 or tuple(idx.shape) != (self.E, self.batch):
+            raise ValueError(f"rows must be [R, D] and idx [{self.E},{self.batch}]")
+        d = self.desc
+        d.dynamics = self.spec.desc(params)
+        d.rows, d.row_len = rows.data_ptr(), rows.shape[1]
+        d.next_obs_off = self.x_dim + self.u_dim + 2 if next_obs_off is None else next_obs_off
+        d.idx = idx.data_ptr()
+        d.grads, d.metrics = self.grads.data_ptr(), self.metrics.data_ptr()
+        if self.workspace is None:
+            nws = self.lib.mbpo_ens_nll_workspace_floats(C.byref(d))
+            if nws < 0:
+                check(int(nws), "mbpo_ens_nll_workspace_floats")
+            self.workspace = torch.zeros(int(nws), device=self.device, dtype=torch.float32)
+        d.workspace = self.workspace.data_ptr()
+        check(self.lib.mbpo_ens_nll_grads(C.byref(d), current_stream_ptr()), "mbpo_ens_nll_grads")
+        return self.grads

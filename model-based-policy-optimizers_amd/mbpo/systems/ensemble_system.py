@@ -59,6 +59,39 @@ class EnsembleDynamics(Dynamics[EnsembleDynamicsParams]):
         flat = torch.cat([lecun_uniform_flat(self.dims, gen) for _ in range(self.n_members)])
         return EnsembleDynamicsParams(params=flat.to(self.device))
 
+    def fit(self, dynamics_params: EnsembleDynamicsParams, rows: torch.Tensor, num_steps: int, batch_size: int = 256,
+            learning_rate: float = 1e-3, weight_decay: float = 0.0, key: int = 0, predict_delta: bool = True,
+            min_std: float = 1e-3, n_rows: Optional[int] = None, next_obs_off: Optional[int] = None):
+        """Model learning (N3 — not in the reference, whose model would come from `bsm`): `num_steps` AdamW steps on the
+        members' Gaussian negative log-likelihood, each member on its own bootstrapped minibatch (sampling with replacement
+        from rows[:n_rows]; Philox randint on the device).  `rows` are true-buffer transition rows (obs, action, reward,
+        discount, next_obs, ...).  Updates dynamics_params.params in place; returns (dynamics_params, losses [num_steps, E])."""
+        dev = self.device
+        rows = rows.to(dev, torch.float32).contiguous()
+        R = int(rows.shape[0] if n_rows is None else n_rows)
+        if R <= 0:
+            raise ValueError("no transitions to fit on")
+        E = self.n_members
+        if getattr(self, "_fit_cfg", None) != (batch_size, predict_delta, min_std, learning_rate, weight_decay):
+            self._nll = ops.EnsembleNllGrad(x_dim=self.x_dim, u_dim=self.u_dim, spec=self.spec, batch=batch_size, device=dev,
+                                            predict_delta=predict_delta, min_std=min_std)
+            self._opt = ops.AdamW(E * self.spec.n_params, dev, learning_rate, weight_decay, apply_if_finite=True)
+            self._fit_cfg = (batch_size, predict_delta, min_std, learning_rate, weight_decay)
+            self._fit_state = torch.tensor([R, 0, 0, R], device=dev, dtype=torch.int32)
+            self._fit_idx = torch.zeros(E * batch_size, device=dev, dtype=torch.int32)
+            self._fit_scratch = torch.zeros(E * batch_size, 1, device=dev, dtype=torch.float32)
+        self._fit_state[0] = R
+        self._fit_state[3] = R
+        losses = torch.zeros(num_steps, E, device=dev, dtype=torch.float32)
+        seed = K.PRNGKey(key)
+        col0 = rows[:, :1].contiguous()          # the sampler gathers something; one column keeps that cheap
+        for it in range(num_steps):
+            ops.replay_sample(col0, self._fit_state, E * batch_size, seed=seed, offset=it, out=self._fit_scratch, idx_out=self._fit_idx)
+            g = self._nll(dynamics_params.params, rows, self._fit_idx.view(E, batch_size), next_obs_off=next_obs_off)
+            self._opt.step(dynamics_params.params, g)
+            losses[it].copy_(self._nll.metrics)
+        return dynamics_params, losses
+
     def member_outputs(self, x: torch.Tensor, u: torch.Tensor, dynamics_params: EnsembleDynamicsParams) -> torch.Tensor:
         """[E, N, 2*x_dim] raw member outputs — mbpo_ensemble_mlp_forward."""
         xu = torch.cat([x.reshape(-1, self.x_dim), u.reshape(-1, self.u_dim)], dim=1).to(self.device, torch.float32).contiguous()

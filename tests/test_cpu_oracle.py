@@ -178,3 +178,33 @@ def test_rollout_episode_autoreset_bookkeeping():
     assert torch.equal(st2.steps, torch.full((N,), 1.0))
     # observation chain: obs[s+1] == next_obs[s]
     assert torch.equal(rows[1:, :, 0:3], rows[:-1, :, 6:9])
+
+
+def test_ensemble_nll_oracle_matches_finite_differences():
+    """oracle/ensemble.py (N3, build-defined loss): autograd gradient vs central differences in fp64, and the closed form of the
+    loss at a known point (zero weights: mean = x, sigma = softplus(0) + min_std)."""
+    import math
+    import torch
+    from oracle import ensemble as oens
+    from oracle import nets as onets
+    g = torch.Generator().manual_seed(0)
+    X, U, E, B = 3, 1, 2, 8
+    dims = [X + U, 64, 2 * X]
+    P = onets.n_params(dims)
+    params = torch.cat([onets.init_mlp_flat(dims, g, torch.float64) for _ in range(E)])
+    rows = torch.randn(40, 2 * X + U + 2, generator=g, dtype=torch.float64)
+    idx = torch.randint(0, 40, (E, B), generator=g)
+    grads, losses = oens.nll_grads(params, dims, E, rows, idx, X, U, True, 1e-3)
+    for j in (0, 5, P - 1, P + 7, 2 * P - 3):
+        e = j // P
+        hp = params.clone(); hp[j] += 1e-6
+        hm = params.clone(); hm[j] -= 1e-6
+        fd = (oens.nll_grads(hp, dims, E, rows, idx, X, U)[1][e] - oens.nll_grads(hm, dims, E, rows, idx, X, U)[1][e]) / 2e-6
+        assert abs(float(fd) - float(grads[j])) <= 1e-6 + 1e-5 * abs(float(grads[j]))
+    zero = torch.zeros(E * P, dtype=torch.float64)
+    _, l0 = oens.nll_grads(zero, dims, E, rows, idx, X, U, True, 1e-3)
+    sig = math.log(2.0) + 1e-3
+    for e in range(E):
+        b = rows[idx[e]]
+        want = (0.5 * ((b[:, X + U + 2:] - b[:, :X]) / sig) ** 2 + math.log(sig)).sum(1).mean()
+        assert abs(float(l0[e]) - float(want)) < 1e-12
