@@ -360,6 +360,25 @@ typedef struct mbpo_ens_train_desc {
 int64_t mbpo_ens_nll_workspace_floats(const mbpo_ens_train_desc *d);
 int mbpo_ens_nll_grads(const mbpo_ens_train_desc *d, void *stream);
 
+/* ---- N4: iCEM trajectory optimizer, device side (trajectory_optimizers/icem_optimizer.py:135-252) ---------------------
+ * One iteration = mbpo_icem_sample -> mbpo_model_rollout(actions = the sampled sequences) -> mbpo_icem_update.
+ * mbpo_icem_sample: coloured noise (utils/general_utils.py:81-208, powerlaw_psd_gaussian, as a direct inverse real DFT; Philox
+ *   stream ICEM) per (sample, action dim) series of length horizon; candidate = clip(mean + noise*std, u_min, u_max) (:186-187);
+ *   the n_prev previous elites are appended (:190); every candidate is replicated over n_particles envs:
+ *   actions [horizon][(n_samples+n_prev)*n_particles][u_dim] (env = candidate*n_particles + particle),
+ *   candidates [(n_samples+n_prev)][horizon][u_dim].  u_min/u_max are [u_dim] device vectors.
+ * mbpo_icem_update: values[c] = mean (use_max: max) over particles of mean_t reward (:146-163) from the rollout's step-major
+ *   transition rows; elites = the n_elites best in np.argsort order; mean <- alpha*mean + (1-alpha)*elite mean, std likewise on
+ *   the population variance (:199-209); best_value/best_sequence keep the best elite seen (:212-221); the n_prev best elites
+ *   go to prev_elites (:227).  workspace: n_candidates int32.  State vectors are [horizon*u_dim] device floats. */
+int mbpo_icem_sample(const float *mean, const float *std, const float *prev_elites, const float *u_min, const float *u_max,
+                     int32_t n_samples, int32_t n_prev, int32_t horizon, int32_t u_dim, int32_t n_particles, float exponent,
+                     uint64_t seed, uint64_t offset, const float *offset_dev, float *actions, float *candidates, void *stream);
+int mbpo_icem_update(const float *rows, int32_t row_len, int32_t reward_col, int32_t n_candidates, int32_t n_particles,
+                     int32_t horizon, int32_t u_dim, const float *candidates, int32_t n_elites, int32_t n_prev, float alpha,
+                     int32_t use_max, float *mean, float *std, float *best_value, float *best_sequence, float *prev_elites,
+                     float *values, int32_t *workspace, void *stream);
+
 /* ---- one-shot all-reduce over xGMI peer memory (multi-GPU SAC gradient exchange) ------------------------
  * replaces: the live form of the reference's jax.lax.pmean(grad) (sac/utils.py:29-33) for vectors small enough that a
  *           collective is pure latency.  Every rank owns an exchange REGION (mbpo_p2p_alloc -> 64-byte IPC handle, passed to

@@ -172,6 +172,7 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
 #define MBPO_STREAM_SAC_ACTOR 7u
 #define MBPO_STREAM_PERM 8u
 #define MBPO_STREAM_ENTROPY 9u
+#define MBPO_STREAM_ICEM 10u
 
 // standard normal for element `idx` of stream `stream` at call counter `offset` under `seed`
 // (Box-Muller on two of the four Philox words; one Philox call per element keeps draws order-independent).

@@ -1,0 +1,198 @@
+// icem.hip — N4: the iCEM trajectory optimizer's device side (trajectory_optimizers/icem_optimizer.py:135-252).
+//   k_icem_sample  coloured-noise candidates: powerlaw_psd_gaussian (utils/general_utils.py:81-208) restated as a direct inverse
+//                  real DFT (horizons are tens of steps: H*K MACs per series, no FFT library), mean + noise*std, clip, previous
+//                  elites appended, every candidate replicated over its particles in the rollout kernel's open-loop layout.
+//   (rollouts)     mbpo_model_rollout with `actions` (rollout_actions, utils/optimizer_utils.py:11-59) — csrc/rollout.hip
+//   k_icem_values  objective: summarize_particles( mean_t reward )                                      (:146-163)
+//   k_icem_update  one workgroup: stable rank of the candidates (np.argsort), elite mean / population variance, soft update,
+//                  best-so-far, the elite fraction carried to the next iteration                          (:196-232)
+// HBM-bound bookkeeping around the rollout; everything stays on the device, the host only sequences the launches.
+#include "common.hpp"
+
+#define ICEM_MAX_HU 4096
+
+struct IcemSampleArgs {
+  const float *mean, *std, *prev_elites, *u_min, *u_max;
+  int S, Kp, H, U, P;
+  float exponent;
+  unsigned long long seed, offset;
+  const float *offset_dev;
+  float *actions;      // [H][(S+Kp)*P][U]
+  float *candidates;   // [S+Kp][H][U]
+};
+
+__global__ void __launch_bounds__(256) k_icem_sample(IcemSampleArgs A) {
+  extern __shared__ float s_tab[];             // cos / sin tables [H][K]
+  const int H = A.H, U = A.U, K = H / 2 + 1;
+  float *s_cos = s_tab, *s_sin = s_tab + H * K, *s_scale = s_sin + H * K;
+  for (int i = threadIdx.x; i < H * K; i += blockDim.x) {
+    const int t = i / K, k = i - t * K;
+    const float ang = 6.28318530717958647692f * (float)((k * t) % H) / (float)H;
+    s_cos[i] = cosf(ang);
+    s_sin[i] = sinf(ang);
+  }
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const float f = fmaxf((float)k / (float)H, 1.0f / (float)H);      // rfftfreq, low-frequency cutoff fmin = 1/samples
+    s_scale[k] = powf(f, -0.5f * A.exponent);
+  }
+  __syncthreads();
+  // theoretical output std (general_utils.py:177-180)
+  float wsum = 0.f;
+  for (int k = 1; k < K; ++k) {
+    float w = s_scale[k];
+    if (k == K - 1) w *= (1.0f + (float)(H % 2)) * 0.5f;
+    wsum += w * w;
+  }
+  const float sigma = 2.0f * sqrtf(wsum) / (float)H;
+  const unsigned long long off = A.offset + (A.offset_dev ? (unsigned long long)A.offset_dev[0] : 0ull);
+  const int NC = A.S + A.Kp, N = NC * A.P;
+  for (int sd = blockIdx.x * blockDim.x + threadIdx.x; sd < NC * U; sd += gridDim.x * blockDim.x) {
+    const int c = sd / U, d = sd - c * U;
+    if (c >= A.S) {        // previous elites ride along unchanged (:190)
+      for (int t = 0; t < H; ++t) {
+        const float a = A.prev_elites[((long long)(c - A.S) * H + t) * U + d];
+        A.candidates[((long long)c * H + t) * U + d] = a;
+        for (int p = 0; p < A.P; ++p) A.actions[((long long)t * N + c * A.P + p) * U + d] = a;
+      }
+      continue;
+    }
+    // Fourier coefficients of this series
+    float sr[65], si[65];
+    for (int k = 0; k < K; ++k) {
+      const unsigned long long base = ((unsigned long long)sd * K + k) * 2ull;
+      sr[k] = philox_normal(A.seed, off, MBPO_STREAM_ICEM, base) * s_scale[k];
+      si[k] = philox_normal(A.seed, off, MBPO_STREAM_ICEM, base + 1ull) * s_scale[k];
+    }
+    if (!(H % 2)) {        // even length: the Nyquist coefficient is real (:193-197)
+      si[K - 1] = 0.f;
+      sr[K - 1] *= 1.41421356237309504880f;
+    }
+    si[0] = 0.f;           // the DC coefficient is real (:199-201)
+    sr[0] *= 1.41421356237309504880f;
+    for (int t = 0; t < H; ++t) {
+      // irfft: y_t = (1/H) [ s_0 + 2 sum_{0<k<H/2} (sr_k cos - si_k sin) + (H even) s_{H/2} cos(pi t) ]
+      float y = sr[0];
+      const int kmax = (H % 2) ? K : K - 1;
+      for (int k = 1; k < kmax; ++k) y += 2.0f * (sr[k] * s_cos[t * K + k] - si[k] * s_sin[t * K + k]);
+      if (!(H % 2)) y += sr[K - 1] * s_cos[t * K + K - 1];
+      y = y / (float)H / sigma;
+      float a = A.mean[t * U + d] + y * A.std[t * U + d];                      // :186
+      a = fminf(fmaxf(a, A.u_min[d]), A.u_max[d]);                              // :187
+      A.candidates[((long long)c * H + t) * U + d] = a;
+      for (int p = 0; p < A.P; ++p) A.actions[((long long)t * N + c * A.P + p) * U + d] = a;
+    }
+  }
+}
+
+extern "C" int mbpo_icem_sample(const float *mean, const float *std, const float *prev_elites, const float *u_min, const float *u_max,
+                                int32_t n_samples, int32_t n_prev, int32_t horizon, int32_t u_dim, int32_t n_particles, float exponent,
+                                uint64_t seed, uint64_t offset, const float *offset_dev, float *actions, float *candidates, void *stream) {
+  MBPO_REQUIRE(mean && std && u_min && u_max && actions && candidates, MBPO_ERR_ARG, "icem_sample: null pointer");
+  MBPO_REQUIRE(n_samples > 0 && n_prev >= 0 && u_dim > 0 && n_particles > 0, MBPO_ERR_ARG, "icem_sample: bad sizes");
+  MBPO_REQUIRE(horizon >= 2 && horizon <= 128, MBPO_ERR_UNSUPPORTED, "icem_sample: horizon must be in [2, 128]");
+  MBPO_REQUIRE(n_prev == 0 || prev_elites, MBPO_ERR_ARG, "icem_sample: prev_elites is NULL");
+  IcemSampleArgs A{mean, std, prev_elites, u_min, u_max, n_samples, n_prev, horizon, u_dim, n_particles, exponent, seed, offset, offset_dev,
+                   actions, candidates};
+  const int K = horizon / 2 + 1;
+  const size_t lds = sizeof(float) * (2ull * horizon * K + K);
+  const int work = (n_samples + n_prev) * u_dim;
+  hipLaunchKernelGGL(k_icem_sample, dim3((work + 255) / 256), dim3(256), lds, (hipStream_t)stream, A);
+  MBPO_CHECK_LAUNCH("icem_sample");
+  return MBPO_OK;
+}
+
+// ---- objective + elite update ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_icem_values(const float *rows, int row_len, int reward_col, int NC, int P, int H, int use_max,
+                                                      float *values) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= NC) return;
+  const long long N = (long long)NC * P;
+  float agg = 0.f;
+  for (int p = 0; p < P; ++p) {
+    float acc = 0.f;
+    for (int t = 0; t < H; ++t) acc += rows[((long long)t * N + (long long)c * P + p) * row_len + reward_col];
+    const float m = acc / (float)H;                                   // jnp.mean(transitions.reward, axis=-1)
+    agg = (p == 0) ? m : (use_max ? fmaxf(agg, m) : agg + m);
+  }
+  values[c] = use_max ? agg : agg / (float)P;                          // summarize_raw_samples: mean (or max under optimism)
+}
+
+struct IcemUpdateArgs {
+  const float *values, *candidates;
+  int NC, H, U, n_elites, n_prev;
+  float alpha;
+  float *mean, *std, *best_value, *best_sequence, *prev_elites;
+  int *rank;   // workspace [NC]
+};
+
+__global__ void __launch_bounds__(1024) k_icem_update(IcemUpdateArgs A) {
+  const int tid = threadIdx.x, NC = A.NC, HU = A.H * A.U;
+  // stable ascending rank = position in np.argsort(values)
+  for (int c = tid; c < NC; c += 1024) {
+    const float v = A.values[c];
+    int r = 0;
+    for (int j = 0; j < NC; ++j) {
+      const float w = A.values[j];
+      r += (w < v || (w == v && j < c)) ? 1 : 0;
+    }
+    A.rank[c] = r;
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int first = NC - A.n_elites;      // elites = sorted positions [first, NC)
+  // the best elite (rank NC-1) and the best-so-far sequence (:212-221)
+  __shared__ int s_best;
+  for (int c = tid; c < NC; c += 1024)
+    if (A.rank[c] == NC - 1) s_best = c;
+  __syncthreads();
+  const int cb = s_best;
+  const float best_elite = A.values[cb];
+  const bool take = A.best_value[0] <= best_elite;
+  for (int i = tid; i < HU; i += 1024) {
+    // elite mean / population variance of element i over the elites, in sorted order
+    float m = 0.f;
+    for (int c = 0; c < NC; ++c)
+      if (A.rank[c] >= first) m += A.candidates[(long long)c * HU + i];
+    m /= (float)A.n_elites;
+    float v = 0.f;
+    for (int c = 0; c < NC; ++c)
+      if (A.rank[c] >= first) {
+        const float dlt = A.candidates[(long long)c * HU + i] - m;
+        v += dlt * dlt;
+      }
+    v /= (float)A.n_elites;
+    const float sd = A.std[i];
+    const float nm = A.mean[i] * A.alpha + (1.f - A.alpha) * m;          // :205
+    const float nv = sd * sd * A.alpha + (1.f - A.alpha) * v;            // :206
+    A.mean[i] = nm;
+    A.std[i] = sqrtf(nv);                                                // :209
+    if (take) A.best_sequence[i] = A.candidates[(long long)cb * HU + i];
+  }
+  // elites[-n_prev:] in sorted order -> next iteration's prev_elites (:227)
+  for (int c = tid; c < NC; c += 1024) {
+    const int pos = A.rank[c] - (NC - A.n_prev);
+    if (pos >= 0)
+      for (int i = 0; i < HU; ++i) A.prev_elites[(long long)pos * HU + i] = A.candidates[(long long)c * HU + i];
+  }
+  __syncthreads();
+  if (tid == 0 && take) A.best_value[0] = best_elite;
+}
+
+extern "C" int mbpo_icem_update(const float *rows, int32_t row_len, int32_t reward_col, int32_t n_candidates, int32_t n_particles,
+                                int32_t horizon, int32_t u_dim, const float *candidates, int32_t n_elites, int32_t n_prev, float alpha,
+                                int32_t use_max, float *mean, float *std, float *best_value, float *best_sequence, float *prev_elites,
+                                float *values, int32_t *workspace, void *stream) {
+  MBPO_REQUIRE(rows && candidates && mean && std && best_value && best_sequence && values && workspace, MBPO_ERR_ARG, "icem_update: null pointer");
+  MBPO_REQUIRE(n_candidates > 0 && n_particles > 0 && horizon > 0 && u_dim > 0, MBPO_ERR_ARG, "icem_update: bad sizes");
+  MBPO_REQUIRE(n_elites > 0 && n_elites <= n_candidates && n_prev >= 0 && n_prev <= n_elites, MBPO_ERR_ARG, "icem_update: bad elite counts");
+  MBPO_REQUIRE(n_prev == 0 || prev_elites, MBPO_ERR_ARG, "icem_update: prev_elites is NULL");
+  MBPO_REQUIRE(reward_col >= 0 && reward_col < row_len, MBPO_ERR_ARG, "icem_update: bad reward column");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_icem_values, dim3((n_candidates + 255) / 256), dim3(256), 0, st, rows, row_len, reward_col, n_candidates, n_particles,
+                     horizon, use_max, values);
+  IcemUpdateArgs A{values, candidates, n_candidates, horizon, u_dim, n_elites, n_prev, alpha, mean, std, best_value, best_sequence,
+                   prev_elites, workspace};
+  hipLaunchKernelGGL(k_icem_update, dim3(1), dim3(1024), 0, st, A);
+  MBPO_CHECK_LAUNCH("icem_update");
+  return MBPO_OK;
+}

@@ -220,6 +220,11 @@ def _bind_optional(lib: C.CDLL) -> None:
     lib.mbpo_ens_nll_workspace_floats.argtypes = [C.POINTER(EnsTrainDesc)]
     lib.mbpo_ens_nll_grads.restype = C.c_int
     lib.mbpo_ens_nll_grads.argtypes = [C.POINTER(EnsTrainDesc), vp]
+    u64 = C.c_uint64
+    lib.mbpo_icem_sample.restype = C.c_int
+    lib.mbpo_icem_sample.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u64, u64, vp, vp, vp, vp]
+    lib.mbpo_icem_update.restype = C.c_int
+    lib.mbpo_icem_update.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     # one-shot peer-memory all-reduce (csrc/p2p.hip)
     lib.mbpo_p2p_region_bytes.restype = C.c_int64
     lib.mbpo_p2p_region_bytes.argtypes = [i32, i64]

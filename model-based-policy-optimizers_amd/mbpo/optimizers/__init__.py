@@ -3,3 +3,4 @@ from mbpo.optimizers.base_optimizer import BaseOptimizer
 from mbpo.optimizers.policy_optimizers.brax_optimizers import BraxOptimizer, BraxOutput, BraxState, PPOOptimizer, SACOptimizer
 from mbpo.optimizers.policy_optimizers.bptt_optimizer import BPTTOptimizer, BPTTState
 from mbpo.optimizers.policy_optimizers.sac.sac import SAC
+from mbpo.optimizers.trajectory_optimizers.icem_optimizer import iCEMOptimizer, iCemOptimizerState, iCemParams, iCemTO

@@ -19,6 +19,7 @@ STREAM_SAC_CRITIC = 6
 STREAM_SAC_ACTOR = 7
 STREAM_PERM = 8
 STREAM_ENTROPY = 9
+STREAM_ICEM = 10
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):

@@ -208,3 +208,31 @@ def test_ensemble_nll_oracle_matches_finite_differences():
         b = rows[idx[e]]
         want = (0.5 * ((b[:, X + U + 2:] - b[:, :X]) / sig) ** 2 + math.log(sig)).sum(1).mean()
         assert abs(float(l0[e]) - float(want)) < 1e-12
+
+
+def test_icem_oracle_noise_and_update_properties():
+    """oracle/icem.py: powerlaw_psd_gaussian is normalised to unit variance for every exponent and series length parity, its
+    spectrum falls as f^-beta; the elite update follows np.argsort (best last, ties by index) and the soft update formula."""
+    import numpy as np
+    from oracle import icem as oicem
+    rng = np.random.default_rng(0)
+    for H in (20, 21):
+        K = H // 2 + 1
+        for beta in (0.0, 1.0, 2.0):
+            y = oicem.powerlaw_psd_gaussian(beta, H, rng.standard_normal((20000, K)), rng.standard_normal((20000, K)))
+            assert y.shape == (20000, H)
+            assert abs(y.std() - 1.0) < 0.03, (H, beta, y.std())
+            spec = (np.abs(np.fft.rfft(y, axis=-1)) ** 2).mean(axis=0)
+            if beta > 0:
+                assert spec[1] > spec[K // 2] > spec[K - 2]          # coloured: power decreases with frequency
+    # deterministic candidates from the Philox stream: same (seed, offset) -> same samples, different offset -> different
+    a = oicem.sample_candidates(np.zeros((8, 2)), np.ones((8, 2)), np.zeros((1, 8, 2)), -1.0, 1.0, 16, 8, 2, 1.0, 11, 0)
+    b = oicem.sample_candidates(np.zeros((8, 2)), np.ones((8, 2)), np.zeros((1, 8, 2)), -1.0, 1.0, 16, 8, 2, 1.0, 11, 0)
+    c = oicem.sample_candidates(np.zeros((8, 2)), np.ones((8, 2)), np.zeros((1, 8, 2)), -1.0, 1.0, 16, 8, 2, 1.0, 11, 1)
+    assert np.array_equal(a, b) and not np.array_equal(a, c) and a.shape == (17, 8, 2) and np.abs(a).max() <= 1.0
+    vals = np.array([0.0, 3.0, 1.0, 3.0, -2.0])
+    cand = np.arange(5 * 2 * 1, dtype=np.float64).reshape(5, 2, 1)
+    m, s, bv, bs, pe = oicem.update(vals, cand, np.zeros((2, 1)), np.ones((2, 1)), -np.inf, np.zeros((2, 1)), 3, 2, 0.5)
+    assert bv == 3.0 and np.array_equal(bs, cand[3])                 # stable argsort: of the tied bests the later index is last
+    assert np.array_equal(pe, cand[[1, 3]])
+    assert np.allclose(m, 0.5 * cand[[2, 1, 3]].mean(0)) and np.allclose(s, np.sqrt(0.5 + 0.5 * cand[[2, 1, 3]].var(0)))
