@@ -221,7 +221,9 @@ def test_icem_oracle_noise_and_update_properties():
         for beta in (0.0, 1.0, 2.0):
             y = oicem.powerlaw_psd_gaussian(beta, H, rng.standard_normal((20000, K)), rng.standard_normal((20000, K)))
             assert y.shape == (20000, H)
-            assert abs(y.std() - 1.0) < 0.03, (H, beta, y.std())
+            # `sigma` (general_utils.py:177-180) normalises the non-DC power to one: unit variance about each series' own mean
+            nd = y - y.mean(axis=-1, keepdims=True)
+            assert abs(np.sqrt((nd ** 2).mean()) - 1.0) < 0.03, (H, beta)
             spec = (np.abs(np.fft.rfft(y, axis=-1)) ** 2).mean(axis=0)
             if beta > 0:
                 assert spec[1] > spec[K // 2] > spec[K - 2]          # coloured: power decreases with frequency
