@@ -110,6 +110,15 @@ class PPO:
         self.policy_spec = ops.MlpSpec(self.policy_dims, policy_activation, 1)
         self.dp = DataParallel(process_group)
         self._all_reduce = self.dp.all_reduce_fn()
+        # multi-GPU: the flat gradient and the normaliser sums go through peer memory (csrc/p2p.hpp) when the exchange regions can
+        # be set up and reproduce torch.distributed.all_reduce at start-up; otherwise the library collective stays
+        self.p2p = None
+        if self.dp.group is not None and self.dp.world_size > 1:
+            from mbpo.parallel import P2PExchange
+            n_pv = ops.MlpSpec(self.policy_dims).n_params + ops.MlpSpec(self.value_dims).n_params
+            self.p2p = P2PExchange.create(self.dp, n_pv, self.device)
+            if self.p2p is not None:
+                self._all_reduce = self.p2p.all_reduce_sum
         self.updater = ops.PpoUpdater(
             x_dim=self.x_dim, u_dim=self.u_dim, policy_dims=self.policy_dims, value_dims=self.value_dims, batch_size=batch_size,
             unroll_length=unroll_length, device=self.device, policy_activation=policy_activation,

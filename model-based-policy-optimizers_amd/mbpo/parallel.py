@@ -85,6 +85,8 @@ class P2PExchange:
         flag) before the next collective, so one rank's failure turns into `None` on every rank instead of a deadlock."""
         if dp.group is None or dp.world_size < 2 or os.environ.get("MBPO_P2P_ALLREDUCE", "1") == "0":
             return None
+        if not torch.cuda.is_available():       # no device, no peer memory: the (gloo) collective stays
+            return None
         import torch.distributed as dist
         device = torch.device(device)
         ex = cls(dp, n_max, device)
@@ -201,6 +203,8 @@ class P2PExchange:
     @classmethod
     def create(cls, dp: "DataParallel", n_max: int, device) -> Optional["P2PExchange"]:
         if dp.group is None or dp.world_size < 2 or os.environ.get("MBPO_P2P_ALLREDUCE", "1") == "0":
+            return None
+        if not torch.cuda.is_available():       # no device, no peer memory: the (gloo) collective stays
             return None
         import torch.distributed as dist
         device = torch.device(device)

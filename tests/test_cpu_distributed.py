@@ -37,6 +37,9 @@ def _worker(rank, world, port, tmpdir):
         keys = [None] * world
         dist.all_gather_object(keys, dp.rank_key(123))
         assert len(set(keys)) == world                      # per-rank keys differ
+        # no GPU here: the peer-memory exchange declines on every rank and the collective path stays
+        from mbpo.parallel import P2PExchange
+        assert P2PExchange.create(dp, 1000, "cuda:0") is None
 
         # ---- parameter broadcast
         g = torch.Generator().manual_seed(100 + rank)        # deliberately different per rank
