@@ -178,9 +178,16 @@ class BPTTOptimizer(BaseOptimizer):
                  sample_simulated_transitions: bool = True,
                  sampling_buffer_size: int = 10_000_000,
                  device=None,
+                 process_group=None,
                  *args, **kwargs):
         super().__init__(*args, **kwargs)
         _hip.load()                                   # fail loudly without the HIP library
+        # data-parallel ranks: every rank runs num_samples_per_gradient_update trajectories from its own sampling
+        # buffer; actor and critic gradients and the normalisers' sums are summed over the ranks (the mean through grad_scale),
+        # parameters start identical (rank-0 broadcast in init) and stay identical
+        from mbpo.parallel import DataParallel
+        self.dp = DataParallel(process_group)
+        self._all_reduce = self.dp.all_reduce_fn()
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.obs_dim, self.action_dim = int(obs_dim), int(action_dim)
         self.state_normalizer = Normalizer((self.obs_dim,))
@@ -260,6 +267,8 @@ class BPTTOptimizer(BaseOptimizer):
         critic_params = torch.cat([lecun_normal_flat(self.critic_dims, gen), lecun_normal_flat(self.critic_dims, gen)]).to(dev)
         gen = torch.Generator().manual_seed(int(actor_key) % (2 ** 63))
         actor_params = lecun_normal_flat(self.actor_dims, gen).to(dev)
+        self.dp.broadcast(actor_params)
+        self.dp.broadcast(critic_params)
         z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)
         system_params = self.system.init_params(system_key)
         if true_buffer_state is None:
@@ -331,7 +340,10 @@ class BPTTOptimizer(BaseOptimizer):
         ag(actor_params=w.actor_params, target_critic_params=w.target_critic_params, init_states=self._init_obs,
            state_mean=w.state_norm.mean, state_std=w.state_norm.std, reward_mean_std=self._reward_ms, offset=0,
            offset_dev=self._step_dev, **w.sys_kw)
-        self._actor_opt.step(w.actor_params, ag.grads)
+        gs = 1.0 / self.dp.world_size
+        if self._all_reduce is not None:
+            self._all_reduce(ag.grads)
+        self._actor_opt.step(w.actor_params, ag.grads, grad_scale=gs)
         # critic: K minibatches drawn with replacement from the n*H simulated transitions   (:380-419)
         ops.replay_sample(ag.transitions, self._traj_state, self._critic_idx.numel(), seed=critic_seed, offset=0,
                           offset_dev=self._step_dev, out=self._critic_rows, idx_out=self._critic_idx)
@@ -339,7 +351,9 @@ class BPTTOptimizer(BaseOptimizer):
         for k in range(self.critic_updates_per_policy_updates):
             cg = self._critic_grad(w.critic_params, ag.transitions, ag.lambda_values, self._critic_idx[k * B:(k + 1) * B],
                                    w.state_norm.mean, w.state_norm.std)
-            self._critic_opt.step(w.critic_params, cg, target=w.target_critic_params, tau=self.tau)
+            if self._all_reduce is not None:
+                self._all_reduce(cg)
+            self._critic_opt.step(w.critic_params, cg, target=w.target_critic_params, tau=self.tau, grad_scale=gs)
         # summary of this step (actor_grad_norm, critic_grad_norm, actor_loss, critic_loss)
         w.step_summary[0:1].copy_(self._actor_opt.grad_norm)
         w.step_summary[1:2].copy_(self._critic_opt.grad_norm)
@@ -347,10 +361,10 @@ class BPTTOptimizer(BaseOptimizer):
         w.step_summary[3:4].copy_(self._critic_grad.metrics)
         # normalisers on the simulated transitions (:475-476), then into the sampling buffer (:477-478)
         if self.normalize:
-            ops.running_stats_update(ag.transitions, 0, X, w.state_norm.vec, sums=self._stats_sums_x, workspace=self._stats_ws_x,
-                                     std_min=EPS, std_max=float("inf"))
-            ops.running_stats_update(ag.transitions, X + U, 1, w.reward_norm.vec, sums=self._stats_sums_r, workspace=self._stats_ws_r,
-                                     std_min=EPS, std_max=float("inf"))
+            ops.running_stats_update(ag.transitions, 0, X, w.state_norm.vec, all_reduce=self._all_reduce, sums=self._stats_sums_x,
+                                     workspace=self._stats_ws_x, std_min=EPS, std_max=float("inf"))
+            ops.running_stats_update(ag.transitions, X + U, 1, w.reward_norm.vec, all_reduce=self._all_reduce, sums=self._stats_sums_r,
+                                     workspace=self._stats_ws_r, std_min=EPS, std_max=float("inf"))
         if self.sample_simulated_transitions:
             buff = self.sampling_buffer.insert_rows(buff, ag.transitions)
         self._step_dev.add_(1.0)
@@ -403,7 +417,7 @@ class BPTTOptimizer(BaseOptimizer):
         self._critic_opt.load_state(bptt_state.critic_opt_state.mu, bptt_state.critic_opt_state.nu, bptt_state.critic_opt_state.count)
         self._step_dev.zero_()
         # per-train() Philox seeds; the step counter is the Philox offset (the reference re-splits a key every step)
-        seeds = tuple(K.split(train_key, 4)[:3])
+        seeds = tuple(self.dp.rank_key(k) for k in K.split(train_key, 4)[:3])    # ranks draw different states / noise / minibatches
         self._last_seeds = seeds                       # (initial-state sampling, action noise, critic minibatch) — for parity tests
         summaries = torch.zeros(self.train_steps, 6, device=self.device, dtype=torch.float32)
         prev_reward = torch.zeros((), device=self.device)

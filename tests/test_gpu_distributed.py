@@ -182,3 +182,51 @@ def test_sac_sgd_step_over_peer_memory_two_ranks(tmp_path):
     port = 35500 + (os.getpid() % 2000)
     mp.spawn(_p2p_sac_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"p2psac_ok{r}").exists() for r in range(world))
+
+
+def _bptt_worker(rank, world, port, tmpdir):
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mbpo.optimizers import BPTTOptimizer
+        from mbpo.replay import UniformSamplingQueue
+        from mbpo.systems import PendulumSystem
+        from mbpo.types import Transition
+        system = PendulumSystem()
+        s0 = system.reset()
+        dummy = Transition(observation=s0.x_next, action=torch.zeros(1, device=dev), reward=s0.reward, discount=torch.tensor(0.99, device=dev),
+                           next_observation=s0.x_next)
+        q = UniformSamplingQueue(64, dummy, 1, device=dev)
+        g = torch.Generator().manual_seed(0)
+        th = (torch.rand(32, generator=g) * 2 - 1) * 3.14159
+        obs = torch.stack([torch.cos(th), torch.sin(th), torch.zeros(32)], 1).to(dev)
+        sbs = q.insert(q.init(0), Transition(observation=obs, action=torch.zeros(32, 1, device=dev), reward=torch.zeros(32, device=dev),
+                                             discount=torch.ones(32, device=dev), next_observation=obs))
+        opt = BPTTOptimizer(obs_dim=3, action_dim=1, horizon=6, num_samples_per_gradient_update=16, train_steps=5, sampling_buffer_size=4096,
+                            process_group=dist.group.WORLD)
+        opt.set_system(system)
+        st = opt.init(key=100 + rank, true_buffer_state=sbs)        # different keys: the broadcast must make the nets identical
+        out = opt.train(bptt_state=st)
+        o = out.optimizer_state
+        for t in (o.actor_params, o.critic_params, o.target_critic_params, o.state_normalizer_state.vec):
+            assert bool(torch.isfinite(t).all())
+            ts = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(ts, t)
+            assert all(torch.equal(ts[0], x) for x in ts)            # replicas stay bit-identical
+        assert float(o.state_normalizer_state.size) == 5 * 16 * 6 * world
+        (Path(tmpdir) / f"bptt_ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bptt_data_parallel_two_ranks(tmp_path):
+    """BPTTOptimizer with a process group: gradients and normaliser sums are reduced, replicas stay bit-identical."""
+    world = 2
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_bptt_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"bptt_ok{r}").exists() for r in range(world))
