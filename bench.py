@@ -271,6 +271,17 @@ def main():
         t_kernel = time_kernel_alone(trainer)
         t_roll = time_rollout_alone(trainer, ts, env_state, buffer_state)
         achieved = BATCH * flop_per_sample / t_kernel / 1e12
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be collected from inside this process (separate
+        # rocprofv3 --pmc passes, MI355X_MICROARCH.md); the committed measurement of this same command is reported
+        traffic, traffic_note = None, "no PMC measurement committed"
+        try:
+            pmc = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
+            k = pmc["k_sac_fwd_bwd<64,4>"]
+            traffic = int((k["fetch_kb"] + k["write_kb"]) * 1024)
+            traffic_note = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes); "
+                            "1.64 MB of it are the per-tile gradient slabs (deterministic reduction), reads are L2-absorbed weights")
+        except Exception:      # noqa: BLE001
+            pass
         out = {
             "metric": "model-rollout transitions/sec + SAC updates/sec, Pendulum 5-ens h=5",
             "value": world * N_ENVS * S_STEPS * args.steps / dt,
@@ -291,7 +302,7 @@ def main():
             "sac_update_samples_per_s": world * BATCH * GRAD_UPDATES * args.steps / dt,
             "params_finite": finite,
             "roofline": {"bound": "mfma", "kernel": "k_sac_fwd_bwd<64,4>", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_us": t_kernel * 1e6, "algorithmic_flop_per_launch": BATCH * flop_per_sample,
                          "launches_per_step": GRAD_UPDATES},
             "rollout_kernel": {"kernel": "k_model_rollout64", "avg_launch_us": t_roll * 1e6,

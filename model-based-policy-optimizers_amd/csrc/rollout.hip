@@ -439,9 +439,9 @@ __global__ void __launch_bounds__(512) k_model_rollout(RolloutArgs A) {
 
 
 // ------------------------------------------------------------------------------------------------
-// H == 64: the rollout on phase runners (chain_run.hpp).  16 waves per 16-env tile:
+// H == 64: the rollout on phase runners (chain_run.hpp).  12 waves per 16-env tile:
 //   policy phase   waves 0..3 walk the policy chain in lockstep (SP = 4), one barrier per layer;
-//   model phase    waves 2e, 2e+1 walk member e's chain (SP = 2), up to 8 members side by side, one barrier per layer —
+//   model phase    waves 2e, 2e+1 walk member e's chain (SP = 2), up to 6 members side by side, one barrier per layer —
 //                  5 members x 64 MFMAs per layer is 2560 MFMA cycles per SIMD and layer: this phase is fp32-MFMA-throughput
 //                  bound on the CU, everything else is arranged to stay out of its way;
 //   next-layer weights are requested one step ahead (first layers before the preceding bookkeeping section);
@@ -475,12 +475,16 @@ extern "C" int mbpo_debug_set_rollout_stamps(void *buf) {
     AA.stamps[i] = t_;                                                               \
   }
 
-__global__ void __launch_bounds__(1024) k_model_rollout64(RolloutArgs64 AA) {
+// 12 waves (3 per SIMD -> 170 VGPRs each): with 16 waves the 128-register cap spilled 60 VGPRs into the step loop and the PMC
+// counters showed 63 MB of scratch writes per launch against 1 MB of transition rows (profiles/r01_pmc_traffic.json).
+// (Dealing the members 2,2,2,2,4 waves to level the MFMA load per SIMD was tried: the second runner instantiation brought
+// 26 spills back and the kernel got slower, 82 -> 92 us.)
+#define RO64_WAVES 12
+__global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs64 AA) {
   extern __shared__ __align__(16) float smem[];
   const RolloutArgs &A = AA.a;
   constexpr int HT = 4;
-  constexpr int MAXC = 8;   // member chains side by side (2 waves each)
-  const int tid_ = threadIdx.x, nthreads = 1024;
+  const int tid_ = threadIdx.x, nthreads = 64 * RO64_WAVES;
   const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   const int X = A.x_dim, U = A.u_dim, D = A.row_len;
   const int E = (A.system_kind == MBPO_SYS_ENSEMBLE) ? A.dyn.n_nets : 0;
@@ -718,7 +722,7 @@ __global__ void __launch_bounds__(1024) k_model_rollout64(RolloutArgs64 AA) {
       RO_STAMP(6);
       // ---- write the tile's 16 rows (the next step's section A works on the other row buffer) ----
       if (A.env_major) {
-        for (int r = wave; r < 16; r += 16) {
+        for (int r = wave; r < 16; r += RO64_WAVES) {
           const long long env = env0 + r;
           if (env < N)
             for (int c = lane; c < D; c += 64) A.transitions[(env * A.n_steps + s) * D + c] = s_row[r * D + c];
@@ -854,12 +858,12 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
     else AA.sh_pi = NetShape{X, 0, 2 * U, 0};
     if (E > 0) AA.sh_dyn = NetShape{A.dyn.dims[0], A.dyn.n_layers, A.dyn.dims[A.dyn.n_layers], A.dyn.act};
     else AA.sh_dyn = NetShape{X + U, 0, X, 0};
-    if (AA.a.n_chains > 8) AA.a.n_chains = 8;   // 16 waves = 8 member chains of 2 waves
+    if (AA.a.n_chains > RO64_WAVES / 2) AA.a.n_chains = RO64_WAVES / 2;   // member chains of 2 waves side by side
     if (AA.a.n_chains < 1) AA.a.n_chains = 1;
     lds = (fixed_f + 2ull * (AA.a.n_chains > 1 ? AA.a.n_chains : 1) * 16 * A.ld_h) * sizeof(float);
     rc = mbpo_ensure_lds<k_model_rollout64>(lds, "model_rollout");
     if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL(k_model_rollout64, dim3(grid), dim3(1024), lds, st, AA);
+    hipLaunchKernelGGL(k_model_rollout64, dim3(grid), dim3(64 * RO64_WAVES), lds, st, AA);
   } else if (H == 128) LAUNCH_RO(128) else LAUNCH_RO(256)
 #undef LAUNCH_RO
   MBPO_CHECK_LAUNCH("model_rollout");
