@@ -238,3 +238,21 @@ def test_icem_oracle_noise_and_update_properties():
     assert bv == 3.0 and np.array_equal(bs, cand[3])                 # stable argsort: of the tied bests the later index is last
     assert np.array_equal(pe, cand[[1, 3]])
     assert np.allclose(m, 0.5 * cand[[2, 1, 3]].mean(0)) and np.allclose(s, np.sqrt(0.5 + 0.5 * cand[[2, 1, 3]].var(0)))
+
+
+def test_oracle_reproduces_sac_step_golden():
+    """tests/golden/sac_step_small.npz (tests/golden/make_sac_step_golden.py): the fp64 oracle must reproduce the committed
+    gradients, losses and updated state — any edit to oracle/sac.py / oracle/nets.py that changes the arithmetic shows up here."""
+    import importlib.util
+    from pathlib import Path
+    import numpy as np
+    gdir = Path(__file__).resolve().parent / "golden"
+    spec = importlib.util.spec_from_file_location("make_sac_step_golden", gdir / "make_sac_step_golden.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gold = np.load(gdir / "sac_step_small.npz")
+    cfg, st, batch, noise, nm, ns = mod.build()
+    np.testing.assert_array_equal(st.params.numpy(), gold["params"])          # the generator's inputs are what the file holds
+    out = mod.evaluate(cfg, st, batch, noise, nm, ns)
+    for k, v in out.items():
+        np.testing.assert_allclose(v, gold[k], rtol=1e-12, atol=1e-13, err_msg=k)
