@@ -33,6 +33,7 @@ struct BpttArgs {
   float *w_xs, *w_as, *w_eps, *w_rs, *w_vs, *w_km;
   float *slabs, *extras;
   int ld_x, ld_xu, ld_h, ld_y, ld_ye, LH, EC;
+  NetShape sh_pi, sh_cr, sh_dyn;
 };
 
 // analytic pendulum step + vector-Jacobian product (dynamics/pendulum_dynamics.py:29-63)
@@ -116,7 +117,9 @@ template <int H>
 __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int tid_ = threadIdx.x, nthreads = blockDim.x;
+  const int tid = tid_, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   const int X = A.X, U = A.U, HZ = A.H;
   const int ld_x = A.ld_x, ld_xu = A.ld_xu, ld_h = A.ld_h, ld_y = A.ld_y, ld_ye = A.ld_ye, LH = A.LH, EC = A.EC;
   const int T = 16 * ld_h;
@@ -184,17 +187,22 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
       if (i < A.n) A.w_xs[(i * (HZ + 1)) * X + c] = v;
     }
     __syncthreads();
+#pragma nounroll
     for (int t = 0; t < HZ; ++t) {
+      // per-lane addresses are re-derived every step: hoisted out of the time loop they filled all 256 VGPRs and spilled 340 more
+      const int tid = opaque(tid_), lane = tid & 63;
       for (int idx = tid; idx < 16 * X; idx += nthreads) {
         const int r = idx / X, c = idx - r * X;
         s_on[r * ld_x + c] = (s_x[r * ld_x + c] - A.s_mean[c]) / A.s_std[c];
       }
       __syncthreads();
       {  // policy(stop_gradient(obs))  (optimizer_utils.py:85-86, bptt_optimizer.py:305-325)
-        FwdChain fc{&A.pi, A.pi.params, s_on, ld_x, s_B, s_B + T, nullptr, nullptr, s_y};
-        for (int l = 0; l < PL; ++l) {
-          if (wave < 4) group_fwd_step<HT, 4>(fc, l, ld_h, ld_y, wave, lane);
-          __syncthreads();
+        if (wave < 4) {
+          WSet<HT, 4> R4;
+          chain_fwd_prefetch<HT, 4>(R4, A.sh_pi, A.pi.params, wave, lane);
+          chain_fwd_run<HT, 4>(A.sh_pi, A.pi.params, s_on, ld_x, s_B, s_B + T, nullptr, nullptr, s_y, ld_y, ld_h, PL, wave, lane, R4);
+        } else {
+          chain_idle_run(PL);
         }
       }
       for (int idx = tid; idx < 16 * U; idx += nthreads) {
@@ -226,11 +234,14 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
         for (int e0 = 0; e0 < E; e0 += EC) {
           const int e = e0 + chain2;
           const bool on = chain2 < EC && e < E;
-          FwdChain fc{&A.dyn, A.dyn.params + (long long)(on ? e : 0) * A.dyn.net_stride, s_xu, ld_xu, s_B + chain2 * 2 * T,
-                      s_B + chain2 * 2 * T + T, nullptr, nullptr, s_ye + chain2 * 16 * ld_ye};
-          for (int l = 0; l < DL; ++l) {
-            if (on) group_fwd_step<HT, 2>(fc, l, ld_h, ld_ye, sub2, lane);
-            __syncthreads();
+          if (on) {
+            const float *ep = A.dyn.params + (long long)e * A.dyn.net_stride;
+            WSet<HT, 2> R2;
+            chain_fwd_prefetch<HT, 2>(R2, A.sh_dyn, ep, sub2, lane);
+            chain_fwd_run<HT, 2>(A.sh_dyn, ep, s_xu, ld_xu, s_B + chain2 * 2 * T, s_B + chain2 * 2 * T + T, nullptr, nullptr,
+                                 s_ye + chain2 * 16 * ld_ye, ld_ye, ld_h, DL, sub2, lane, R2);
+          } else {
+            chain_idle_run(DL);
           }
           for (int idx = tid; idx < 16 * X; idx += nthreads) {
             const int r = idx / X, c = idx - r * X;
@@ -258,12 +269,14 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
       }
       __syncthreads();
       {  // target critics on the normalised next state (:338-343)
-        FwdChain fc;
-        if (chain2 == 0) fc = FwdChain{&A.cr, cr1, s_nn, ld_x, s_B, s_B + T, nullptr, nullptr, s_yv};
-        else fc = FwdChain{&A.cr, cr2, s_nn, ld_x, s_B + 2 * T, s_B + 3 * T, nullptr, nullptr, s_yv + 16 * 4};
-        for (int l = 0; l < CL; ++l) {
-          if (chain2 < 2) group_fwd_step<HT, 2>(fc, l, ld_h, 4, sub2, lane);
-          __syncthreads();
+        if (chain2 < 2) {
+          const float *cp = chain2 ? cr2 : cr1;
+          WSet<HT, 2> R2;
+          chain_fwd_prefetch<HT, 2>(R2, A.sh_cr, cp, sub2, lane);
+          chain_fwd_run<HT, 2>(A.sh_cr, cp, s_nn, ld_x, s_B + 2 * chain2 * T, s_B + 2 * chain2 * T + T, nullptr, nullptr,
+                               s_yv + chain2 * 16 * 4, 4, ld_h, CL, sub2, lane, R2);
+        } else {
+          chain_idle_run(CL);
         }
       }
       if (tid < 16) {
@@ -318,7 +331,9 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
     for (int idx = tid; idx < 16 * ld_x; idx += nthreads) s_gx[idx] = 0.f;
     __syncthreads();
     // ================================================= BACKWARD =================================================
+#pragma nounroll
     for (int t = HZ - 1; t >= 0; --t) {
+      const int tid = opaque(tid_), lane = tid & 63;
       // ---- reload the step: x_t, x_{t+1}, a_t, eps_t
       for (int idx = tid; idx < 16 * X; idx += nthreads) {
         const int r = idx / X, c = idx - r * X;
@@ -342,14 +357,18 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
       // ---- recompute: policy (z,h kept) || target critics (z kept)
       float *zc1 = s_B, *zc2 = s_B + LH * T, *ppc = s_B + 2 * LH * T;   // critics: z | z | 4 pp tiles
       {
-        FwdChain fc;
-        if (chain2 == 0) fc = FwdChain{&A.pi, A.pi.params, s_on, ld_x, nullptr, nullptr, zp, hp, s_y};
-        else if (chain2 == 1) fc = FwdChain{&A.cr, cr1, s_nn, ld_x, ppc, ppc + T, zc1, nullptr, s_yv};
-        else fc = FwdChain{&A.cr, cr2, s_nn, ld_x, ppc + 2 * T, ppc + 3 * T, zc2, nullptr, s_yv + 16 * 4};
         const int Lm = PL > CL ? PL : CL;
-        for (int l = 0; l < Lm; ++l) {
-          if (chain2 < 3) group_fwd_step<HT, 2>(fc, l, ld_h, chain2 == 0 ? ld_y : 4, sub2, lane);
-          __syncthreads();
+        if (chain2 < 3) {
+          const bool pol = chain2 == 0;
+          const NetShape shr = pol ? A.sh_pi : A.sh_cr;
+          const float *rp = pol ? A.pi.params : (chain2 == 1 ? cr1 : cr2);
+          float *rpp = pol ? nullptr : ppc + 2 * (chain2 - 1) * T;
+          WSet<HT, 2> R2;
+          chain_fwd_prefetch<HT, 2>(R2, shr, rp, sub2, lane);
+          chain_fwd_run<HT, 2>(shr, rp, pol ? s_on : s_nn, ld_x, rpp, pol ? nullptr : rpp + T, pol ? zp : (chain2 == 1 ? zc1 : zc2),
+                               pol ? hp : nullptr, pol ? s_y : s_yv + (chain2 - 1) * 16 * 4, pol ? ld_y : 4, ld_h, Lm, sub2, lane, R2);
+        } else {
+          chain_idle_run(Lm);
         }
       }
       // ---- dL/dV_t on the arg-min target critic
@@ -365,16 +384,15 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
       __syncthreads();
       {  // critic input gradients
         const int net = chain2 - 1;
-        const float *dcur = s_dyv + (net > 0 ? 16 * 4 : 0);
-        int ldc = 4;
-        float *d0 = ppc + (net > 0 ? 2 * T : 0), *d1 = d0 + T;
-        for (int l = CL - 1; l >= 0; --l) {
-          float *dn = (l & 1) ? d1 : d0;
-          if (chain2 == 1 || chain2 == 2)
-            group_bwd_dgrad_layer<HT, 2>(A.cr, net ? cr2 : cr1, l, dcur, ldc, net ? zc2 : zc1, ld_h, dn, s_dxc + (net > 0 ? 16 * ld_x : 0), ld_x, sub2, lane);
-          __syncthreads();
-          dcur = dn;
-          ldc = ld_h;
+        if (chain2 == 1 || chain2 == 2) {
+          const float *cp = net ? cr2 : cr1;
+          float *d0 = ppc + (net > 0 ? 2 * T : 0);
+          WSet<HT, 2> R2;
+          chain_dgrad_prefetch<HT, 2>(R2, A.sh_cr, cp, sub2, lane);
+          chain_dgrad_run<HT, 2>(A.sh_cr, cp, s_dyv + (net > 0 ? 16 * 4 : 0), 4, net ? zc2 : zc1, d0, d0 + T, s_dxc + (net > 0 ? 16 * ld_x : 0),
+                                 ld_x, ld_h, CL, sub2, lane, R2);
+        } else {
+          chain_idle_run(CL);
         }
       }
       for (int idx = tid; idx < 16 * X; idx += nthreads) {
@@ -396,10 +414,12 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
           const bool on = chain2 < EC && e < E;
           const float *ep = A.dyn.params + (long long)(on ? e : 0) * A.dyn.net_stride;
           float *ze = s_B + chain2 * (LH + 2) * T, *ppe = ze + LH * T;
-          FwdChain fc{&A.dyn, ep, s_xu, ld_xu, ppe, ppe + T, ze, nullptr, s_ye + chain2 * 16 * ld_ye};
-          for (int l = 0; l < DL; ++l) {
-            if (on) group_fwd_step<HT, 2>(fc, l, ld_h, ld_ye, sub2, lane);
-            __syncthreads();
+          if (on) {
+            WSet<HT, 2> R2;
+            chain_fwd_prefetch<HT, 2>(R2, A.sh_dyn, ep, sub2, lane);
+            chain_fwd_run<HT, 2>(A.sh_dyn, ep, s_xu, ld_xu, ppe, ppe + T, ze, nullptr, s_ye + chain2 * 16 * ld_ye, ld_ye, ld_h, DL, sub2, lane, R2);
+          } else {
+            chain_idle_run(DL);
           }
           for (int idx = tid; idx < EC * 16 * dout; idx += nthreads) {
             const int cc = idx / (16 * dout), rem = idx - cc * 16 * dout;
@@ -408,14 +428,13 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
           }
           __syncthreads();
           {
-            const float *dcur = s_dye + chain2 * 16 * ld_ye;
-            int ldc = ld_ye;
-            for (int l = DL - 1; l >= 0; --l) {
-              float *dn = (l & 1) ? ppe + T : ppe;
-              if (on) group_bwd_dgrad_layer<HT, 2>(A.dyn, ep, l, dcur, ldc, ze, ld_h, dn, s_dxe + chain2 * 16 * ld_xu, ld_xu, sub2, lane);
-              __syncthreads();
-              dcur = dn;
-              ldc = ld_h;
+            if (on) {
+              WSet<HT, 2> R2;
+              chain_dgrad_prefetch<HT, 2>(R2, A.sh_dyn, ep, sub2, lane);
+              chain_dgrad_run<HT, 2>(A.sh_dyn, ep, s_dye + chain2 * 16 * ld_ye, ld_ye, ze, ppe, ppe + T, s_dxe + chain2 * 16 * ld_xu, ld_xu, ld_h,
+                                     DL, sub2, lane, R2);
+            } else {
+              chain_idle_run(DL);
             }
           }
           for (int idx = tid; idx < 16 * (X + U); idx += nthreads) {
@@ -468,18 +487,16 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
       // ---- policy backward: chain 0 = delta(total), chain 1 = delta(log-prob path) with input gradient, chain 2 = wgrad
       {
         float *dt0 = s_B, *dt1 = s_B + T, *dl0 = s_B + 2 * T, *dl1 = s_B + 3 * T;
-        const float *dcur_t = s_dyt, *dcur_l = s_dyl;
-        int ldc = ld_y;
         const bool accum = !(first_tile && t == HZ - 1);
-        for (int l = PL - 1; l >= 0; --l) {
-          float *dnt = (l & 1) ? dt1 : dt0, *dnl = (l & 1) ? dl1 : dl0;
-          if (chain2 == 0) group_bwd_dgrad_layer<HT, 2>(A.pi, A.pi.params, l, dcur_t, ldc, zp, ld_h, dnt, nullptr, ld_x, sub2, lane);
-          else if (chain2 == 1) group_bwd_dgrad_layer<HT, 2>(A.pi, A.pi.params, l, dcur_l, ldc, zp, ld_h, dnl, s_don, ld_x, sub2, lane);
-          else if (chain2 == 2) group_bwd_wgrad_layer<HT, 2>(A.pi, l, s_on, ld_x, hp, ld_h, dcur_t, ldc, slab, sub2, lane, accum);
-          __syncthreads();
-          dcur_t = dnt;
-          dcur_l = dnl;
-          ldc = ld_h;
+        if (chain2 < 2) {
+          WSet<HT, 2> R2;
+          chain_dgrad_prefetch<HT, 2>(R2, A.sh_pi, A.pi.params, sub2, lane);
+          chain_dgrad_run<HT, 2>(A.sh_pi, A.pi.params, chain2 ? s_dyl : s_dyt, ld_y, zp, chain2 ? dl0 : dt0, chain2 ? dl1 : dt1,
+                                 chain2 ? s_don : nullptr, ld_x, ld_h, PL, sub2, lane, R2);
+        } else if (chain2 == 2) {
+          chain_wgrad_run<HT, 2>(A.sh_pi, s_on, ld_x, hp, s_dyt, ld_y, dt0, dt1, slab, accum, ld_h, PL, sub2, lane);
+        } else {
+          chain_idle_run(PL);
         }
       }
       // ---- dL/dx_t = model/reward x-part + policy-input path (through the state normaliser)
@@ -680,6 +697,10 @@ extern "C" int mbpo_bptt_actor_grads(const mbpo_bptt_desc *d, void *stream) {
   A.w_xs = ws + pl.o_xs; A.w_as = ws + pl.o_as; A.w_eps = ws + pl.o_eps; A.w_rs = ws + pl.o_rs; A.w_vs = ws + pl.o_vs;
   A.w_km = ws + pl.o_km; A.slabs = ws + pl.o_slabs; A.extras = ws + pl.o_extras;
   A.ld_x = pl.ld_x; A.ld_xu = pl.ld_xu; A.ld_h = pl.ld_h; A.ld_y = pl.ld_y; A.ld_ye = pl.ld_ye; A.LH = pl.LH; A.EC = pl.EC;
+  A.sh_pi = NetShape{A.pi.dims[0], A.pi.n_layers, A.pi.dims[A.pi.n_layers], A.pi.act};
+  A.sh_cr = NetShape{A.cr.dims[0], A.cr.n_layers, A.cr.dims[A.cr.n_layers], A.cr.act};
+  if (A.system_kind == MBPO_SYS_ENSEMBLE) A.sh_dyn = NetShape{A.dyn.dims[0], A.dyn.n_layers, A.dyn.dims[A.dyn.n_layers], A.dyn.act};
+  else A.sh_dyn = NetShape{A.X + A.U, 0, A.X, 0};
   rc = mbpo_ensure_lds<k_bptt_actor<64>>(pl.lds, "bptt_actor_grads");
   if (rc != MBPO_OK) return rc;
   hipStream_t st = (hipStream_t)stream;

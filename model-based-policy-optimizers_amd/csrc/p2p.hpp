@@ -16,7 +16,7 @@
 #define MBPO_P2P_MAX_RANKS 16
 #endif
 #define P2P_FLAG_STRIDE 16          // uint32 words between two flags (64 B apart)
-#define P2P_SPIN_MAX (1 << 22)
+#define P2P_SPIN_MAX (1 << 24)   // ~20-30 s of polling: longer than any start-up skew between ranks, still finite
 
 struct P2pDev {
   int world, rank;
