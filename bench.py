@@ -196,69 +196,85 @@ def main():
             dist.init_process_group(backend=backend, **({"device_id": device} if backend == "nccl" else {}))
         pg = dist.group.WORLD
 
-    log(f"building trainer on {device} (world={world})")
-    trainer = build_trainer(device, pg, use_graph=not args.no_graph)
-    from mbpo.utils import keys as K
-    ts = trainer.init_training_state(7)
-    env_state = trainer.reset_envs(trainer.env, 11 + rank, N_ENVS)
-    buffer_state = trainer.replay_buffer.init(13 + rank)
-    ts, env_state, buffer_state, _ = trainer.prefill_replay_buffer(ts, env_state, buffer_state, 17 + rank)
-    torch.cuda.synchronize()
-    log("prefill done")
+    def measure():
+        log(f"building trainer on {device} (world={world})")
+        trainer = build_trainer(device, pg, use_graph=not args.no_graph)
+        from mbpo.utils import keys as K
+        ts = trainer.init_training_state(7)
+        env_state = trainer.reset_envs(trainer.env, 11 + rank, N_ENVS)
+        buffer_state = trainer.replay_buffer.init(13 + rank)
+        ts, env_state, buffer_state, _ = trainer.prefill_replay_buffer(ts, env_state, buffer_state, 17 + rank)
+        torch.cuda.synchronize()
+        log("prefill done")
 
-    use_graph = trainer.use_graph
-    key = 23 + rank
+        use_graph = trainer.use_graph
+        key = 23 + rank
 
-    def one_step():
-        nonlocal ts, env_state, buffer_state, key
-        key, k = K.split(key)
-        ts, env_state, buffer_state = trainer.training_step(ts, env_state, buffer_state, k)
+        def one_step():
+            nonlocal ts, env_state, buffer_state, key
+            key, k = K.split(key)
+            ts, env_state, buffer_state = trainer.training_step(ts, env_state, buffer_state, k)
 
-    graph = None
-    # warm-up: W eager steps (also compiles/loads every kernel), then capture
-    for _ in range(max(args.warmup, 1)):
-        one_step()
-    torch.cuda.synchronize()
-    log(f"{max(args.warmup, 1)} eager warm-up steps done")
-    if use_graph:
-        # With ranks > 1 the captured step contains the RCCL all-reduces; if this RCCL/torch build cannot capture them
-        # every rank falls back to eager launches together (the capture fails identically on all ranks).
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                trainer.training_step(ts, env_state, buffer_state, 29)
-            log("graph captured")
-            graph.replay()   # one untimed replay
-            torch.cuda.synchronize()
-            log("graph replayed once")
-        except Exception as e:  # noqa: BLE001
-            if pg is None:
-                raise
-            log(f"hipGraph capture with collectives failed ({type(e).__name__}: {e}); running eagerly")
-            graph = None
-            torch.cuda.synchronize()
+        graph = None
+        # warm-up: W eager steps (also compiles/loads every kernel), then capture
+        for _ in range(max(args.warmup, 1)):
+            one_step()
+        torch.cuda.synchronize()
+        log(f"{max(args.warmup, 1)} eager warm-up steps done")
+        if use_graph:
+            # With ranks > 1 the captured step contains the RCCL all-reduces; if this RCCL/torch build cannot capture them
+            # every rank falls back to eager launches together (the capture fails identically on all ranks).
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    trainer.training_step(ts, env_state, buffer_state, 29)
+                log("graph captured")
+                graph.replay()   # one untimed replay
+                torch.cuda.synchronize()
+                log("graph replayed once")
+            except Exception as e:  # noqa: BLE001
+                if pg is None:
+                    raise
+                log(f"hipGraph capture with collectives failed ({type(e).__name__}: {e}); running eagerly")
+                graph = None
+                torch.cuda.synchronize()
 
-    def barrier():
+        def barrier():
+            if pg is not None:
+                import torch.distributed as dist
+                dist.barrier()
+
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if graph is not None:
+                graph.replay()
+            else:
+                one_step()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
         if pg is not None:
             import torch.distributed as dist
-            dist.barrier()
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
 
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if graph is not None:
-            graph.replay()
-        else:
-            one_step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if pg is not None:
+        return trainer, ts, env_state, buffer_state, graph, dt
+
+    trainer, ts, env_state, buffer_state, graph, dt = measure()
+    if pg is not None and getattr(trainer, "p2p", None) is not None:
+        # a peer exchange that timed out poisons the gradients with NaN (csrc/p2p.hpp); such a run is not a measurement:
+        # every rank then repeats the whole run over the RCCL all-reduce
         import torch.distributed as dist
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        bad = torch.tensor([int(trainer.p2p.status() != 0 or not bool(torch.isfinite(trainer.updater.params).all()))],
+                           device=device, dtype=torch.int32)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad):
+            log("peer-memory exchange failed during the run; measuring again with torch.distributed all_reduce")
+            os.environ["MBPO_P2P_ALLREDUCE"] = "0"
+            trainer, ts, env_state, buffer_state, graph, dt = measure()
 
     log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
     finite = bool(torch.isfinite(trainer.updater.params).all())

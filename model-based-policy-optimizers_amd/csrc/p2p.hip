@@ -70,6 +70,15 @@ extern "C" int mbpo_p2p_open(const void *handle64, int32_t peer_device, void **p
   void *p = nullptr;
   e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
   MBPO_REQUIRE(e == hipSuccess, MBPO_ERR_LAUNCH, "p2p_open: %s", hipGetErrorString(e));
+  // touch the mapping through the runtime's copy path first: a mapping this device cannot reach then comes back as an error
+  // code here (and the caller keeps the library collective) rather than as a memory fault inside the exchange kernels
+  unsigned int word = 0;
+  e = hipMemcpy(&word, p, sizeof(word), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipIpcCloseMemHandle(p);
+    MBPO_REQUIRE(false, MBPO_ERR_UNSUPPORTED, "p2p_open: mapped peer region is not readable from device %d: %s", dev, hipGetErrorString(e));
+  }
   *ptr = p;
   return MBPO_OK;
 }

@@ -51,7 +51,9 @@ __device__ __forceinline__ void p2p_push(const P2pDev &P, unsigned epoch, long l
 __device__ __forceinline__ bool p2p_wait(const P2pDev &P, unsigned want) {
   __shared__ int s_p2p_ok;
   if (threadIdx.x == 0) {
-    int ok = 1;
+    // a timeout is sticky: once this rank has given up on an exchange every later wait fails at once (the host sees the
+    // status word and raises) instead of spending the full bounded wait per launch
+    int ok = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u;
     for (int r = 0; r < P.world && ok; ++r) {
       ok = 0;
       for (int spin = 0; spin < P2P_SPIN_MAX; ++spin) {

@@ -18,7 +18,7 @@ from typing import Any, Callable, Dict, List, Optional, Sequence
 
 import torch
 
-from mbpo import ops
+from mbpo import _hip, ops
 from mbpo.optimizers.policy_optimizers.brax_utils.base import State
 from mbpo.optimizers.policy_optimizers.sac.sac import Evaluator, RunningStatisticsState, policy_act
 from mbpo.parallel import DataParallel
@@ -227,6 +227,9 @@ class PPO:
         for _ in range(self.num_training_steps_per_epoch):
             training_state, state, key = self.training_step(training_state, state, key)
         acc = self.updater.metrics_accum.cpu()
+        if self.p2p is not None and self.p2p.status() != 0:
+            raise _hip.MbpoHipError("PPO: the peer-memory gradient exchange timed out on this rank; "
+                                    "set MBPO_P2P_ALLREDUCE=0 to use the RCCL all-reduce")
         cnt = max(float(acc[4]), 1.0)
         metrics = {'total_loss': float(acc[0]) / cnt, 'policy_loss': float(acc[1]) / cnt, 'v_loss': float(acc[2]) / cnt,
                    'entropy_loss': float(acc[3]) / cnt}

@@ -22,7 +22,7 @@ from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from mbpo import ops
+from mbpo import _hip, ops
 from mbpo.optimizers.policy_optimizers.brax_utils.base import State
 from mbpo.parallel import DataParallel
 from mbpo.replay import ReplayBufferState, UniformSamplingQueue
@@ -341,6 +341,10 @@ class SAC:
             training_state, env_state, buffer_state = self.training_step(training_state, env_state, buffer_state, k)
             done_steps += 1
         acc = self.updater.metrics_accum.cpu()
+        if self.p2p is not None and self.p2p.status() != 0:
+            # a rank never arrived within the bounded wait (csrc/p2p.hpp): its gradients were poisoned with NaN, not skipped
+            raise _hip.MbpoHipError("SAC: the peer-memory gradient exchange timed out on this rank; "
+                                    "set MBPO_P2P_ALLREDUCE=0 to use the RCCL all-reduce")
         cnt = max(float(acc[4]), 1.0)
         metrics = {'critic_loss': float(acc[0]) / cnt, 'actor_loss': float(acc[1]) / cnt, 'alpha_loss': float(acc[2]) / cnt,
                    'alpha': float(acc[3]) / cnt, 'buffer_current_size': float(self.replay_buffer.size(buffer_state))}

@@ -155,106 +155,6 @@ class P2PExchange:
         self.desc = d
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
-        """In-place SUM over ranks (no-op without a group)."""
-        if self.group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t
-
-    def all_reduce_fn(self):
-        """Callable for ops.SacUpdater / ops.running_stats_update, or None when there is nothing to reduce."""
-        return self.all_reduce_sum if self.group is not None else None
-
-    def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
-        if self.group is not None:
-            import torch.distributed as dist
-            dist.broadcast(t, src=src, group=self.group)
-        return t
-
-    def rank_key(self, key: int) -> int:
-        """Per-rank key for everything that must DIFFER across ranks (env resets, rollout noise, replay sampling)."""
-        return K.split(key, self.world_size)[self.rank] if self.world_size > 1 else key
-
-    def shard(self, n: int) -> range:
-        """Contiguous shard of `n` units (envs) owned by this rank; n must divide evenly."""
-        if n % self.world_size:
-            raise ValueError(f"{n} units do not shard evenly over {self.world_size} ranks")
-        per = n // self.world_size
-        return range(self.rank * per, (self.rank + 1) * per)
-
-
-class P2PExchange:
-    """Peer-memory exchange regions for the one-shot all-reduce (csrc/p2p.hpp): every rank allocates a region, the 64-byte IPC
-    handles travel through the process group (all_gather_object), every rank maps every peer's region.
-
-    `create` returns None (the caller then keeps the RCCL all-reduce) when the regions cannot be set up, when
-    MBPO_P2P_ALLREDUCE=0, or when the self-check — one exchange of a rank-dependent vector compared with
-    torch.distributed.all_reduce — does not reproduce the library's result on every rank."""
-
-    def __init__(self, dp: "DataParallel", n_max: int, device: torch.device):
-        from mbpo import _hip
-        self.lib = _hip.load()
-        self._hip = _hip
-        self.dp, self.n_max, self.device = dp, int(n_max), device
-        self.own = C.c_void_p()
-        self.peers = {}
-        self.desc = None
-
-    @classmethod
-    def create(cls, dp: "DataParallel", n_max: int, device) -> Optional["P2PExchange"]:
-        if dp.group is None or dp.world_size < 2 or os.environ.get("MBPO_P2P_ALLREDUCE", "1") == "0":
-            return None
-        if not torch.cuda.is_available():       # no device, no peer memory: the (gloo) collective stays
-            return None
-        import torch.distributed as dist
-        device = torch.device(device)
-        ex = cls(dp, n_max, device)
-        ok = 1
-        try:
-            ex._setup()
-        except Exception as e:      # noqa: BLE001 — any failure means: use the library collective
-            ok = 0
-            ex._err = repr(e)
-        flag = torch.tensor([ok], device=device, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=dp.group)
-        if int(flag) == 0:
-            ex.close()
-            return None
-        ok = 1 if ex._self_check() else 0
-        flag = torch.tensor([ok], device=device, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=dp.group)
-        if int(flag) == 0:
-            ex.close()
-            return None
-        return ex
-
-    def _setup(self):
-        import torch.distributed as dist
-        _hip, lib, dp = self._hip, self.lib, self.dp
-        nbytes = lib.mbpo_p2p_region_bytes(dp.world_size, self.n_max)
-        if nbytes < 0:
-            _hip.check(int(nbytes), "mbpo_p2p_region_bytes")
-        handle = (C.c_ubyte * 64)()
-        _hip.check(lib.mbpo_p2p_alloc(nbytes, C.byref(self.own), handle), "mbpo_p2p_alloc")
-        mine = (bytes(handle), torch.cuda.current_device() if self.device.index is None else self.device.index, os.getpid())
-        gathered = [None] * dp.world_size
-        dist.all_gather_object(gathered, mine, group=dp.group)
-        d = _hip.P2pDesc()
-        d.world, d.rank, d.n_max = dp.world_size, dp.rank, self.n_max
-        my_dev = mine[1]
-        for r, (h, dev_idx, _pid) in enumerate(gathered):
-            if r == dp.rank:
-                d.regions[r] = self.own.value
-                continue
-            p = C.c_void_p()
-            hb = (C.c_ubyte * 64).from_buffer_copy(h)
-            _hip.check(lib.mbpo_p2p_open(hb, -1 if dev_idx == my_dev else dev_idx, C.byref(p)), "mbpo_p2p_open")
-            self.peers[r] = p
-            d.regions[r] = p.value
-        self.desc = d
-        dist.barrier(group=dp.group)
-
-    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         """In-place SUM of a contiguous fp32 device tensor (numel <= n_max) over the ranks."""
         _hip = self._hip
         _hip.require_device_tensor(t, "t")
