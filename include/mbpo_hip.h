@@ -152,8 +152,10 @@ int mbpo_replay_sample(const float *data, int64_t max_size, int32_t row_len, con
  *           std = clip(sqrt(max(summed_variance,0)/count), std_min, std_max)   (brax: 1e-6, 1e6)
  * The same update IS BPTT's Normalizer.update (bptt_optimizer.py:52-67) with summed_variance = std^2 * size:
  *   sum (x - new_mean)^2 + size*(mean - new_mean)^2 == sum d*(d - upd); its floor is std_min = 1e-8, no ceiling.
- * stats (device, fp32) = [count, mean[x], summed_variance[x], std[x]];  workspace >= 64*x_dim floats.
+ * stats (device, fp32) = [count, mean[x], summed_variance[x], std[x]];
+ * workspace >= mbpo_running_stats_workspace_floats(x_dim) floats (one partial per workgroup and column).
  */
+int64_t mbpo_running_stats_workspace_floats(int32_t x_dim);
 int mbpo_running_stats_reduce(const float *rows, int64_t n_rows, int32_t row_len, int32_t col_off, int32_t x_dim,
                               const float *stats, float *sums, float *workspace, int32_t pass, void *stream);
 int mbpo_running_stats_apply(float *stats, const float *sums, int32_t x_dim, float std_min, float std_max, void *stream);

@@ -11,12 +11,21 @@ __device__ __forceinline__ float opt_wave_sum(float v) {
   return v;
 }
 
+// at most ADAMW_MAX_PARTS partials however long the vector is: block b sums the chunks b, b + gridDim.x, ... in that order, so
+// the result depends on n only (and equals the one-chunk-per-block sum for n <= 256 * ADAMW_MAX_PARTS)
+#define ADAMW_MAX_PARTS 1024
+#define ADAMW_MAX_BLOCKS 4096
+
 __global__ void __launch_bounds__(256) k_grad_stats(const float *grads, long long n, float scale, float *part) {
   __shared__ float s_a[4], s_b[4];
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  float g = i < n ? grads[i] * scale : 0.f;
-  const bool fin = isfinite(g);
-  float ss = opt_wave_sum(fin ? g * g : 0.f), nf = opt_wave_sum(fin ? 0.f : 1.f);
+  float ss_t = 0.f, nf_t = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float g = grads[i] * scale;
+    const bool fin = isfinite(g);
+    ss_t += fin ? g * g : 0.f;
+    nf_t += fin ? 0.f : 1.f;
+  }
+  float ss = opt_wave_sum(ss_t), nf = opt_wave_sum(nf_t);
   if ((threadIdx.x & 63) == 0) {
     s_a[threadIdx.x >> 6] = ss;
     s_b[threadIdx.x >> 6] = nf;
@@ -55,29 +64,29 @@ __global__ void __launch_bounds__(256) k_adamw_step(AdamwArgs A) {
   reduce_parts(A.part, A.n_parts, &ss, &nf);
   if (blockIdx.x == 0 && threadIdx.x == 0 && A.grad_norm_out) A.grad_norm_out[0] = nf > 0.f ? NAN : sqrtf(ss);   // optax.global_norm
   if (A.apply_if_finite && nf > 0.f) return;   // [3P optax.apply_if_finite] skip params, moments and count
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= A.n) return;
   const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
   const float count = A.count[0] + 1.0f;
-  const float g = A.grads[i] * A.scale;
-  const float mu = b1 * A.m[i] + 0.1f * g;                 // optax forms (1 - b) in double: f32(0.1), f32(0.001)
-  const float nu = b2 * A.v[i] + 0.001f * (g * g);
-  A.m[i] = mu;
-  A.v[i] = nu;
-  const float mu_hat = mu / (1.f - powf(b1, count));
-  const float nu_hat = nu / (1.f - powf(b2, count));
-  const float p = A.params[i];
-  const float pn = p + (-A.lr) * (mu_hat / (sqrtf(nu_hat) + eps) + A.wd * p);
-  A.params[i] = pn;
-  if (A.target) A.target[i] = A.one_minus_tau * A.target[i] + A.tau * pn;   // soft_update (optimizer_utils.py:155-161)
+  const float c1 = 1.f - powf(b1, count), c2 = 1.f - powf(b2, count);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < A.n; i += (long long)gridDim.x * 256) {
+    const float g = A.grads[i] * A.scale;
+    const float mu = b1 * A.m[i] + 0.1f * g;                 // optax forms (1 - b) in double: f32(0.1), f32(0.001)
+    const float nu = b2 * A.v[i] + 0.001f * (g * g);
+    A.m[i] = mu;
+    A.v[i] = nu;
+    const float mu_hat = mu / c1;
+    const float nu_hat = nu / c2;
+    const float p = A.params[i];
+    const float pn = p + (-A.lr) * (mu_hat / (sqrtf(nu_hat) + eps) + A.wd * p);
+    A.params[i] = pn;
+    if (A.target) A.target[i] = A.one_minus_tau * A.target[i] + A.tau * pn;   // soft_update (optimizer_utils.py:155-161)
+  }
 }
 
-__global__ void k_adamw_bump(float *count, const float *part, int n_parts, int apply_if_finite) {
-  if (threadIdx.x == 0) {
-    float nf = 0.f;
-    for (int p = 0; p < n_parts; ++p) nf += part[2 * p + 1];
-    if (!(apply_if_finite && nf > 0.f)) count[0] = count[0] + 1.0f;
-  }
+__global__ void __launch_bounds__(64) k_adamw_bump(float *count, const float *part, int n_parts, int apply_if_finite) {
+  float nf = 0.f;   // a count of non-finite entries: small integers, exact in any order
+  for (int p = threadIdx.x; p < n_parts; p += 64) nf += part[2 * p + 1];
+  nf = opt_wave_sum(nf);
+  if (threadIdx.x == 0 && !(apply_if_finite && nf > 0.f)) count[0] = count[0] + 1.0f;
 }
 
 extern "C" int mbpo_adamw_step(float *params, const float *grads, float *adam_m, float *adam_v, float *step_count, int64_t n,
@@ -85,15 +94,17 @@ extern "C" int mbpo_adamw_step(float *params, const float *grads, float *adam_m,
                                float *grad_norm_out, float *workspace, void *stream) {
   MBPO_REQUIRE(params && grads && adam_m && adam_v && step_count && workspace, MBPO_ERR_ARG, "adamw_step: null pointer");
   MBPO_REQUIRE(n > 0 && n < (1LL << 31), MBPO_ERR_ARG, "adamw_step: bad n");
-  const int blocks = (int)((n + 255) / 256);
+  const long long chunks = (n + 255) / 256;
+  const int parts = (int)(chunks < ADAMW_MAX_PARTS ? chunks : ADAMW_MAX_PARTS);
+  const int blocks = (int)(chunks < ADAMW_MAX_BLOCKS ? chunks : ADAMW_MAX_BLOCKS);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_grad_stats, dim3(blocks), dim3(256), 0, st, grads, (long long)n, grad_scale, workspace);
+  hipLaunchKernelGGL(k_grad_stats, dim3(parts), dim3(256), 0, st, grads, (long long)n, grad_scale, workspace);
   AdamwArgs A;
   A.params = params; A.m = adam_m; A.v = adam_v; A.target = target; A.grad_norm_out = grad_norm_out;
-  A.grads = grads; A.count = step_count; A.part = workspace; A.n = n; A.n_parts = blocks; A.apply_if_finite = apply_if_finite;
+  A.grads = grads; A.count = step_count; A.part = workspace; A.n = n; A.n_parts = parts; A.apply_if_finite = apply_if_finite;
   A.lr = lr; A.wd = wd; A.scale = grad_scale; A.tau = tau; A.one_minus_tau = (float)(1.0 - (double)tau);
   hipLaunchKernelGGL(k_adamw_step, dim3(blocks), dim3(256), 0, st, A);
-  hipLaunchKernelGGL(k_adamw_bump, dim3(1), dim3(64), 0, st, step_count, (const float *)workspace, blocks, apply_if_finite);
+  hipLaunchKernelGGL(k_adamw_bump, dim3(1), dim3(64), 0, st, step_count, (const float *)workspace, parts, apply_if_finite);
   MBPO_CHECK_LAUNCH("adamw_step");
   return MBPO_OK;
 }

@@ -127,7 +127,7 @@ extern "C" int mbpo_replay_sample(const float *data, int64_t max_size, int32_t r
 // ------------------------------------------------------------------------------------------------
 // running_statistics.update, split into reduce (per-rank sums) and apply.
 // ------------------------------------------------------------------------------------------------
-#define STATS_WGS 64
+#define STATS_WGS 512
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -167,15 +167,38 @@ __global__ void __launch_bounds__(256) k_stats_partial(const float *rows, long l
   }
 }
 
+// column c's partials are summed by 256/X threads (slice sl takes partials sl, sl + nsl, ...; 8 loads in flight), the slices then
+// in slice order: a fixed order for given (n_parts, X)
 template <int PASS>
-__global__ void k_stats_sums(const float *partial, int n_parts, int X, long long n_rows, float *sums) {
+__global__ void __launch_bounds__(256) k_stats_sums(const float *partial, int n_parts, int X, long long n_rows, float *sums) {
+  __shared__ float s_sl[256];
   const int tid = threadIdx.x;
+  const int nsl = 256 / X, c = tid % X, sl = tid / X;
+  float acc = 0.f;
+  if (sl < nsl) {
+    int g = sl;
+    for (; g + 7 * nsl < n_parts; g += 8 * nsl) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = partial[(long long)(g + k * nsl) * X + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    for (; g < n_parts; g += nsl) acc += partial[(long long)g * X + c];
+  }
+  s_sl[tid] = acc;
+  __syncthreads();
   if (tid < X) {
-    float acc = 0.f;
-    for (int g = 0; g < n_parts; ++g) acc += partial[g * X + tid];
-    sums[1 + PASS * X + tid] = acc;
+    float a = 0.f;
+    for (int k = 0; k < nsl; ++k) a += s_sl[k * X + tid];
+    sums[1 + PASS * X + tid] = a;
   }
   if (PASS == 0 && tid == 0) sums[0] = (float)n_rows;
+}
+
+extern "C" int64_t mbpo_running_stats_workspace_floats(int32_t x_dim) {
+  if (x_dim <= 0 || x_dim > 128) return MBPO_ERR_ARG;
+  return (int64_t)STATS_WGS * x_dim;
 }
 
 extern "C" int mbpo_running_stats_reduce(const float *rows, int64_t n_rows, int32_t row_len, int32_t col_off, int32_t x_dim,
@@ -192,11 +215,11 @@ extern "C" int mbpo_running_stats_reduce(const float *rows, int64_t n_rows, int3
   if (pass == 0) {
     hipLaunchKernelGGL(k_stats_partial<0>, dim3(grid), dim3(256), 0, st, rows, (long long)n_rows, row_len, col_off, x_dim, stats,
                        (const float *)sums, workspace);
-    hipLaunchKernelGGL(k_stats_sums<0>, dim3(1), dim3(128), 0, st, workspace, grid, x_dim, (long long)n_rows, sums);
+    hipLaunchKernelGGL(k_stats_sums<0>, dim3(1), dim3(256), 0, st, workspace, grid, x_dim, (long long)n_rows, sums);
   } else {
     hipLaunchKernelGGL(k_stats_partial<1>, dim3(grid), dim3(256), 0, st, rows, (long long)n_rows, row_len, col_off, x_dim, stats,
                        (const float *)sums, workspace);
-    hipLaunchKernelGGL(k_stats_sums<1>, dim3(1), dim3(128), 0, st, workspace, grid, x_dim, (long long)n_rows, sums);
+    hipLaunchKernelGGL(k_stats_sums<1>, dim3(1), dim3(256), 0, st, workspace, grid, x_dim, (long long)n_rows, sums);
   }
   MBPO_CHECK_LAUNCH("running_stats_reduce");
   return MBPO_OK;

@@ -216,6 +216,8 @@ def _bind_optional(lib: C.CDLL) -> None:
     if fn is not None:
         fn.restype = C.c_int64
         fn.argtypes = [i32, i32, vp, i64]
+    lib.mbpo_running_stats_workspace_floats.restype = C.c_int64
+    lib.mbpo_running_stats_workspace_floats.argtypes = [i32]
     lib.mbpo_ens_nll_workspace_floats.restype = C.c_int64
     lib.mbpo_ens_nll_workspace_floats.argtypes = [C.POINTER(EnsTrainDesc)]
     lib.mbpo_ens_nll_grads.restype = C.c_int

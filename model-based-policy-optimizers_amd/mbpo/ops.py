@@ -177,7 +177,12 @@ def replay_sample(data: torch.Tensor, state: torch.Tensor, n: int, seed: int, of
 
 
 # ------------------------------------------------------------------------------------------------ running statistics (R8)
-STATS_WORKSPACE_FLOATS = 64 * 2 * 128
+def stats_workspace_floats(x_dim: int) -> int:
+    """Floats mbpo_running_stats_reduce needs in `workspace` (one partial per workgroup and column)."""
+    n = load().mbpo_running_stats_workspace_floats(int(x_dim))
+    if n < 0:
+        check(int(n), "mbpo_running_stats_workspace_floats")
+    return int(n)
 
 
 def running_stats_reduce(rows: torch.Tensor, col_off: int, x_dim: int, stats: torch.Tensor, pass_: int,
@@ -188,7 +193,9 @@ def running_stats_reduce(rows: torch.Tensor, col_off: int, x_dim: int, stats: to
     if sums is None:
         sums = torch.zeros(1 + 2 * x_dim, device=rows.device, dtype=torch.float32)
     if workspace is None:
-        workspace = torch.empty(64 * x_dim, device=rows.device, dtype=torch.float32)
+        workspace = torch.empty(stats_workspace_floats(x_dim), device=rows.device, dtype=torch.float32)
+    elif workspace.numel() < stats_workspace_floats(x_dim):
+        raise ValueError(f"workspace must hold {stats_workspace_floats(x_dim)} floats, got {workspace.numel()}")
     check(lib.mbpo_running_stats_reduce(rows.data_ptr(), rows.shape[0], rows.shape[1], col_off, x_dim, stats.data_ptr(),
                                         sums.data_ptr(), workspace.data_ptr(), pass_, current_stream_ptr()),
           "mbpo_running_stats_reduce")

@@ -253,8 +253,8 @@ class BPTTOptimizer(BaseOptimizer):
         self._traj_state = torch.tensor([self.num_transitions, 0, 0, self.num_transitions], device=dev, dtype=torch.int32)
         self._reward_ms = f(2)
         self._step_dev = f(1)
-        self._stats_sums_x, self._stats_ws_x = f(1 + 2 * X), f(64 * X)
-        self._stats_sums_r, self._stats_ws_r = f(3), f(64)
+        self._stats_sums_x, self._stats_ws_x = f(1 + 2 * X), f(ops.stats_workspace_floats(X))
+        self._stats_sums_r, self._stats_ws_r = f(3), f(ops.stats_workspace_floats(1))
 
     # -- reference API --------------------------------------------------------------------------------------------
     def init(self, key: int, true_buffer_state: Optional[ReplayBufferState] = None) -> BPTTState:

@@ -132,7 +132,7 @@ class PPO:
         self._ring_state = torch.zeros(4, dtype=torch.int32, device=self.device)                # head = 0: plain row gather
         self._stats_vec = torch.zeros(1 + 3 * self.x_dim, device=self.device)
         self._stats_sums = torch.zeros(1 + 2 * self.x_dim, device=self.device)
-        self._stats_ws = torch.empty(64 * self.x_dim, device=self.device)
+        self._stats_ws = torch.empty(ops.stats_workspace_floats(self.x_dim), device=self.device)
         self._call_counter = 0
 
     # ------------------------------------------------------------------------------------------------ policy / state

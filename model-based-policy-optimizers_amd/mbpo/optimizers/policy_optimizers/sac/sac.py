@@ -208,7 +208,7 @@ class SAC:
         self._rollout_rows = torch.empty(S * N, self.row_len, device=self.device)
         self._batch_rows = torch.empty(batch_size * grad_updates_per_step, self.row_len, device=self.device)
         self._stats_sums = torch.zeros(1 + 2 * self.x_dim, device=self.device)
-        self._stats_ws = torch.empty(64 * self.x_dim, device=self.device)
+        self._stats_ws = torch.empty(ops.stats_workspace_floats(self.x_dim), device=self.device)
         self._stats_vec = torch.zeros(1 + 3 * self.x_dim, device=self.device)
         self.use_graph = use_graph
         self._graph = None
