@@ -113,7 +113,7 @@ __device__ __forceinline__ void reward_vjp(const BpttArgs &A, const float *xu, f
   for (int d = 0; d < U; ++d) dxu[X + d] += g * (-2.f * rp[d] * xu[X + d]);
 }
 
-template <int H>
+template <int H, bool WIDE>
 __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
@@ -199,8 +199,8 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
       {  // policy(stop_gradient(obs))  (optimizer_utils.py:85-86, bptt_optimizer.py:305-325)
         if (wave < 4) {
           WSet<HT, 4> R4;
-          chain_fwd_prefetch<HT, 4>(R4, A.sh_pi, A.pi.params, wave, lane);
-          chain_fwd_run<HT, 4>(A.sh_pi, A.pi.params, s_on, ld_x, s_B, s_B + T, nullptr, nullptr, s_y, ld_y, ld_h, PL, wave, lane, R4);
+          chain_fwd_prefetch<HT, 4, WIDE>(R4, A.sh_pi, A.pi.params, wave, lane);
+          chain_fwd_run<HT, 4, WIDE>(A.sh_pi, A.pi.params, s_on, ld_x, s_B, s_B + T, nullptr, nullptr, s_y, ld_y, ld_h, PL, wave, lane, R4);
         } else {
           chain_idle_run(PL);
         }
@@ -237,8 +237,8 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
           if (on) {
             const float *ep = A.dyn.params + (long long)e * A.dyn.net_stride;
             WSet<HT, 2> R2;
-            chain_fwd_prefetch<HT, 2>(R2, A.sh_dyn, ep, sub2, lane);
-            chain_fwd_run<HT, 2>(A.sh_dyn, ep, s_xu, ld_xu, s_B + chain2 * 2 * T, s_B + chain2 * 2 * T + T, nullptr, nullptr,
+            chain_fwd_prefetch<HT, 2, WIDE>(R2, A.sh_dyn, ep, sub2, lane);
+            chain_fwd_run<HT, 2, WIDE>(A.sh_dyn, ep, s_xu, ld_xu, s_B + chain2 * 2 * T, s_B + chain2 * 2 * T + T, nullptr, nullptr,
                                  s_ye + chain2 * 16 * ld_ye, ld_ye, ld_h, DL, sub2, lane, R2);
           } else {
             chain_idle_run(DL);
@@ -272,8 +272,8 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
         if (chain2 < 2) {
           const float *cp = chain2 ? cr2 : cr1;
           WSet<HT, 2> R2;
-          chain_fwd_prefetch<HT, 2>(R2, A.sh_cr, cp, sub2, lane);
-          chain_fwd_run<HT, 2>(A.sh_cr, cp, s_nn, ld_x, s_B + 2 * chain2 * T, s_B + 2 * chain2 * T + T, nullptr, nullptr,
+          chain_fwd_prefetch<HT, 2, WIDE>(R2, A.sh_cr, cp, sub2, lane);
+          chain_fwd_run<HT, 2, WIDE>(A.sh_cr, cp, s_nn, ld_x, s_B + 2 * chain2 * T, s_B + 2 * chain2 * T + T, nullptr, nullptr,
                                s_yv + chain2 * 16 * 4, 4, ld_h, CL, sub2, lane, R2);
         } else {
           chain_idle_run(CL);
@@ -364,8 +364,8 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
           const float *rp = pol ? A.pi.params : (chain2 == 1 ? cr1 : cr2);
           float *rpp = pol ? nullptr : ppc + 2 * (chain2 - 1) * T;
           WSet<HT, 2> R2;
-          chain_fwd_prefetch<HT, 2>(R2, shr, rp, sub2, lane);
-          chain_fwd_run<HT, 2>(shr, rp, pol ? s_on : s_nn, ld_x, rpp, pol ? nullptr : rpp + T, pol ? zp : (chain2 == 1 ? zc1 : zc2),
+          chain_fwd_prefetch<HT, 2, WIDE>(R2, shr, rp, sub2, lane);
+          chain_fwd_run<HT, 2, WIDE>(shr, rp, pol ? s_on : s_nn, ld_x, rpp, pol ? nullptr : rpp + T, pol ? zp : (chain2 == 1 ? zc1 : zc2),
                                pol ? hp : nullptr, pol ? s_y : s_yv + (chain2 - 1) * 16 * 4, pol ? ld_y : 4, ld_h, Lm, sub2, lane, R2);
         } else {
           chain_idle_run(Lm);
@@ -388,8 +388,8 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
           const float *cp = net ? cr2 : cr1;
           float *d0 = ppc + (net > 0 ? 2 * T : 0);
           WSet<HT, 2> R2;
-          chain_dgrad_prefetch<HT, 2>(R2, A.sh_cr, cp, sub2, lane);
-          chain_dgrad_run<HT, 2>(A.sh_cr, cp, s_dyv + (net > 0 ? 16 * 4 : 0), 4, net ? zc2 : zc1, d0, d0 + T, s_dxc + (net > 0 ? 16 * ld_x : 0),
+          chain_dgrad_prefetch<HT, 2, WIDE>(R2, A.sh_cr, cp, sub2, lane);
+          chain_dgrad_run<HT, 2, WIDE>(A.sh_cr, cp, s_dyv + (net > 0 ? 16 * 4 : 0), 4, net ? zc2 : zc1, d0, d0 + T, s_dxc + (net > 0 ? 16 * ld_x : 0),
                                  ld_x, ld_h, CL, sub2, lane, R2);
         } else {
           chain_idle_run(CL);
@@ -416,8 +416,8 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
           float *ze = s_B + chain2 * (LH + 2) * T, *ppe = ze + LH * T;
           if (on) {
             WSet<HT, 2> R2;
-            chain_fwd_prefetch<HT, 2>(R2, A.sh_dyn, ep, sub2, lane);
-            chain_fwd_run<HT, 2>(A.sh_dyn, ep, s_xu, ld_xu, ppe, ppe + T, ze, nullptr, s_ye + chain2 * 16 * ld_ye, ld_ye, ld_h, DL, sub2, lane, R2);
+            chain_fwd_prefetch<HT, 2, WIDE>(R2, A.sh_dyn, ep, sub2, lane);
+            chain_fwd_run<HT, 2, WIDE>(A.sh_dyn, ep, s_xu, ld_xu, ppe, ppe + T, ze, nullptr, s_ye + chain2 * 16 * ld_ye, ld_ye, ld_h, DL, sub2, lane, R2);
           } else {
             chain_idle_run(DL);
           }
@@ -430,8 +430,8 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
           {
             if (on) {
               WSet<HT, 2> R2;
-              chain_dgrad_prefetch<HT, 2>(R2, A.sh_dyn, ep, sub2, lane);
-              chain_dgrad_run<HT, 2>(A.sh_dyn, ep, s_dye + chain2 * 16 * ld_ye, ld_ye, ze, ppe, ppe + T, s_dxe + chain2 * 16 * ld_xu, ld_xu, ld_h,
+              chain_dgrad_prefetch<HT, 2, WIDE>(R2, A.sh_dyn, ep, sub2, lane);
+              chain_dgrad_run<HT, 2, WIDE>(A.sh_dyn, ep, s_dye + chain2 * 16 * ld_ye, ld_ye, ze, ppe, ppe + T, s_dxe + chain2 * 16 * ld_xu, ld_xu, ld_h,
                                      DL, sub2, lane, R2);
             } else {
               chain_idle_run(DL);
@@ -490,11 +490,11 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
         const bool accum = !(first_tile && t == HZ - 1);
         if (chain2 < 2) {
           WSet<HT, 2> R2;
-          chain_dgrad_prefetch<HT, 2>(R2, A.sh_pi, A.pi.params, sub2, lane);
-          chain_dgrad_run<HT, 2>(A.sh_pi, A.pi.params, chain2 ? s_dyl : s_dyt, ld_y, zp, chain2 ? dl0 : dt0, chain2 ? dl1 : dt1,
+          chain_dgrad_prefetch<HT, 2, WIDE>(R2, A.sh_pi, A.pi.params, sub2, lane);
+          chain_dgrad_run<HT, 2, WIDE>(A.sh_pi, A.pi.params, chain2 ? s_dyl : s_dyt, ld_y, zp, chain2 ? dl0 : dt0, chain2 ? dl1 : dt1,
                                  chain2 ? s_don : nullptr, ld_x, ld_h, PL, sub2, lane, R2);
         } else if (chain2 == 2) {
-          chain_wgrad_run<HT, 2>(A.sh_pi, s_on, ld_x, hp, s_dyt, ld_y, dt0, dt1, slab, accum, ld_h, PL, sub2, lane);
+          chain_wgrad_run<HT, 2, WIDE>(A.sh_pi, s_on, ld_x, hp, s_dyt, ld_y, dt0, dt1, slab, accum, ld_h, PL, sub2, lane);
         } else {
           chain_idle_run(PL);
         }
@@ -701,10 +701,12 @@ extern "C" int mbpo_bptt_actor_grads(const mbpo_bptt_desc *d, void *stream) {
   A.sh_cr = NetShape{A.cr.dims[0], A.cr.n_layers, A.cr.dims[A.cr.n_layers], A.cr.act};
   if (A.system_kind == MBPO_SYS_ENSEMBLE) A.sh_dyn = NetShape{A.dyn.dims[0], A.dyn.n_layers, A.dyn.dims[A.dyn.n_layers], A.dyn.act};
   else A.sh_dyn = NetShape{A.X + A.U, 0, A.X, 0};
-  rc = mbpo_ensure_lds<k_bptt_actor<64>>(pl.lds, "bptt_actor_grads");
+  const bool wide = net_is_wide(A.sh_pi) || net_is_wide(A.sh_cr) || net_is_wide(A.sh_dyn);
+  rc = wide ? mbpo_ensure_lds<k_bptt_actor<64, true>>(pl.lds, "bptt_actor_grads") : mbpo_ensure_lds<k_bptt_actor<64, false>>(pl.lds, "bptt_actor_grads");
   if (rc != MBPO_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_bptt_actor<64>, dim3(pl.n_slabs), dim3(512), pl.lds, st, A);
+  if (wide) hipLaunchKernelGGL((k_bptt_actor<64, true>), dim3(pl.n_slabs), dim3(512), pl.lds, st, A);
+  else hipLaunchKernelGGL((k_bptt_actor<64, false>), dim3(pl.n_slabs), dim3(512), pl.lds, st, A);
   BpttReduceArgs R;
   R.slabs = A.slabs; R.extras = A.extras; R.n_slabs = pl.n_slabs; R.P = pl.P; R.H = d->horizon; R.n = d->n; R.ent_coef = d->ent_coef;
   R.grads = d->grads; R.metrics = d->metrics;
@@ -729,7 +731,7 @@ struct CriticArgs {
 
 // 4 chains x SP waves on phase runners (chain_run.hpp): forward = critic_1 | critic_2 (z and h kept); backward = a dgrad and a
 // wgrad chain per net side by side; a workgroup walks tiles and accumulates into its slab.
-template <int H, int SP>
+template <int H, int SP, bool WIDE>
 __global__ void __launch_bounds__(256 * SP) k_critic_fwd_bwd(CriticArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
@@ -759,7 +761,7 @@ __global__ void __launch_bounds__(256 * SP) k_critic_fwd_bwd(CriticArgs A) {
     const int tid = opaque(tid_), lane = tid & 63;
     const long long j0 = tile * 16;
     WSet<HT, SP> R;
-    if (chain < 2) chain_fwd_prefetch<HT, SP>(R, A.sh, params, sub, lane);
+    if (chain < 2) chain_fwd_prefetch<HT, SP, WIDE>(R, A.sh, params, sub, lane);
     for (int idx = tid; idx < 16 * X; idx += nthreads) {
       const int r = idx & 15, c = idx >> 4;
       const long long j = j0 + r;
@@ -769,9 +771,9 @@ __global__ void __launch_bounds__(256 * SP) k_critic_fwd_bwd(CriticArgs A) {
     }
     if (tid < 16) s_tg[tid] = (j0 + tid < A.batch) ? A.lambda_values[A.idx[j0 + tid]] : 0.f;
     __syncthreads();
-    if (chain < 2) chain_fwd_run<HT, SP>(A.sh, params, s_x, ld_x, nullptr, nullptr, zb, hb, s_yv + net * 64, 4, ld_h, CL, sub, lane, R);
+    if (chain < 2) chain_fwd_run<HT, SP, WIDE>(A.sh, params, s_x, ld_x, nullptr, nullptr, zb, hb, s_yv + net * 64, 4, ld_h, CL, sub, lane, R);
     else chain_idle_run(CL);
-    if (chain < 2) chain_dgrad_prefetch<HT, SP>(R, A.sh, params, sub, lane);
+    if (chain < 2) chain_dgrad_prefetch<HT, SP, WIDE>(R, A.sh, params, sub, lane);
     if (tid < 32) {
       const int k = tid >> 4, r = tid & 15;
       const bool ok = j0 + r < A.batch;
@@ -784,8 +786,8 @@ __global__ void __launch_bounds__(256 * SP) k_critic_fwd_bwd(CriticArgs A) {
       for (int i = 0; i < 32; ++i) loss += s_ls[i];
     {
       float *d0 = s_pp + (2 * net) * T, *d1 = d0 + T;
-      if (chain < 2) chain_dgrad_run<HT, SP>(A.sh, params, s_dyv + net * 64, 4, zb, d0, d1, nullptr, ld_x, ld_h, CL, sub, lane, R);
-      else chain_wgrad_run<HT, SP>(A.sh, s_x, ld_x, hb, s_dyv + net * 64, 4, d0, d1, slab, !first, ld_h, CL, sub, lane);
+      if (chain < 2) chain_dgrad_run<HT, SP, WIDE>(A.sh, params, s_dyv + net * 64, 4, zb, d0, d1, nullptr, ld_x, ld_h, CL, sub, lane, R);
+      else chain_wgrad_run<HT, SP, WIDE>(A.sh, s_x, ld_x, hb, s_dyv + net * 64, 4, d0, d1, slab, !first, ld_h, CL, sub, lane);
     }
   }
   if (tid_ == 0) A.extras[blockIdx.x] = loss;
@@ -849,10 +851,12 @@ extern "C" int mbpo_critic_grads(const float *critic_params, int32_t x_dim, int3
   A.X = x_dim; A.D = row_len; A.transitions = transitions; A.lambda_values = lambda_values; A.s_mean = state_mean; A.s_std = state_std;
   A.idx = idx; A.batch = batch; A.slabs = workspace; A.extras = workspace + (long long)ns * 2 * A.cr.n_params;
   A.sh = NetShape{x_dim, critic_layers, 1, activation};
-  rc = mbpo_ensure_lds<k_critic_fwd_bwd<64, 4>>(lds, "critic_grads");
+  const bool wide = net_is_wide(A.sh);
+  rc = wide ? mbpo_ensure_lds<k_critic_fwd_bwd<64, 4, true>>(lds, "critic_grads") : mbpo_ensure_lds<k_critic_fwd_bwd<64, 4, false>>(lds, "critic_grads");
   if (rc != MBPO_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((k_critic_fwd_bwd<64, 4>), dim3(ns), dim3(1024), lds, st, A);
+  if (wide) hipLaunchKernelGGL((k_critic_fwd_bwd<64, 4, true>), dim3(ns), dim3(1024), lds, st, A);
+  else hipLaunchKernelGGL((k_critic_fwd_bwd<64, 4, false>), dim3(ns), dim3(1024), lds, st, A);
   const int C2 = 2 * A.cr.n_params;
   hipLaunchKernelGGL(k_critic_reduce, dim3((C2 + 255) / 256), dim3(256), 0, st, (const float *)A.slabs, (const float *)A.extras, ns, C2,
                      (long long)batch, grads, metrics);

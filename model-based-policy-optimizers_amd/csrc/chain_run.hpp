@@ -117,6 +117,27 @@ __device__ __forceinline__ void wset_load_fwd_out(WSet<HT, SP> &S, const float *
   for (int t = 0; t < NTL; ++t) gload1(S.b[t], W, (unsigned)(H * N * 4) + vcol[t]);
 }
 
+// forward, output layer wider than one n-tile (16 < N <= H): every wave of the group takes its hidden-layer column slice,
+// w[s*CT + t] = W[g*KS + s][c0 + CT*r + t] (row stride N; columns >= N read column 0 and are never stored)
+template <int HT, int SP>
+__device__ __forceinline__ void wset_load_fwd_outw(WSet<HT, SP> &S, const float *W, int N, int sub, int lane) {
+  constexpr int H = 16 * HT, KS = 4 * HT, CT = HT / SP;
+  const int r = lane & 15, g = lane >> 4;
+  unsigned vcol[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int n = sub * 16 * CT + CT * r + t;
+    vcol[t] = (unsigned)((n < N ? n : 0) * 4);
+  }
+  const unsigned vrow = (unsigned)(g * KS * N * 4);
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int t = 0; t < CT; ++t) gload1(S.w[s * CT + t], W, vrow + (unsigned)(s * N * 4) + vcol[t]);
+#pragma unroll
+  for (int t = 0; t < CT; ++t) gload1(S.b[t], W, (unsigned)(H * N * 4) + vcol[t]);
+}
+
 // dgrad of a hidden layer (W [H][H]): w[t*NS + n] = W[k0 + CT*r + t][g*NS + n]
 template <int HT, int SP>
 __device__ __forceinline__ void wset_load_dg_full(WSet<HT, SP> &S, const float *W, int sub, int lane) {
@@ -127,15 +148,16 @@ __device__ __forceinline__ void wset_load_dg_full(WSet<HT, SP> &S, const float *
   for (int t = 0; t < CT; ++t) gloadv<NS>(&S.w[t * NS], W, v0 + (unsigned)(t * H * 4));
 }
 
-// dgrad of the output layer (W [H][N], N <= 32): w[s*CT + t] = W[k0 + CT*r + t][clamp(g*nc + s)], s < 8
-template <int HT, int SP>
+// dgrad of the output layer (W [H][N], N <= 4*NSTEP): w[s*CT + t] = W[k0 + CT*r + t][clamp(g*nc + s)], s < NSTEP
+template <int HT, int SP, int NSTEP = 8>
 __device__ __forceinline__ void wset_load_dg_out(WSet<HT, SP> &S, const float *W, int N, int sub, int lane) {
   constexpr int CT = HT / SP;
+  static_assert(NSTEP * CT <= WSet<HT, SP>::NW, "output-layer dgrad image does not fit the register set");
   const int r = lane & 15, g = lane >> 4;
   const int nc = (N + 3) >> 2;
   const unsigned vrow = (unsigned)((sub * 16 * CT + CT * r) * N * 4);
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
+  for (int s = 0; s < NSTEP; ++s) {
     const int n = g * nc + s;
     const int nn = ((s < nc) && (n < N)) ? n : 0;
 #pragma unroll
@@ -143,12 +165,14 @@ __device__ __forceinline__ void wset_load_dg_out(WSet<HT, SP> &S, const float *W
   }
 }
 
-// dgrad of layer 0 towards the network input (W [K][H], K <= 16), wave 0: w[n] = W[clamp(r)][g*NS + n]
+// dgrad of layer 0 towards the network input (W [K][H], K <= 32): wave `sub` takes input rows 16*sub .. 16*sub+15,
+// w[n] = W[clamp(16*sub + r)][g*NS + n]
 template <int HT, int SP>
-__device__ __forceinline__ void wset_load_dg_in(WSet<HT, SP> &S, const float *W, int K, int lane) {
+__device__ __forceinline__ void wset_load_dg_in(WSet<HT, SP> &S, const float *W, int K, int sub, int lane) {
   constexpr int H = 16 * HT, NS = 4 * HT;
   const int r = lane & 15, g = lane >> 4;
-  gloadv<NS>(S.w, W, (unsigned)((((r < K) ? r : 0) * H + g * NS) * 4));
+  const int k = 16 * sub + r;
+  gloadv<NS>(S.w, W, (unsigned)((((k < K) ? k : 0) * H + g * NS) * 4));
 }
 
 // ---- computes on a register image ----------------------------------------------------------------------------
@@ -231,8 +255,35 @@ __device__ __forceinline__ void wset_fwd_out(const WSet<HT, SP> &S, const float 
   }
 }
 
-// delta_{l-1}[:, k0 .. k0+16*CT) from a hidden (FULL) or output-layer (OUT: N <= 32) dgrad image
-template <int HT, int SP, bool OUT>
+template <int HT, int SP>
+__device__ __forceinline__ void wset_fwd_outw(const WSet<HT, SP> &S, const float *x, int ldx, int N, float *y, int ldy, int sub, int lane) {
+  constexpr int KS = 4 * HT, CT = HT / SP;
+  const int r = lane & 15, g = lane >> 4;
+  f32x4 acc[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float *xr = x + r * ldx + g * KS;
+#pragma unroll
+  for (int q = 0; q < KS / 4; ++q) {
+    float av[4];
+    load_vec_lds<4>(xr + 4 * q, av);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], S.w[(4 * q + u) * CT + t], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    const int n = sub * 16 * CT + CT * r + t;
+    if (n < N) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[(4 * g + i) * ldy + n] = acc[t][i] + S.b[t];
+    }
+  }
+}
+
+// delta_{l-1}[:, k0 .. k0+16*CT) from a hidden (FULL) or output-layer (OUT: N <= 4*NSTEP) dgrad image
+template <int HT, int SP, bool OUT, int NSTEP = 8>
 __device__ __forceinline__ void wset_dgrad(const WSet<HT, SP> &S, const float *delta, int ldd, int N, const float *zp, float *dx, int ldh,
                                            int act, int lane) {
   constexpr int NS = 4 * HT, CT = HT / SP;
@@ -253,16 +304,16 @@ __device__ __forceinline__ void wset_dgrad(const WSet<HT, SP> &S, const float *d
     }
   } else {
     const int nc = (N + 3) >> 2;
-    float av[8];
+    float av[NSTEP];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < NSTEP; ++s) {
       const int n = g * nc + s;
       const bool ok = (s < nc) && (n < N);
       av[s] = delta[r * ldd + (ok ? n : 0)];
       av[s] = ok ? av[s] : 0.f;
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
       for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], S.w[s * CT + t], acc[t], 0, 0, 0);
   }
@@ -280,7 +331,8 @@ __device__ __forceinline__ void wset_dgrad(const WSet<HT, SP> &S, const float *d
 }
 
 template <int HT, int SP>
-__device__ __forceinline__ void wset_dgrad_in(const WSet<HT, SP> &S, const float *delta, int ldd, int K, float *dX, int ld_dx, int lane) {
+__device__ __forceinline__ void wset_dgrad_in(const WSet<HT, SP> &S, const float *delta, int ldd, int K, float *dX, int ld_dx, int sub,
+                                              int lane) {
   constexpr int NS = 4 * HT;
   const int r = lane & 15, g = lane >> 4;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -292,37 +344,57 @@ __device__ __forceinline__ void wset_dgrad_in(const WSet<HT, SP> &S, const float
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], S.w[4 * q + u], acc, 0, 0, 0);
   }
-  if (r < K) {
+  const int k = 16 * sub + r;
+  if (k < K) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dX[(4 * g + i) * ld_dx + r] = acc[i];
+    for (int i = 0; i < 4; ++i) dX[(4 * g + i) * ld_dx + k] = acc[i];
   }
 }
 
 // ------------------------------------------------------------------------------------------------ fast-path predicates
-template <int HT, int SP>
+// WIDE (compile-time) selects which shapes take the register-image path:
+//   !WIDE: networks whose input and output fit one 16-column tile where it matters (K_in <= 32 forward, <= 16 for an input
+//          gradient; N_out <= 16 on wave 0, or <= 32 when a wave owns 2 column tiles).  The lean code every x<=16 kernel runs.
+//    WIDE: additionally the output layer on all waves' hidden-layer column slices (N_out <= H), its dgrad through a 16-step
+//          image (N_out <= 64), the input gradient in two row tiles (K_in <= 32), wider weight-gradient tiles.  More code and
+//          registers in every kernel that instantiates it, so the host picks the WIDE kernel only for such shapes.
+template <int HT, int SP, bool WIDE = false>
 __device__ __forceinline__ bool fast_shape(const NetShape &sh) {
-  // input layer through the 8-step image, output layer through one n-tile image, hidden layers always
-  return (4 * HT * (HT / SP) <= 64) && sh.K_in <= 32 && sh.N_out <= 16 * (HT / SP) && sh.N_out <= 32 && sh.L >= 2;
+  if constexpr (WIDE) return (4 * HT * (HT / SP) <= 64) && sh.K_in <= 32 && sh.N_out <= 16 * HT && sh.N_out <= 64 && sh.L >= 2;
+  else return (4 * HT * (HT / SP) <= 64) && sh.K_in <= 32 && sh.N_out <= 16 * (HT / SP) && sh.N_out <= 32 && sh.L >= 2;
 }
 
+// host side: does a network need the WIDE kernel variants (anything beyond one 16-column tile at its input or output)?
+static inline bool net_is_wide(const NetShape &sh) { return sh.L > 0 && (sh.K_in > 16 || sh.N_out > 16); }
+
 // First-layer request of a forward / dgrad phase (issued by the kernel before the preceding elementwise section).
-template <int HT, int SP>
+template <int HT, int SP, bool WIDE = false>
 __device__ __forceinline__ void chain_fwd_prefetch(WSet<HT, SP> &A, const NetShape sh, const float *params, int sub, int lane) {
-  if (fast_shape<HT, SP>(sh)) wset_load_fwd_in<HT, SP>(A, params, sh.K_in, sub, lane);
+  if (fast_shape<HT, SP, WIDE>(sh)) wset_load_fwd_in<HT, SP>(A, params, sh.K_in, sub, lane);
 }
-template <int HT, int SP>
+template <int HT, int SP, bool WIDE = false>
 __device__ __forceinline__ void chain_dgrad_prefetch(WSet<HT, SP> &A, const NetShape sh, const float *params, int sub, int lane) {
   constexpr int H = 16 * HT;
-  if (fast_shape<HT, SP>(sh)) wset_load_dg_out<HT, SP>(A, params + (sh.K_in * H + H) + (sh.L - 2) * (H * H + H), sh.N_out, sub, lane);
+  if (fast_shape<HT, SP, WIDE>(sh)) {
+    const float *Wl = params + (sh.K_in * H + H) + (sh.L - 2) * (H * H + H);
+    if (!WIDE || sh.N_out <= 32) wset_load_dg_out<HT, SP, 8>(A, Wl, sh.N_out, sub, lane);
+    else if constexpr (WIDE) wset_load_dg_out<HT, SP, 16>(A, Wl, sh.N_out, sub, lane);
+  }
 }
 
 // request for layer ln (>= 1) of a forward chain: a hidden image, or the output image for the wave that computes it
-template <int HT, int SP>
+template <int HT, int SP, bool WIDE = false>
 __device__ __forceinline__ void fwd_request(WSet<HT, SP> &S, const float *W1, int ln, int L, int N_out, int sub, int lane) {
   constexpr int H = 16 * HT;
   const float *Wn = W1 + (ln - 1) * (H * H + H);
   if (ln < L - 1) wset_load_fwd_full<HT, SP>(S, Wn, sub, lane);
-  else if (ln == L - 1 && sub == 0) wset_load_fwd_out<HT, SP, 1>(S, Wn, N_out, lane);   // N_out <= 16 per n-tile image
+  else if (ln == L - 1) {
+    if (!WIDE || N_out <= 16) {
+      if (sub == 0) wset_load_fwd_out<HT, SP, 1>(S, Wn, N_out, lane);   // one n-tile image on wave 0
+    } else if (sub * 16 * (HT / SP) < N_out) {
+      if constexpr (WIDE) wset_load_fwd_outw<HT, SP>(S, Wn, N_out, sub, lane);
+    }
+  }
 }
 
 // request for layer ln's dgrad image (ln <= L-2): hidden layers, or the input layer when the input gradient is wanted
@@ -331,14 +403,14 @@ __device__ __forceinline__ void dgrad_request(WSet<HT, SP> &S, const float *para
                                               int sub, int lane) {
   constexpr int H = 16 * HT;
   if (ln >= 1) wset_load_dg_full<HT, SP>(S, W1 + (ln - 1) * (H * H + H), sub, lane);
-  else if (ln == 0 && want_dx && sub == 0) wset_load_dg_in<HT, SP>(S, params, K_in, lane);
+  else if (ln == 0 && want_dx && 16 * sub < K_in) wset_load_dg_in<HT, SP>(S, params, K_in, sub, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ forward runner
 // x: network input tile [16][ldx].  Hidden outputs go to hbuf + l*T (when hbuf) or ping-pong pp0/pp1; pre-activations to
 // zbuf + l*T (when zbuf); the output layer to y [16][ldy].  A must hold layer 0's request (chain_fwd_prefetch).
 // Executes exactly n_steps workgroup barriers.
-template <int HT, int SP>
+template <int HT, int SP, bool WIDE = false>
 __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__restrict__ params, const float *x, int ldx, float *pp0,
                                               float *pp1, float *zbuf, float *hbuf, float *y, int ldy, int ldh, int n_steps, int sub,
                                               int lane_, WSet<HT, SP> &A, unsigned long long *dbg = nullptr) {
@@ -356,11 +428,11 @@ __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__
 #define hout(l) ((hbuf ? hbuf + (l) * T : (((l) & 1) ? pp1 : pp0)) + c0)
 #define zout(l) (zbuf ? zbuf + (l) * T + c0 : nullptr)
 #define hin(l) ((const float *)(hbuf ? hbuf + ((l) - 1) * T : ((((l) - 1) & 1) ? pp1 : pp0)))   /* l >= 1 */
-  if (fast_shape<HT, SP>(sh)) {
+  if (fast_shape<HT, SP, WIDE>(sh)) {
     if constexpr (4 * HT * (HT / SP) <= 64) {
       WSet<HT, SP> B;
       const float *W1 = params + sh.K_in * H + H;   // layer 1
-#define request(S, ln, lane) fwd_request<HT, SP>(S, W1, ln, L, sh.N_out, sub, lane)
+#define request(S, ln, lane) fwd_request<HT, SP, WIDE>(S, W1, ln, L, sh.N_out, sub, lane)
       // ---- layer 0 (input image in A) ----
       {
         const int lane = opaque(lane_);
@@ -401,14 +473,22 @@ __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__
         in_a = true;
       }
       // ---- output layer L-1 (image in B, or in A after an odd number of hidden layers; no register copies) ----
-      if (sub == 0) {
-        const int lane = opaque(lane_);
-        if (sh.N_out <= 16) {
-          if (in_a) wset_fwd_out<HT, SP, 1>(A, hin(L - 1), ldh, sh.N_out, y, ldy, lane);
-          else wset_fwd_out<HT, SP, 1>(B, hin(L - 1), ldh, sh.N_out, y, ldy, lane);
-        } else {
-          if constexpr (CT >= 2) gen_dense_fwd(hin(L - 1), ldh, H, W1 + (L - 2) * (H * H + H), sh.N_out,
-                                               W1 + (L - 2) * (H * H + H) + H * sh.N_out, 0, sh.N_out, y, nullptr, ldy, -1, lane);
+      if (!WIDE || sh.N_out <= 16) {
+        if (sub == 0) {
+          const int lane = opaque(lane_);
+          if (sh.N_out <= 16) {
+            if (in_a) wset_fwd_out<HT, SP, 1>(A, hin(L - 1), ldh, sh.N_out, y, ldy, lane);
+            else wset_fwd_out<HT, SP, 1>(B, hin(L - 1), ldh, sh.N_out, y, ldy, lane);
+          } else {
+            if constexpr (!WIDE && CT >= 2) gen_dense_fwd(hin(L - 1), ldh, H, W1 + (L - 2) * (H * H + H), sh.N_out,
+                                                          W1 + (L - 2) * (H * H + H) + H * sh.N_out, 0, sh.N_out, y, nullptr, ldy, -1, lane);
+          }
+        }
+      } else if (c0 < sh.N_out) {
+        if constexpr (WIDE) {
+          const int lane = opaque(lane_);
+          if (in_a) wset_fwd_outw<HT, SP>(A, hin(L - 1), ldh, sh.N_out, y, ldy, sub, lane);
+          else wset_fwd_outw<HT, SP>(B, hin(L - 1), ldh, sh.N_out, y, ldy, sub, lane);
         }
       }
       __syncthreads();
@@ -452,7 +532,7 @@ __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__
 // dY [16][ldy] is the delta of the output layer; deltas of hidden layers ping-pong through d0/d1 (layer l's dgrad writes
 // delta_{l-1} to (l&1 ? d1 : d0)); zbuf from the forward (layer l at + l*T); dX (optional) receives the input gradient.
 // A must hold layer L-1's request (chain_dgrad_prefetch).  Executes exactly n_steps workgroup barriers.
-template <int HT, int SP>
+template <int HT, int SP, bool WIDE = false>
 __device__ __forceinline__ void chain_dgrad_run(const NetShape sh, const float *__restrict__ params, const float *dY, int ldy,
                                                 const float *zbuf, float *d0, float *d1, float *dX, int ld_dx, int ldh, int n_steps,
                                                 int sub, int lane_, WSet<HT, SP> &A) {
@@ -463,7 +543,7 @@ __device__ __forceinline__ void chain_dgrad_run(const NetShape sh, const float *
 #define dout(l) ((((l) & 1) ? d1 : d0) + k0)                 /* delta_{l-1}, this wave's slice */
 #define zprev(l) (zbuf + ((l) - 1) * T + k0)
   const float *W1 = params + sh.K_in * H + H;   // layer 1
-  const bool fast = fast_shape<HT, SP>(sh) && (dX == nullptr || sh.K_in <= 16);
+  const bool fast = fast_shape<HT, SP, WIDE>(sh) && (WIDE || dX == nullptr || sh.K_in <= 16);
   if (fast) {
     if constexpr (4 * HT * (HT / SP) <= 64) {
       WSet<HT, SP> B;
@@ -473,7 +553,8 @@ __device__ __forceinline__ void chain_dgrad_run(const NetShape sh, const float *
         const int lane = opaque(lane_);
         wset_wait(A);
         request(B, L - 2, lane);
-        wset_dgrad<HT, SP, true>(A, dY, ldy, sh.N_out, zprev(L - 1), dout(L - 1), ldh, sh.act, lane);
+        if (!WIDE || sh.N_out <= 32) wset_dgrad<HT, SP, true, 8>(A, dY, ldy, sh.N_out, zprev(L - 1), dout(L - 1), ldh, sh.act, lane);
+        else if constexpr (WIDE) wset_dgrad<HT, SP, true, 16>(A, dY, ldy, sh.N_out, zprev(L - 1), dout(L - 1), ldh, sh.act, lane);
         __syncthreads();
       }
       // ---- hidden layers L-2 .. 1, two per trip: B then A ----
@@ -501,10 +582,10 @@ __device__ __forceinline__ void chain_dgrad_run(const NetShape sh, const float *
         in_a = true;
       }
       // ---- layer 0: input gradient (image in B, or in A after an odd number of hidden layers) ----
-      if (dX && sub == 0) {
+      if (dX && 16 * sub < sh.K_in) {
         const int lane = opaque(lane_);
-        if (in_a) wset_dgrad_in<HT, SP>(A, din(0), ldh, sh.K_in, dX, ld_dx, lane);
-        else wset_dgrad_in<HT, SP>(B, din(0), ldh, sh.K_in, dX, ld_dx, lane);
+        if (in_a) wset_dgrad_in<HT, SP>(A, din(0), ldh, sh.K_in, dX, ld_dx, sub, lane);
+        else wset_dgrad_in<HT, SP>(B, din(0), ldh, sh.K_in, dX, ld_dx, sub, lane);
       }
       __syncthreads();
     }
@@ -634,7 +715,7 @@ __device__ __forceinline__ void wgrad_tile_fast(const float *a_src, int lda, int
 // ------------------------------------------------------------------------------------------------ wgrad runner
 // Walks L-1..0 beside a dgrad runner that shares dY/d0/d1: dW_l, db_l from (h_{l-1} | x, delta_l) into `slab` (flat layout
 // of one net).  Executes n_steps barriers.
-template <int HT, int SP>
+template <int HT, int SP, bool WIDE = false>
 __device__ __forceinline__ void chain_wgrad_run(const NetShape sh, const float *x, int ldx, const float *hbuf, const float *dY, int ldy,
                                                 const float *d0, const float *d1, float *__restrict__ slab, bool accumulate, int ldh,
                                                 int n_steps, int sub, int lane_, unsigned long long *dbg = nullptr) {
@@ -664,6 +745,12 @@ __device__ __forceinline__ void chain_wgrad_run(const NetShape sh, const float *
       if (N <= 16) {
         if (sub == 0) wgrad_tile_fast<CT, 1, true>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, gb, lane, accumulate);
         else wgrad_tile_fast<CT, 1, false>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, gb, lane, accumulate);
+      } else if (WIDE && N <= 32) {
+        if (sub == 0) wgrad_tile_fast<CT, 2, true>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, gb, lane, accumulate);
+        else wgrad_tile_fast<CT, 2, false>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, gb, lane, accumulate);
+      } else if (WIDE && N <= 64) {
+        if (sub == 0) wgrad_tile_fast<CT, 4, true>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, gb, lane, accumulate);
+        else wgrad_tile_fast<CT, 4, false>(hp + k0, ldp, 16 * CT, delta, ldd, N, gW + k0 * N, N, gb, lane, accumulate);
       } else {
         gen_dense_wgrad(hp, ldp, k0, k0 + 16 * CT, delta, ldd, 0, N, gW, N, lane, accumulate);
         if (sub == 0) wave_dense_bgrad(delta, ldd, N, gb, lane, accumulate);
@@ -674,6 +761,8 @@ __device__ __forceinline__ void chain_wgrad_run(const NetShape sh, const float *
         wgrad_tile_fast<HT, CT, true>(hp, ldp, H, delta + c0, ldd, 16 * CT, gW + c0, N, gb + c0, lane, accumulate);
       } else if (K <= 16) {
         wgrad_tile_fast<1, CT, true>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, gb + c0, lane, accumulate);
+      } else if (WIDE && K <= 32) {
+        wgrad_tile_fast<2, CT, true>(hp, ldp, K, delta + c0, ldd, 16 * CT, gW + c0, N, gb + c0, lane, accumulate);
       } else {
         gen_dense_wgrad(hp, ldp, 0, K, delta, ldd, c0, c0 + 16 * CT, gW, N, lane, accumulate);
         wave_dense_bgrad(delta + c0, ldd, 16 * CT, gb + c0, lane, accumulate);

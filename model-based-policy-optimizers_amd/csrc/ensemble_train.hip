@@ -24,7 +24,7 @@ struct EnsTrainArgs {
   int n_slots, ld_xu, ld_h, ld_y, LH;
 };
 
-template <int SP>
+template <int SP, bool WIDE>
 __global__ void __launch_bounds__(128 * SP) k_ens_nll_fwd_bwd(EnsTrainArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = 4;
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(128 * SP) k_ens_nll_fwd_bwd(EnsTrainArgs A) {
     const int tid = opaque(tid_), lane = tid & 63;
     const long long j0 = tile * 16;
     WSet<HT, SP> R;
-    if (chain == 0) chain_fwd_prefetch<HT, SP>(R, A.sh, params, sub, lane);
+    if (chain == 0) chain_fwd_prefetch<HT, SP, WIDE>(R, A.sh, params, sub, lane);
     for (int i2 = tid; i2 < 16 * (X + U); i2 += nthreads) {
       const int r = i2 & 15, c = i2 >> 4;
       const long long j = j0 + r;
@@ -71,9 +71,9 @@ __global__ void __launch_bounds__(128 * SP) k_ens_nll_fwd_bwd(EnsTrainArgs A) {
       s_t[r * ld_y + c] = t;
     }
     __syncthreads();
-    if (chain == 0) chain_fwd_run<HT, SP>(A.sh, params, s_xu, ld_xu, nullptr, nullptr, s_st, s_st + LH * T, s_y, ld_y, ld_h, L, sub, lane, R);
+    if (chain == 0) chain_fwd_run<HT, SP, WIDE>(A.sh, params, s_xu, ld_xu, nullptr, nullptr, s_st, s_st + LH * T, s_y, ld_y, ld_h, L, sub, lane, R);
     else chain_idle_run(L);
-    if (chain == 0) chain_dgrad_prefetch<HT, SP>(R, A.sh, params, sub, lane);
+    if (chain == 0) chain_dgrad_prefetch<HT, SP, WIDE>(R, A.sh, params, sub, lane);
     // d loss / d(mu, raw) per element, loss partial per row
     for (int i2 = tid; i2 < 16 * X; i2 += nthreads) {
       const int r = i2 & 15, c = i2 >> 4;
@@ -91,8 +91,8 @@ __global__ void __launch_bounds__(128 * SP) k_ens_nll_fwd_bwd(EnsTrainArgs A) {
       for (int c = 0; c < X; ++c) a += s_t[tid * ld_y + X + c];
       s_ls[tid] = a;
     }
-    if (chain == 0) chain_dgrad_run<HT, SP>(A.sh, params, s_dy, ld_y, s_st, s_pp, s_pp + T, nullptr, ld_xu, ld_h, L, sub, lane, R);
-    else chain_wgrad_run<HT, SP>(A.sh, s_xu, ld_xu, s_st + LH * T, s_dy, ld_y, s_pp, s_pp + T, slab, !first, ld_h, L, sub, lane);
+    if (chain == 0) chain_dgrad_run<HT, SP, WIDE>(A.sh, params, s_dy, ld_y, s_st, s_pp, s_pp + T, nullptr, ld_xu, ld_h, L, sub, lane, R);
+    else chain_wgrad_run<HT, SP, WIDE>(A.sh, s_xu, ld_xu, s_st + LH * T, s_dy, ld_y, s_pp, s_pp + T, slab, !first, ld_h, L, sub, lane);
     if (tid == 0)
       for (int i = 0; i < 16; ++i) loss += s_ls[i];
     __syncthreads();
@@ -184,10 +184,12 @@ extern "C" int mbpo_ens_nll_grads(const mbpo_ens_train_desc *d, void *stream) {
   A.rows = d->rows; A.idx = d->idx; A.batch = d->batch; A.predict_delta = d->predict_delta; A.min_std = d->min_std;
   A.slabs = d->workspace; A.extras = d->workspace + (long long)E * pl.n_slots * pl.dyn.n_params;
   A.n_slots = pl.n_slots; A.ld_xu = pl.ld_xu; A.ld_h = pl.ld_h; A.ld_y = pl.ld_y; A.LH = pl.LH;
-  rc = mbpo_ensure_lds<k_ens_nll_fwd_bwd<4>>(pl.lds, "ens_nll_grads");
+  const bool wide = net_is_wide(A.sh);
+  rc = wide ? mbpo_ensure_lds<k_ens_nll_fwd_bwd<4, true>>(pl.lds, "ens_nll_grads") : mbpo_ensure_lds<k_ens_nll_fwd_bwd<4, false>>(pl.lds, "ens_nll_grads");
   if (rc != MBPO_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_ens_nll_fwd_bwd<4>, dim3(E * pl.n_slots), dim3(512), pl.lds, st, A);
+  if (wide) hipLaunchKernelGGL((k_ens_nll_fwd_bwd<4, true>), dim3(E * pl.n_slots), dim3(512), pl.lds, st, A);
+  else hipLaunchKernelGGL((k_ens_nll_fwd_bwd<4, false>), dim3(E * pl.n_slots), dim3(512), pl.lds, st, A);
   hipLaunchKernelGGL(k_ens_reduce, dim3((pl.dyn.n_params + 255) / 256, E), dim3(256), 0, st, (const float *)A.slabs, (const float *)A.extras,
                      pl.n_slots, pl.dyn.n_params, (long long)d->batch, d->grads, d->metrics);
   MBPO_CHECK_LAUNCH("ens_nll_grads");

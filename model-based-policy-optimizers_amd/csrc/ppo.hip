@@ -116,7 +116,7 @@ __global__ void k_moments_final(const float *partial, int n_parts, long long n, 
 }
 
 // ------------------------------------------------------------------------------------------------ loss fwd/bwd
-template <int H, int SP>   // 4 chains x SP waves
+template <int H, int SP, bool WIDE>   // 4 chains x SP waves; WIDE: chain_run.hpp fast_shape
 __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
     const int tid = opaque(tid_), lane = tid & 63;
     const long long r0 = tile * 16;
     WSet<HT, SP> R;
-    if (chain < 2) chain_fwd_prefetch<HT, SP>(R, sh, nparams, sub, lane);
+    if (chain < 2) chain_fwd_prefetch<HT, SP, WIDE>(R, sh, nparams, sub, lane);
     {
       const long long nvalid = (M - r0 < 16 ? M - r0 : 16) * D;
       for (int idx = tid; idx < 16 * D; idx += nthreads) {   // flat copy, row stride D (no padding, no division)
@@ -173,11 +173,11 @@ __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
     __syncthreads();
     // ---- forward: policy logits (:80) and value baseline (:82), both stored for the backward
     if (chain < 2)
-      chain_fwd_run<HT, SP>(sh, nparams, s_x, ld_x, nullptr, nullptr, net ? zv : zp, net ? hv : hp, net ? y_v : y_pi, ld_y, ld_h, Lmax,
+      chain_fwd_run<HT, SP, WIDE>(sh, nparams, s_x, ld_x, nullptr, nullptr, net ? zv : zp, net ? hv : hp, net ? y_v : y_pi, ld_y, ld_h, Lmax,
                             sub, lane, R);
     else
       chain_idle_run(Lmax);
-    if (chain < 2) chain_dgrad_prefetch<HT, SP>(R, sh, nparams, sub, lane);
+    if (chain < 2) chain_dgrad_prefetch<HT, SP, WIDE>(R, sh, nparams, sub, lane);
     // ---- per-sample loss terms and output gradients
     if (tid < 16) {
       const int r = tid;
@@ -240,9 +240,9 @@ __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
     {
       float *d0 = s_pp + (2 * net) * TT, *d1 = d0 + TT;
       if (chain < 2)
-        chain_dgrad_run<HT, SP>(sh, nparams, s_dy + net * 16 * ld_y, ld_y, net ? zv : zp, d0, d1, nullptr, ld_x, ld_h, Lmax, sub, lane, R);
+        chain_dgrad_run<HT, SP, WIDE>(sh, nparams, s_dy + net * 16 * ld_y, ld_y, net ? zv : zp, d0, d1, nullptr, ld_x, ld_h, Lmax, sub, lane, R);
       else
-        chain_wgrad_run<HT, SP>(sh, s_x, ld_x, net ? hv : hp, s_dy + net * 16 * ld_y, ld_y, d0, d1, net ? slab_v : slab_pi, !first, ld_h,
+        chain_wgrad_run<HT, SP, WIDE>(sh, s_x, ld_x, net ? hv : hp, s_dy + net * 16 * ld_y, ld_y, d0, d1, net ? slab_v : slab_pi, !first, ld_h,
                                 Lmax, sub, lane);
     }
   }
@@ -469,13 +469,15 @@ extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
   }
   // 4. loss forward/backward
   if (pl.H == 64) {
-    rc = mbpo_ensure_lds<k_ppo_fwd_bwd<64, 4>>(pl.lds_fb, "ppo_grads");
+    const bool wide = net_is_wide(A.sh_pi) || net_is_wide(A.sh_v);
+    rc = wide ? mbpo_ensure_lds<k_ppo_fwd_bwd<64, 4, true>>(pl.lds_fb, "ppo_grads") : mbpo_ensure_lds<k_ppo_fwd_bwd<64, 4, false>>(pl.lds_fb, "ppo_grads");
     if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL((k_ppo_fwd_bwd<64, 4>), dim3(pl.n_slabs), dim3(1024), pl.lds_fb, st, A);
+    if (wide) hipLaunchKernelGGL((k_ppo_fwd_bwd<64, 4, true>), dim3(pl.n_slabs), dim3(1024), pl.lds_fb, st, A);
+    else hipLaunchKernelGGL((k_ppo_fwd_bwd<64, 4, false>), dim3(pl.n_slabs), dim3(1024), pl.lds_fb, st, A);
   } else {
-    rc = mbpo_ensure_lds<k_ppo_fwd_bwd<128, 2>>(pl.lds_fb, "ppo_grads");
+    rc = mbpo_ensure_lds<k_ppo_fwd_bwd<128, 2, false>>(pl.lds_fb, "ppo_grads");
     if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL((k_ppo_fwd_bwd<128, 2>), dim3(pl.n_slabs), dim3(512), pl.lds_fb, st, A);
+    hipLaunchKernelGGL((k_ppo_fwd_bwd<128, 2, false>), dim3(pl.n_slabs), dim3(512), pl.lds_fb, st, A);
   }
   // 5. reduce
   PpoReduceArgs R;

@@ -480,6 +480,7 @@ extern "C" int mbpo_debug_set_rollout_stamps(void *buf) {
 // (Dealing the members 2,2,2,2,4 waves to level the MFMA load per SIMD was tried: the second runner instantiation brought
 // 26 spills back and the kernel got slower, 82 -> 92 us.)
 #define RO64_WAVES 12
+template <bool WIDE>
 __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs64 AA) {
   extern __shared__ __align__(16) float smem[];
   const RolloutArgs &A = AA.a;
@@ -545,7 +546,7 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
       WSet<HT, 2> Rm;
       RO_STAMP(0);
       // ---- section A: policy input, obs into the dynamics input and the row; open-loop actions ----
-      if (!A.actions && wave < 4) chain_fwd_prefetch<HT, 4>(Rp, AA.sh_pi, A.policy.params, wave, lane);
+      if (!A.actions && wave < 4) chain_fwd_prefetch<HT, 4, WIDE>(Rp, AA.sh_pi, A.policy.params, wave, lane);
       for (int idx = tid; idx < 16 * X; idx += nthreads) {
         const int r = idx & 15, c = idx >> 4;
         const float o = s_obs[r * ld_x + c];
@@ -567,12 +568,12 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
       RO_STAMP(1);
       // ---- policy chain -> logits in s_y[0] ----
       if (!A.actions) {
-        if (wave < 4) chain_fwd_run<HT, 4>(AA.sh_pi, A.policy.params, s_pin, ld_x, s_pp, s_pp + T, nullptr, nullptr, s_y, ld_y, ld_h, PL, wave, lane, Rp);
+        if (wave < 4) chain_fwd_run<HT, 4, WIDE>(AA.sh_pi, A.policy.params, s_pin, ld_x, s_pp, s_pp + T, nullptr, nullptr, s_y, ld_y, ld_h, PL, wave, lane, Rp);
         else chain_idle_run(PL);
       }
       RO_STAMP(2);
       const bool mactive = (E > 0) && (mchain < A.n_chains) && (mchain < E);
-      if (mactive) chain_fwd_prefetch<HT, 2>(Rm, AA.sh_dyn, A.dyn.params + (long long)mchain * A.dyn.net_stride, msub, lane);
+      if (mactive) chain_fwd_prefetch<HT, 2, WIDE>(Rm, AA.sh_dyn, A.dyn.params + (long long)mchain * A.dyn.net_stride, msub, lane);
       // ---- section B: NormalTanh sample (parametric_distribution.py:97-124) + AutoReset pre-step (training.py:119-124) ----
       if (!A.actions) {
         for (int idx = tid; idx < 16 * U; idx += nthreads) {
@@ -618,9 +619,9 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
             const int e = e0 + mchain;
             const bool act = (mchain < A.n_chains) && (e < E);
             if (act && (e0 > 0 || ar > 0))
-              chain_fwd_prefetch<HT, 2>(Rm, AA.sh_dyn, A.dyn.params + (long long)e * A.dyn.net_stride, msub, lane);
+              chain_fwd_prefetch<HT, 2, WIDE>(Rm, AA.sh_dyn, A.dyn.params + (long long)e * A.dyn.net_stride, msub, lane);
             if (act)
-              chain_fwd_run<HT, 2>(AA.sh_dyn, A.dyn.params + (long long)e * A.dyn.net_stride, s_xu, ld_xu, s_pp + mchain * 2 * T,
+              chain_fwd_run<HT, 2, WIDE>(AA.sh_dyn, A.dyn.params + (long long)e * A.dyn.net_stride, s_xu, ld_xu, s_pp + mchain * 2 * T,
                                    s_pp + mchain * 2 * T + T, nullptr, nullptr, s_y + e * 16 * ld_y, ld_y, ld_h, DL, msub, lane, Rm);
             else
               chain_idle_run(DL);
@@ -861,9 +862,11 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
     if (AA.a.n_chains > RO64_WAVES / 2) AA.a.n_chains = RO64_WAVES / 2;   // member chains of 2 waves side by side
     if (AA.a.n_chains < 1) AA.a.n_chains = 1;
     lds = (fixed_f + 2ull * (AA.a.n_chains > 1 ? AA.a.n_chains : 1) * 16 * A.ld_h) * sizeof(float);
-    rc = mbpo_ensure_lds<k_model_rollout64>(lds, "model_rollout");
+    const bool wide = net_is_wide(AA.sh_pi) || net_is_wide(AA.sh_dyn);
+    rc = wide ? mbpo_ensure_lds<k_model_rollout64<true>>(lds, "model_rollout") : mbpo_ensure_lds<k_model_rollout64<false>>(lds, "model_rollout");
     if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL(k_model_rollout64, dim3(grid), dim3(64 * RO64_WAVES), lds, st, AA);
+    if (wide) hipLaunchKernelGGL(k_model_rollout64<true>, dim3(grid), dim3(64 * RO64_WAVES), lds, st, AA);
+    else hipLaunchKernelGGL(k_model_rollout64<false>, dim3(grid), dim3(64 * RO64_WAVES), lds, st, AA);
   } else if (H == 128) LAUNCH_RO(128) else LAUNCH_RO(256)
 #undef LAUNCH_RO
   MBPO_CHECK_LAUNCH("model_rollout");

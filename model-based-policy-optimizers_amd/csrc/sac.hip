@@ -115,7 +115,7 @@ __device__ __forceinline__ ActSample normal_tanh_sample(float loc, float raw, fl
 //   P3  per layer: c0/c1: Q1/Q2 dgrad               P3  per layer: c0/c1: Q1/Q2 input-gradient
 //                  c2/c3: Q1/Q2 wgrad               -- dL/dlogits
 //                                                   P4  per layer: c0: pi dgrad   c1: pi wgrad
-template <int H, int SP>   // SP = waves per chain: 4 chains x SP waves
+template <int H, int SP, bool WIDE>   // SP = waves per chain: 4 chains x SP waves; WIDE: chain_run.hpp fast_shape
 __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
@@ -192,12 +192,12 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
       const int len = (role == 0) ? (ph == 0 ? Lmax : QL) : ((ph == 0 || ph == 3) ? PL : QL);
       const NetShape sh = netid == 0 ? A.sh_pi : A.sh_q;
       if (mode == CH_FWD)
-        chain_fwd_run<HT, SP>(sh, cparams, P(cx), cldx, P(cpp0), P(cpp1), P(czb), P(chb), P(cy), ld_y, ld_h, len, sub, lane, R,
+        chain_fwd_run<HT, SP, WIDE>(sh, cparams, P(cx), cldx, P(cpp0), P(cpp1), P(czb), P(chb), P(cy), ld_y, ld_h, len, sub, lane, R,
                               (A.stamps && tile == 0 && role == 1 && ph == 0 && wave == 0) ? A.stamps + 40 : nullptr);
       else if (mode == CH_DGRAD)
-        chain_dgrad_run<HT, SP>(sh, cparams, P(cy), ld_y, P(czb), P(cpp0), P(cpp1), P(cdx), ld_xu, ld_h, len, sub, lane, R);
+        chain_dgrad_run<HT, SP, WIDE>(sh, cparams, P(cy), ld_y, P(czb), P(cpp0), P(cpp1), P(cdx), ld_xu, ld_h, len, sub, lane, R);
       else if (mode == CH_WGRAD)
-        chain_wgrad_run<HT, SP>(sh, P(cx), cldx, P(chb), P(cy), ld_y, P(cpp0), P(cpp1), cslab, false, ld_h, len, sub, lane,
+        chain_wgrad_run<HT, SP, WIDE>(sh, P(cx), cldx, P(chb), P(cy), ld_y, P(cpp0), P(cpp1), cslab, false, ld_h, len, sub, lane,
                                 (A.stamps && tile == 0 && role == 0 && sub == 0 && chain == 2) ? A.stamps + 48 : nullptr);
       else
         chain_idle_run(len);
@@ -214,8 +214,8 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
       cslab = cd.slab_sel == 1 ? A.slab_pi + (long long)tile * A.pi.n_params + cd.slab_off
                                : (cd.slab_sel == 2 ? A.slab_q + (long long)tile * (2 * A.q.n_params) + cd.slab_off : nullptr);
       const NetShape shn = netid == 0 ? A.sh_pi : A.sh_q;
-      if (mode == CH_FWD) chain_fwd_prefetch<HT, SP>(R, shn, cparams, sub, lane);
-      else if (mode == CH_DGRAD) chain_dgrad_prefetch<HT, SP>(R, shn, cparams, sub, lane);
+      if (mode == CH_FWD) chain_fwd_prefetch<HT, SP, WIDE>(R, shn, cparams, sub, lane);
+      else if (mode == CH_DGRAD) chain_dgrad_prefetch<HT, SP, WIDE>(R, shn, cparams, sub, lane);
     }
     if (A.stamps && tile == 0 && tid == 0 && ph == 1) {
       unsigned long long t_;
@@ -882,13 +882,19 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
   hipStream_t st = (hipStream_t)stream;
   if (phase_mask & 1) {
     if (pl.H == 64) {
-      rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64>>(pl.lds, "sac_grads");
-      if (rc != MBPO_OK) return rc;
-      hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64>), dim3(2 * pl.n_tiles), dim3(256 * SP64), pl.lds, st, A);
+      if (net_is_wide(A.sh_pi) || net_is_wide(A.sh_q)) {
+        rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64, true>>(pl.lds, "sac_grads");
+        if (rc != MBPO_OK) return rc;
+        hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64, true>), dim3(2 * pl.n_tiles), dim3(256 * SP64), pl.lds, st, A);
+      } else {
+        rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64, false>>(pl.lds, "sac_grads");
+        if (rc != MBPO_OK) return rc;
+        hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64, false>), dim3(2 * pl.n_tiles), dim3(256 * SP64), pl.lds, st, A);
+      }
     } else {
-      rc = mbpo_ensure_lds<k_sac_fwd_bwd<128, 2>>(pl.lds, "sac_grads");
+      rc = mbpo_ensure_lds<k_sac_fwd_bwd<128, 2, false>>(pl.lds, "sac_grads");
       if (rc != MBPO_OK) return rc;
-      hipLaunchKernelGGL((k_sac_fwd_bwd<128, 2>), dim3(2 * pl.n_tiles), dim3(512), pl.lds, st, A);
+      hipLaunchKernelGGL((k_sac_fwd_bwd<128, 2, false>), dim3(2 * pl.n_tiles), dim3(512), pl.lds, st, A);
     }
   }
   if (!(phase_mask & 2)) {
