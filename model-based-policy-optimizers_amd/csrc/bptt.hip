@@ -176,337 +176,340 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
   float loss_ret = 0.f, loss_lp = 0.f;   // threads 0..15
   bool first_tile = true;
   const long long n_tiles = (A.n + 15) >> 4;
+  const bool ens = A.system_kind == MBPO_SYS_ENSEMBLE;
+  const int NR = ens ? (E + EC - 1) / EC : 0;   // ensemble rounds of EC member chains
+  const int Rm = ens ? NR : 1;                  // model ops of a forward step (pendulum: one elementwise op)
+  const int nF = Rm + 3, nB = 5 + (ens ? 2 * NR : 1);
+  // LDS offsets (floats from smem) of everything a chain can touch: the chain descriptor below is a handful of scalars
+  const int o_on = (int)(s_on - smem), o_nn = (int)(s_nn - smem), o_xu = (int)(s_xu - smem), o_y = (int)(s_y - smem);
+  const int o_dyt = (int)(s_dyt - smem), o_dyl = (int)(s_dyl - smem), o_yv = (int)(s_yv - smem), o_dyv = (int)(s_dyv - smem);
+  const int o_ye = (int)(s_ye - smem), o_dye = (int)(s_dye - smem), o_don = (int)(s_don - smem), o_dxc = (int)(s_dxc - smem);
+  const int o_dxe = (int)(s_dxe - smem), o_zp = (int)(zp - smem), o_hp = (int)(hp - smem), o_B = (int)(s_B - smem);
+#define P(off) ((off) < 0 ? (float *)nullptr : smem + (off))
+
+  // One step of the horizon = a short PROGRAM of ops; an op = (chain run, elementwise section, barrier).  Forward and backward
+  // steps walk the same loop body, so every runner (forward / dgrad / wgrad) is instantiated at exactly ONE call site — the
+  // per-site copies of the first version were 270 KB of code for a 64 KB instruction cache and spilled 250 VGPRs.
+  //   forward  t: [pi fwd | sample a_t] [member round r fwd | mean += ..]* (or [pendulum step]) [- | reward, normalise x'] [V1,V2 fwd | store, advance]
+  //   backward t: [- | reload step t] [pi, V1, V2 recompute | dL/dV] [V dgrad | dL/dx' += ..]
+  //               ([member round r recompute | dL/dy_e] [member dgrad | dL/d(x,a) += ..])* (or [- | pendulum vjp])
+  //               [- | reward vjp, dL/dlogits] [pi dgrad x2, wgrad | dL/dx_t]
+  enum { R_NONE, R_PI_FWD, R_ENS_FWD, R_CR_FWD, R_RECOMP, R_CR_DG, R_ENS_REFWD, R_ENS_DG, R_PI_BWD };
+  enum { E_SAMPLE, E_ACCUM, E_PEND, E_NN, E_STORE, E_RELOAD, E_DV, E_GXACC, E_DYE, E_DXUACC, E_PENDVJP, E_LOGITS, E_GXFINAL };
+
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, first_tile = false) {
     const long long row0 = tile * 16;
-    // ================================================= FORWARD =================================================
     for (int idx = tid; idx < 16 * X; idx += nthreads) {
       const int r = idx / X, c = idx - r * X;
       const long long i = row0 + r;
       const float v = i < A.n ? A.init_states[i * X + c] : 0.f;
       s_x[r * ld_x + c] = v;
+      s_on[r * ld_x + c] = (v - A.s_mean[c]) / A.s_std[c];
       if (i < A.n) A.w_xs[(i * (HZ + 1)) * X + c] = v;
     }
     __syncthreads();
 #pragma nounroll
-    for (int t = 0; t < HZ; ++t) {
-      // per-lane addresses are re-derived every step: hoisted out of the time loop they filled all 256 VGPRs and spilled 340 more
-      const int tid = opaque(tid_), lane = tid & 63;
-      for (int idx = tid; idx < 16 * X; idx += nthreads) {
-        const int r = idx / X, c = idx - r * X;
-        s_on[r * ld_x + c] = (s_x[r * ld_x + c] - A.s_mean[c]) / A.s_std[c];
-      }
-      __syncthreads();
-      {  // policy(stop_gradient(obs))  (optimizer_utils.py:85-86, bptt_optimizer.py:305-325)
-        if (wave < 4) {
-          WSet<HT, 4> R4;
-          chain_fwd_prefetch<HT, 4, WIDE>(R4, A.sh_pi, A.pi.params, wave, lane);
-          chain_fwd_run<HT, 4, WIDE>(A.sh_pi, A.pi.params, s_on, ld_x, s_B, s_B + T, nullptr, nullptr, s_y, ld_y, ld_h, PL, wave, lane, R4);
+    for (int step = 0; step < 2 * HZ; ++step) {
+      const bool bwd = step >= HZ;
+      const int t = bwd ? 2 * HZ - 1 - step : step;
+      const int nops = bwd ? nB : nF;
+#pragma nounroll
+      for (int op = 0; op < nops; ++op) {
+        // per-lane values are re-derived every op: hoisted out of the loops they fill the register file and spill
+        const int tid = opaque(tid_), lane = tid & 63;
+        // ---- decode the op (wave-uniform scalars) ----
+        int run = R_NONE, elem, rr = 0;
+        if (!bwd) {
+          if (op == 0) { run = R_PI_FWD; elem = E_SAMPLE; }
+          else if (op <= Rm) { run = ens ? R_ENS_FWD : R_NONE; elem = ens ? E_ACCUM : E_PEND; rr = op - 1; }
+          else if (op == Rm + 1) { elem = E_NN; }
+          else { run = R_CR_FWD; elem = E_STORE; }
         } else {
-          chain_idle_run(PL);
+          const int om = op - 3;   // position inside the model block
+          if (op == 0) { elem = E_RELOAD; }
+          else if (op == 1) { run = R_RECOMP; elem = E_DV; }
+          else if (op == 2) { run = R_CR_DG; elem = E_GXACC; }
+          else if (op < nB - 2) {
+            if (ens) { rr = om >> 1; run = (om & 1) ? R_ENS_DG : R_ENS_REFWD; elem = (om & 1) ? E_DXUACC : E_DYE; }
+            else { elem = E_PENDVJP; }
+          } else if (op == nB - 2) { elem = E_LOGITS; }
+          else { run = R_PI_BWD; elem = E_GXFINAL; }
         }
-      }
-      for (int idx = tid; idx < 16 * U; idx += nthreads) {
-        const int r = idx / U, d = idx - r * U;
-        const long long i = row0 + r;
-        const float mu = s_y[r * ld_y + d];
-        const float sg = fminf(fmaxf(softplus_f(s_y[r * ld_y + U + d] + A.c0), 1e-6f), 1e2f);
-        float eps = 0.f;
-        if (i < A.n) {
-          const long long nidx = (i * HZ + t) * U + d;
-          eps = A.act_noise ? A.act_noise[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
-          A.w_eps[nidx] = eps;
-        }
-        const float a = fminf(fmaxf(tanhf(mu + eps * sg), -0.999f), 0.999f);   // squash_action (:313-317)
-        s_xu[r * ld_xu + X + d] = a;
-        if (i < A.n) A.w_as[(i * HZ + t) * U + d] = a;
-      }
-      for (int idx = tid; idx < 16 * X; idx += nthreads) {
-        const int r = idx / X, c = idx - r * X;
-        s_xu[r * ld_xu + c] = s_x[r * ld_x + c];
-      }
-      __syncthreads();
-      // ---- System.step: next state + reward
-      if (A.system_kind == MBPO_SYS_ENSEMBLE) {
-        for (int idx = tid; idx < 16 * X; idx += nthreads) {
-          const int r = idx / X, c = idx - r * X;
-          s_xn[r * ld_x + c] = A.predict_delta ? s_x[r * ld_x + c] : 0.f;
-        }
-        for (int e0 = 0; e0 < E; e0 += EC) {
-          const int e = e0 + chain2;
-          const bool on = chain2 < EC && e < E;
-          if (on) {
-            const float *ep = A.dyn.params + (long long)e * A.dyn.net_stride;
-            WSet<HT, 2> R2;
-            chain_fwd_prefetch<HT, 2, WIDE>(R2, A.sh_dyn, ep, sub2, lane);
-            chain_fwd_run<HT, 2, WIDE>(A.sh_dyn, ep, s_xu, ld_xu, s_B + chain2 * 2 * T, s_B + chain2 * 2 * T + T, nullptr, nullptr,
-                                 s_ye + chain2 * 16 * ld_ye, ld_ye, ld_h, DL, sub2, lane, R2);
-          } else {
-            chain_idle_run(DL);
+        // ---- this wave's chain in the op ----
+        int mode = CH_IDLE, len = 0, cldx = ld_x, cldy = ld_y, cld_dx = ld_x;
+        int cx = -1, cpp0 = -1, cpp1 = -1, czb = -1, chb = -1, cy = -1, cdx = -1;
+        NetShape sh = A.sh_pi;
+        const float *cparams = A.pi.params;
+        if (run == R_PI_FWD) {
+          len = PL;
+          if (chain2 == 0) { mode = CH_FWD; cx = o_on; cpp0 = o_B; cpp1 = o_B + T; cy = o_y; }
+        } else if (run == R_ENS_FWD || run == R_ENS_REFWD || run == R_ENS_DG) {
+          len = DL;
+          const int e = rr * EC + chain2;
+          if (chain2 < EC && e < E) {
+            sh = A.sh_dyn;
+            cparams = A.dyn.params + (long long)e * A.dyn.net_stride;
+            cldy = ld_ye;
+            if (run == R_ENS_FWD) {
+              mode = CH_FWD; cx = o_xu; cldx = ld_xu; cpp0 = o_B + chain2 * 2 * T; cpp1 = cpp0 + T; cy = o_ye + chain2 * 16 * ld_ye;
+            } else {
+              const int ze = o_B + chain2 * (LH + 2) * T;
+              czb = ze; cpp0 = ze + LH * T; cpp1 = cpp0 + T;
+              if (run == R_ENS_REFWD) { mode = CH_FWD; cx = o_xu; cldx = ld_xu; cy = o_ye + chain2 * 16 * ld_ye; }
+              else { mode = CH_DGRAD; cy = o_dye + chain2 * 16 * ld_ye; cdx = o_dxe + chain2 * 16 * ld_xu; cld_dx = ld_xu; }
+            }
           }
+        } else if (run == R_CR_FWD) {
+          len = CL;
+          if (chain2 < 2) {
+            mode = CH_FWD; sh = A.sh_cr; cparams = chain2 ? cr2 : cr1;
+            cx = o_nn; cpp0 = o_B + 2 * chain2 * T; cpp1 = cpp0 + T; cy = o_yv + chain2 * 16 * 4; cldy = 4;
+          }
+        } else if (run == R_RECOMP) {          // critics region: z | z | 4 ping-pong tiles
+          len = PL > CL ? PL : CL;
+          if (chain2 == 0) { mode = CH_FWD; cx = o_on; czb = o_zp; chb = o_hp; cy = o_y; }
+          else if (chain2 < 3) {
+            const int net = chain2 - 1;
+            mode = CH_FWD; sh = A.sh_cr; cparams = net ? cr2 : cr1;
+            cx = o_nn; cpp0 = o_B + 2 * LH * T + 2 * net * T; cpp1 = cpp0 + T; czb = o_B + net * LH * T; cy = o_yv + net * 16 * 4; cldy = 4;
+          }
+        } else if (run == R_CR_DG) {
+          len = CL;
+          if (chain2 == 1 || chain2 == 2) {
+            const int net = chain2 - 1;
+            mode = CH_DGRAD; sh = A.sh_cr; cparams = net ? cr2 : cr1;
+            cy = o_dyv + net * 16 * 4; cldy = 4; czb = o_B + net * LH * T; cpp0 = o_B + 2 * LH * T + 2 * net * T; cpp1 = cpp0 + T;
+            cdx = o_dxc + net * 16 * ld_x;
+          }
+        } else if (run == R_PI_BWD) {          // chain 0: delta(total), chain 1: delta(log-prob path) + input gradient, chain 2: wgrad
+          len = PL;
+          if (chain2 < 2) {
+            mode = CH_DGRAD; cy = chain2 ? o_dyl : o_dyt; czb = o_zp; cpp0 = o_B + 2 * chain2 * T; cpp1 = cpp0 + T;
+            cdx = chain2 ? o_don : -1;
+          } else if (chain2 == 2) {
+            mode = CH_WGRAD; cx = o_on; chb = o_hp; cy = o_dyt; cpp0 = o_B; cpp1 = o_B + T;
+          }
+        }
+        // ---- the run: one call site per runner ----
+        if (run != R_NONE) {
+          if (mode == CH_FWD) {
+            WSet<HT, 2> R2;
+            chain_fwd_prefetch<HT, 2, WIDE>(R2, sh, cparams, sub2, lane);
+            chain_fwd_run<HT, 2, WIDE>(sh, cparams, P(cx), cldx, P(cpp0), P(cpp1), P(czb), P(chb), P(cy), cldy, ld_h, len, sub2, lane, R2);
+          } else if (mode == CH_DGRAD) {
+            WSet<HT, 2> R2;
+            chain_dgrad_prefetch<HT, 2, WIDE>(R2, sh, cparams, sub2, lane);
+            chain_dgrad_run<HT, 2, WIDE>(sh, cparams, P(cy), cldy, P(czb), P(cpp0), P(cpp1), P(cdx), cld_dx, ld_h, len, sub2, lane, R2);
+          } else if (mode == CH_WGRAD) {
+            chain_wgrad_run<HT, 2, WIDE>(sh, P(cx), cldx, P(chb), P(cy), cldy, P(cpp0), P(cpp1), slab, !(first_tile && t == HZ - 1), ld_h, len,
+                                         sub2, lane);
+          } else {
+            chain_idle_run(len);
+          }
+        }
+        // ---- the elementwise section ----
+        if (elem == E_SAMPLE) {
+          for (int idx = tid; idx < 16 * U; idx += nthreads) {
+            const int r = idx / U, d = idx - r * U;
+            const long long i = row0 + r;
+            const float mu = s_y[r * ld_y + d];
+            const float sg = fminf(fmaxf(softplus_f(s_y[r * ld_y + U + d] + A.c0), 1e-6f), 1e2f);
+            float eps = 0.f;
+            if (i < A.n) {
+              const long long nidx = (i * HZ + t) * U + d;
+              eps = A.act_noise ? A.act_noise[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
+              A.w_eps[nidx] = eps;
+            }
+            const float a = fminf(fmaxf(tanhf(mu + eps * sg), -0.999f), 0.999f);   // squash_action (:313-317)
+            s_xu[r * ld_xu + X + d] = a;
+            if (i < A.n) A.w_as[(i * HZ + t) * U + d] = a;
+          }
+          for (int idx = tid; idx < 16 * X; idx += nthreads) {
+            const int r = idx / X, c = idx - r * X;
+            const float xv = s_x[r * ld_x + c];
+            s_xu[r * ld_xu + c] = xv;
+            if (ens) s_xn[r * ld_x + c] = A.predict_delta ? xv : 0.f;   // the member means are added round by round
+          }
+        } else if (elem == E_ACCUM) {
           for (int idx = tid; idx < 16 * X; idx += nthreads) {
             const int r = idx / X, c = idx - r * X;
             float acc = 0.f;
-            for (int cc = 0; cc < EC && e0 + cc < E; ++cc) acc += s_ye[(cc * 16 + r) * ld_ye + c];
+            for (int cc = 0; cc < EC && rr * EC + cc < E; ++cc) acc += s_ye[(cc * 16 + r) * ld_ye + c];
             s_xn[r * ld_x + c] += acc / (float)E;
           }
-          __syncthreads();
-        }
-      } else if (tid < 16) {
-        float xn[3];
-        pend_fwd(s_xu + tid * ld_xu, s_xu[tid * ld_xu + X], A.sys_params, xn);
-        s_xn[tid * ld_x + 0] = xn[0]; s_xn[tid * ld_x + 1] = xn[1]; s_xn[tid * ld_x + 2] = xn[2];
-      }
-      if (tid < 16) {
-        const long long i = row0 + tid;
-        const float rew = reward_fwd(A, s_xu + tid * ld_xu);
-        if (i < A.n) A.w_rs[i * HZ + t] = rew;
-        s_scal[tid] = rew;
-      }
-      __syncthreads();
-      for (int idx = tid; idx < 16 * X; idx += nthreads) {
-        const int r = idx / X, c = idx - r * X;
-        s_nn[r * ld_x + c] = (s_xn[r * ld_x + c] - A.s_mean[c]) / A.s_std[c];
-      }
-      __syncthreads();
-      {  // target critics on the normalised next state (:338-343)
-        if (chain2 < 2) {
-          const float *cp = chain2 ? cr2 : cr1;
-          WSet<HT, 2> R2;
-          chain_fwd_prefetch<HT, 2, WIDE>(R2, A.sh_cr, cp, sub2, lane);
-          chain_fwd_run<HT, 2, WIDE>(A.sh_cr, cp, s_nn, ld_x, s_B + 2 * chain2 * T, s_B + 2 * chain2 * T + T, nullptr, nullptr,
-                               s_yv + chain2 * 16 * 4, 4, ld_h, CL, sub2, lane, R2);
-        } else {
-          chain_idle_run(CL);
-        }
-      }
-      if (tid < 16) {
-        const long long i = row0 + tid;
-        const float v1 = s_yv[tid * 4], v2 = s_yv[(16 + tid) * 4];
-        if (i < A.n) {
-          A.w_vs[i * HZ + t] = fminf(v1, v2);
-          A.w_km[i * HZ + t] = v1 < v2 ? 0.f : (v2 < v1 ? 1.f : 2.f);
-        }
-      }
-      // transition row + advance
-      for (int idx = tid; idx < 16 * DT; idx += nthreads) {
-        const int r = idx / DT, c = idx - r * DT;
-        const long long i = row0 + r;
-        if (i < A.n) {
-          float v;
-          if (c < X + U) v = s_xu[r * ld_xu + c];
-          else if (c == X + U) v = s_scal[r];
-          else if (c == X + U + 1) v = 1.0f;                     // discount = ones (optimizer_utils.py:114)
-          else v = s_xn[r * ld_x + (c - X - U - 2)];
-          A.transitions[(i * HZ + t) * DT + c] = v;
-        }
-      }
-      __syncthreads();
-      for (int idx = tid; idx < 16 * X; idx += nthreads) {
-        const int r = idx / X, c = idx - r * X;
-        const long long i = row0 + r;
-        const float v = s_xn[r * ld_x + c];
-        s_x[r * ld_x + c] = v;
-        if (i < A.n) A.w_xs[(i * (HZ + 1) + t + 1) * X + c] = v;
-      }
-      __syncthreads();
-    }
-    // ================================================= LAMBDA RETURNS =================================================
-    if (tid < 16) {
-      const long long i = row0 + tid;
-      if (i < A.n) {
-        float agg = A.w_vs[i * HZ + HZ - 1];
-        for (int t = HZ - 1; t >= 0; --t) {
-          const float rn = (A.w_rs[i * HZ + t] - r_mean) / r_std;
-          agg = rn + gam * A.w_vs[i * HZ + t] * (1.f - lam) + gam * lam * agg;
-          A.lambda_values[i * HZ + t] = agg;
-        }
-        float gp = 1.f, acc = 0.f;
-        for (int t = 0; t < HZ; ++t) {
-          acc += A.lambda_values[i * HZ + t] * gp;
-          gp *= gam;
-        }
-        loss_ret += acc;
-      }
-    }
-    for (int idx = tid; idx < 16 * ld_x; idx += nthreads) s_gx[idx] = 0.f;
-    __syncthreads();
-    // ================================================= BACKWARD =================================================
-#pragma nounroll
-    for (int t = HZ - 1; t >= 0; --t) {
-      const int tid = opaque(tid_), lane = tid & 63;
-      // ---- reload the step: x_t, x_{t+1}, a_t, eps_t
-      for (int idx = tid; idx < 16 * X; idx += nthreads) {
-        const int r = idx / X, c = idx - r * X;
-        const long long i = row0 + r;
-        const float xt = i < A.n ? A.w_xs[(i * (HZ + 1) + t) * X + c] : 0.f;
-        const float xn = i < A.n ? A.w_xs[(i * (HZ + 1) + t + 1) * X + c] : 0.f;
-        s_x[r * ld_x + c] = xt;
-        s_xu[r * ld_xu + c] = xt;
-        s_on[r * ld_x + c] = (xt - A.s_mean[c]) / A.s_std[c];
-        s_nn[r * ld_x + c] = (xn - A.s_mean[c]) / A.s_std[c];
-      }
-      for (int idx = tid; idx < 16 * U; idx += nthreads) {
-        const int r = idx / U, d = idx - r * U;
-        const long long i = row0 + r;
-        const float a = i < A.n ? A.w_as[(i * HZ + t) * U + d] : 0.f;
-        s_a[idx] = a;
-        s_eps[idx] = i < A.n ? A.w_eps[(i * HZ + t) * U + d] : 0.f;
-        s_xu[r * ld_xu + X + d] = a;
-      }
-      __syncthreads();
-      // ---- recompute: policy (z,h kept) || target critics (z kept)
-      float *zc1 = s_B, *zc2 = s_B + LH * T, *ppc = s_B + 2 * LH * T;   // critics: z | z | 4 pp tiles
-      {
-        const int Lm = PL > CL ? PL : CL;
-        if (chain2 < 3) {
-          const bool pol = chain2 == 0;
-          const NetShape shr = pol ? A.sh_pi : A.sh_cr;
-          const float *rp = pol ? A.pi.params : (chain2 == 1 ? cr1 : cr2);
-          float *rpp = pol ? nullptr : ppc + 2 * (chain2 - 1) * T;
-          WSet<HT, 2> R2;
-          chain_fwd_prefetch<HT, 2, WIDE>(R2, shr, rp, sub2, lane);
-          chain_fwd_run<HT, 2, WIDE>(shr, rp, pol ? s_on : s_nn, ld_x, rpp, pol ? nullptr : rpp + T, pol ? zp : (chain2 == 1 ? zc1 : zc2),
-                               pol ? hp : nullptr, pol ? s_y : s_yv + (chain2 - 1) * 16 * 4, pol ? ld_y : 4, ld_h, Lm, sub2, lane, R2);
-        } else {
-          chain_idle_run(Lm);
-        }
-      }
-      // ---- dL/dV_t on the arg-min target critic
-      if (tid < 16) {
-        const long long i = row0 + tid;
-        float dV = s_gR[t] * gam * (1.f - lam);
-        if (t == HZ - 1) dV += s_gR[HZ];
-        const float km = i < A.n ? A.w_km[i * HZ + t] : 0.f;
-        if (i >= A.n) dV = 0.f;
-        s_dyv[tid * 4] = km == 0.f ? dV : (km == 2.f ? 0.5f * dV : 0.f);
-        s_dyv[(16 + tid) * 4] = km == 1.f ? dV : (km == 2.f ? 0.5f * dV : 0.f);
-      }
-      __syncthreads();
-      {  // critic input gradients
-        const int net = chain2 - 1;
-        if (chain2 == 1 || chain2 == 2) {
-          const float *cp = net ? cr2 : cr1;
-          float *d0 = ppc + (net > 0 ? 2 * T : 0);
-          WSet<HT, 2> R2;
-          chain_dgrad_prefetch<HT, 2, WIDE>(R2, A.sh_cr, cp, sub2, lane);
-          chain_dgrad_run<HT, 2, WIDE>(A.sh_cr, cp, s_dyv + (net > 0 ? 16 * 4 : 0), 4, net ? zc2 : zc1, d0, d0 + T, s_dxc + (net > 0 ? 16 * ld_x : 0),
-                                 ld_x, ld_h, CL, sub2, lane, R2);
-        } else {
-          chain_idle_run(CL);
-        }
-      }
-      for (int idx = tid; idx < 16 * X; idx += nthreads) {
-        const int r = idx / X, c = idx - r * X;
-        s_gx[r * ld_x + c] += (s_dxc[r * ld_x + c] + s_dxc[(16 + r) * ld_x + c]) / A.s_std[c];   // d nn / d x' = 1/std
-      }
-      for (int idx = tid; idx < 16 * ld_xu; idx += nthreads) s_dxu[idx] = 0.f;
-      __syncthreads();
-      // ---- model backward: dL/d[x_t, a_t] from dL/dx_{t+1}
-      if (A.system_kind == MBPO_SYS_ENSEMBLE) {
-        if (A.predict_delta)
+        } else if (elem == E_PEND) {
+          if (tid < 16) {
+            float xn[3];
+            pend_fwd(s_xu + tid * ld_xu, s_xu[tid * ld_xu + X], A.sys_params, xn);
+            s_xn[tid * ld_x + 0] = xn[0]; s_xn[tid * ld_x + 1] = xn[1]; s_xn[tid * ld_x + 2] = xn[2];
+          }
+        } else if (elem == E_NN) {
+          if (tid < 16) {
+            const long long i = row0 + tid;
+            const float rew = reward_fwd(A, s_xu + tid * ld_xu);
+            if (i < A.n) A.w_rs[i * HZ + t] = rew;
+            s_scal[tid] = rew;
+          }
           for (int idx = tid; idx < 16 * X; idx += nthreads) {
             const int r = idx / X, c = idx - r * X;
-            s_dxu[r * ld_xu + c] = s_gx[r * ld_x + c];
+            s_nn[r * ld_x + c] = (s_xn[r * ld_x + c] - A.s_mean[c]) / A.s_std[c];
           }
-        const int dout = A.dyn.dims[DL];
-        for (int e0 = 0; e0 < E; e0 += EC) {
-          const int e = e0 + chain2;
-          const bool on = chain2 < EC && e < E;
-          const float *ep = A.dyn.params + (long long)(on ? e : 0) * A.dyn.net_stride;
-          float *ze = s_B + chain2 * (LH + 2) * T, *ppe = ze + LH * T;
-          if (on) {
-            WSet<HT, 2> R2;
-            chain_fwd_prefetch<HT, 2, WIDE>(R2, A.sh_dyn, ep, sub2, lane);
-            chain_fwd_run<HT, 2, WIDE>(A.sh_dyn, ep, s_xu, ld_xu, ppe, ppe + T, ze, nullptr, s_ye + chain2 * 16 * ld_ye, ld_ye, ld_h, DL, sub2, lane, R2);
-          } else {
-            chain_idle_run(DL);
+        } else if (elem == E_STORE) {
+          if (tid < 16) {
+            const long long i = row0 + tid;
+            const float v1 = s_yv[tid * 4], v2 = s_yv[(16 + tid) * 4];
+            if (i < A.n) {
+              A.w_vs[i * HZ + t] = fminf(v1, v2);
+              A.w_km[i * HZ + t] = v1 < v2 ? 0.f : (v2 < v1 ? 1.f : 2.f);
+            }
           }
+          for (int idx = tid; idx < 16 * DT; idx += nthreads) {   // transition row
+            const int r = idx / DT, c = idx - r * DT;
+            const long long i = row0 + r;
+            if (i < A.n) {
+              float v;
+              if (c < X + U) v = s_xu[r * ld_xu + c];
+              else if (c == X + U) v = s_scal[r];
+              else if (c == X + U + 1) v = 1.0f;                     // discount = ones (optimizer_utils.py:114)
+              else v = s_xn[r * ld_x + (c - X - U - 2)];
+              A.transitions[(i * HZ + t) * DT + c] = v;
+            }
+          }
+          for (int idx = tid; idx < 16 * X; idx += nthreads) {    // advance: x_{t+1} becomes x_t (+ its normalised copy)
+            const int r = idx / X, c = idx - r * X;
+            const long long i = row0 + r;
+            const float v = s_xn[r * ld_x + c];
+            s_x[r * ld_x + c] = v;
+            s_on[r * ld_x + c] = (v - A.s_mean[c]) / A.s_std[c];
+            if (i < A.n) A.w_xs[(i * (HZ + 1) + t + 1) * X + c] = v;
+          }
+        } else if (elem == E_RELOAD) {
+          if (t == HZ - 1) {
+            // ===== lambda returns (once per tile, between the sweeps): R_t = r~_t + g(1-l)V_t + g*l*R_{t+1} =====
+            if (tid < 16) {
+              const long long i = row0 + tid;
+              if (i < A.n) {
+                float agg = A.w_vs[i * HZ + HZ - 1];
+                for (int tt = HZ - 1; tt >= 0; --tt) {
+                  const float rn = (A.w_rs[i * HZ + tt] - r_mean) / r_std;
+                  agg = rn + gam * A.w_vs[i * HZ + tt] * (1.f - lam) + gam * lam * agg;
+                  A.lambda_values[i * HZ + tt] = agg;
+                }
+                float gp = 1.f, acc = 0.f;
+                for (int tt = 0; tt < HZ; ++tt) {
+                  acc += A.lambda_values[i * HZ + tt] * gp;
+                  gp *= gam;
+                }
+                loss_ret += acc;
+              }
+            }
+            for (int idx = tid; idx < 16 * ld_x; idx += nthreads) s_gx[idx] = 0.f;
+          }
+          // reload the step: x_t, x_{t+1}, a_t, eps_t
+          for (int idx = tid; idx < 16 * X; idx += nthreads) {
+            const int r = idx / X, c = idx - r * X;
+            const long long i = row0 + r;
+            const float xt = i < A.n ? A.w_xs[(i * (HZ + 1) + t) * X + c] : 0.f;
+            const float xn = i < A.n ? A.w_xs[(i * (HZ + 1) + t + 1) * X + c] : 0.f;
+            s_x[r * ld_x + c] = xt;
+            s_xu[r * ld_xu + c] = xt;
+            s_on[r * ld_x + c] = (xt - A.s_mean[c]) / A.s_std[c];
+            s_nn[r * ld_x + c] = (xn - A.s_mean[c]) / A.s_std[c];
+          }
+          for (int idx = tid; idx < 16 * U; idx += nthreads) {
+            const int r = idx / U, d = idx - r * U;
+            const long long i = row0 + r;
+            const float a = i < A.n ? A.w_as[(i * HZ + t) * U + d] : 0.f;
+            s_a[idx] = a;
+            s_eps[idx] = i < A.n ? A.w_eps[(i * HZ + t) * U + d] : 0.f;
+            s_xu[r * ld_xu + X + d] = a;
+          }
+        } else if (elem == E_DV) {
+          if (tid < 16) {   // dL/dV_t on the arg-min target critic
+            const long long i = row0 + tid;
+            float dV = s_gR[t] * gam * (1.f - lam);
+            if (t == HZ - 1) dV += s_gR[HZ];
+            const float km = i < A.n ? A.w_km[i * HZ + t] : 0.f;
+            if (i >= A.n) dV = 0.f;
+            s_dyv[tid * 4] = km == 0.f ? dV : (km == 2.f ? 0.5f * dV : 0.f);
+            s_dyv[(16 + tid) * 4] = km == 1.f ? dV : (km == 2.f ? 0.5f * dV : 0.f);
+          }
+        } else if (elem == E_GXACC) {
+          // dL/dx_{t+1} += critic path (d nn / d x' = 1/std); dL/d[x_t, a_t] starts from it (delta model) or from zero
+          for (int idx = tid; idx < 16 * X; idx += nthreads) {
+            const int r = idx / X, c = idx - r * X;
+            const float gxn = s_gx[r * ld_x + c] + (s_dxc[r * ld_x + c] + s_dxc[(16 + r) * ld_x + c]) / A.s_std[c];
+            s_gx[r * ld_x + c] = gxn;
+            s_dxu[r * ld_xu + c] = (ens && A.predict_delta) ? gxn : 0.f;
+          }
+          for (int idx = tid; idx < 16 * U; idx += nthreads) {
+            const int r = idx / U, d = idx - r * U;
+            s_dxu[r * ld_xu + X + d] = 0.f;
+          }
+        } else if (elem == E_DYE) {
+          const int dout = A.dyn.dims[DL];
           for (int idx = tid; idx < EC * 16 * dout; idx += nthreads) {
             const int cc = idx / (16 * dout), rem = idx - cc * 16 * dout;
             const int r = rem / dout, c = rem - r * dout;
             s_dye[(cc * 16 + r) * ld_ye + c] = c < X ? s_gx[r * ld_x + c] / (float)E : 0.f;   // x' = base + mean_e mu_e
           }
-          __syncthreads();
-          {
-            if (on) {
-              WSet<HT, 2> R2;
-              chain_dgrad_prefetch<HT, 2, WIDE>(R2, A.sh_dyn, ep, sub2, lane);
-              chain_dgrad_run<HT, 2, WIDE>(A.sh_dyn, ep, s_dye + chain2 * 16 * ld_ye, ld_ye, ze, ppe, ppe + T, s_dxe + chain2 * 16 * ld_xu, ld_xu, ld_h,
-                                     DL, sub2, lane, R2);
-            } else {
-              chain_idle_run(DL);
-            }
-          }
+        } else if (elem == E_DXUACC) {
           for (int idx = tid; idx < 16 * (X + U); idx += nthreads) {
             const int r = idx / (X + U), c = idx - r * (X + U);
             float acc = 0.f;
-            for (int cc = 0; cc < EC && e0 + cc < E; ++cc) acc += s_dxe[(cc * 16 + r) * ld_xu + c];
+            for (int cc = 0; cc < EC && rr * EC + cc < E; ++cc) acc += s_dxe[(cc * 16 + r) * ld_xu + c];
             s_dxu[r * ld_xu + c] += acc;
           }
-          __syncthreads();
+        } else if (elem == E_PENDVJP) {
+          if (tid < 16) {
+            float dx[3], du;
+            pend_vjp(s_xu + tid * ld_xu, s_xu[tid * ld_xu + X], A.sys_params, s_gx + tid * ld_x, dx, &du);
+            s_dxu[tid * ld_xu + 0] = dx[0]; s_dxu[tid * ld_xu + 1] = dx[1]; s_dxu[tid * ld_xu + 2] = dx[2];
+            s_dxu[tid * ld_xu + X] = du;
+          }
+        } else if (elem == E_LOGITS) {
+          // reward gradient, action / log-prob terms -> dL/dlogits (total, log-prob path)
+          if (tid < 16) {
+            const int r = tid;
+            const long long i = row0 + r;
+            const bool ok = i < A.n;
+            reward_vjp(A, s_xu + r * ld_xu, ok ? s_gR[t] / r_std : 0.f, s_dxu + r * ld_xu);   // dL/dr_t = dL/dR_t / r_std
+            float lp = 0.f;
+            for (int d = 0; d < U; ++d) {
+              const float mu = s_y[r * ld_y + d], sraw = s_y[r * ld_y + U + d] + A.c0;
+              const float sp = softplus_f(sraw);
+              const bool sin_ = (sp > 1e-6f) && (sp < 1e2f);
+              const float sg = fminf(fmaxf(sp, 1e-6f), 1e2f);
+              const float dsig = sin_ ? sigmoid_f(sraw) : 0.f;
+              const float a = s_a[r * U + d], eps = s_eps[r * U + d];
+              const float th = tanhf(mu + eps * sg);
+              const float dadw = (th > -0.999f && th < 0.999f) ? (1.f - th * th) : 0.f;
+              const float om = 1.f - a * a;
+              const float u = 0.5f * logf((1.f + a) / (1.f - a));            // atanh(a)   (:111-120)
+              const float q = (u - mu) / sg;
+              lp += -0.5f * q * q - logf(sg) - LOG_SQRT_2PI_B - logf(om);
+              const float dlp_da = (-q / sg) / om + 2.f * a / om;
+              const float Ga = s_dxu[r * ld_xu + X + d] + w_lp * dlp_da;
+              const float l_mu = w_lp * (q / sg), l_sr = w_lp * ((q * q - 1.f) / sg) * dsig;
+              const float a_mu = Ga * dadw, a_sr = Ga * dadw * eps * dsig;
+              s_dyl[r * ld_y + d] = ok ? l_mu : 0.f;
+              s_dyl[r * ld_y + U + d] = ok ? l_sr : 0.f;
+              s_dyt[r * ld_y + d] = ok ? l_mu + a_mu : 0.f;
+              s_dyt[r * ld_y + U + d] = ok ? l_sr + a_sr : 0.f;
+            }
+            if (ok) loss_lp += lp;
+          }
+        } else {   // E_GXFINAL: dL/dx_t = model/reward x-part + policy-input path (through the state normaliser)
+          for (int idx = tid; idx < 16 * X; idx += nthreads) {
+            const int r = idx / X, c = idx - r * X;
+            s_gx[r * ld_x + c] = s_dxu[r * ld_xu + c] + s_don[r * ld_x + c] / A.s_std[c];
+          }
         }
-      } else if (tid < 16) {
-        float dx[3], du;
-        pend_vjp(s_xu + tid * ld_xu, s_xu[tid * ld_xu + X], A.sys_params, s_gx + tid * ld_x, dx, &du);
-        s_dxu[tid * ld_xu + 0] = dx[0]; s_dxu[tid * ld_xu + 1] = dx[1]; s_dxu[tid * ld_xu + 2] = dx[2];
-        s_dxu[tid * ld_xu + X] = du;
+        __syncthreads();
       }
-      __syncthreads();
-      // ---- reward gradient, action / log-prob terms -> dL/dlogits (total, log-prob path)
-      if (tid < 16) {
-        const int r = tid;
-        const long long i = row0 + r;
-        const bool ok = i < A.n;
-        reward_vjp(A, s_xu + r * ld_xu, ok ? s_gR[t] / r_std : 0.f, s_dxu + r * ld_xu);   // dL/dr_t = dL/dR_t / r_std
-        float lp = 0.f;
-        for (int d = 0; d < U; ++d) {
-          const float mu = s_y[r * ld_y + d], sraw = s_y[r * ld_y + U + d] + A.c0;
-          const float sp = softplus_f(sraw);
-          const bool sin_ = (sp > 1e-6f) && (sp < 1e2f);
-          const float sg = fminf(fmaxf(sp, 1e-6f), 1e2f);
-          const float dsig = sin_ ? sigmoid_f(sraw) : 0.f;
-          const float a = s_a[r * U + d], eps = s_eps[r * U + d];
-          const float th = tanhf(mu + eps * sg);
-          const float dadw = (th > -0.999f && th < 0.999f) ? (1.f - th * th) : 0.f;
-          const float om = 1.f - a * a;
-          const float u = 0.5f * logf((1.f + a) / (1.f - a));            // atanh(a)   (:111-120)
-          const float q = (u - mu) / sg;
-          lp += -0.5f * q * q - logf(sg) - LOG_SQRT_2PI_B - logf(om);
-          const float dlp_da = (-q / sg) / om + 2.f * a / om;
-          const float Ga = s_dxu[r * ld_xu + X + d] + w_lp * dlp_da;
-          const float l_mu = w_lp * (q / sg), l_sr = w_lp * ((q * q - 1.f) / sg) * dsig;
-          const float a_mu = Ga * dadw, a_sr = Ga * dadw * eps * dsig;
-          s_dyl[r * ld_y + d] = ok ? l_mu : 0.f;
-          s_dyl[r * ld_y + U + d] = ok ? l_sr : 0.f;
-          s_dyt[r * ld_y + d] = ok ? l_mu + a_mu : 0.f;
-          s_dyt[r * ld_y + U + d] = ok ? l_sr + a_sr : 0.f;
-        }
-        if (ok) loss_lp += lp;
-      }
-      __syncthreads();
-      // ---- policy backward: chain 0 = delta(total), chain 1 = delta(log-prob path) with input gradient, chain 2 = wgrad
-      {
-        float *dt0 = s_B, *dt1 = s_B + T, *dl0 = s_B + 2 * T, *dl1 = s_B + 3 * T;
-        const bool accum = !(first_tile && t == HZ - 1);
-        if (chain2 < 2) {
-          WSet<HT, 2> R2;
-          chain_dgrad_prefetch<HT, 2, WIDE>(R2, A.sh_pi, A.pi.params, sub2, lane);
-          chain_dgrad_run<HT, 2, WIDE>(A.sh_pi, A.pi.params, chain2 ? s_dyl : s_dyt, ld_y, zp, chain2 ? dl0 : dt0, chain2 ? dl1 : dt1,
-                                 chain2 ? s_don : nullptr, ld_x, ld_h, PL, sub2, lane, R2);
-        } else if (chain2 == 2) {
-          chain_wgrad_run<HT, 2, WIDE>(A.sh_pi, s_on, ld_x, hp, s_dyt, ld_y, dt0, dt1, slab, accum, ld_h, PL, sub2, lane);
-        } else {
-          chain_idle_run(PL);
-        }
-      }
-      // ---- dL/dx_t = model/reward x-part + policy-input path (through the state normaliser)
-      for (int idx = tid; idx < 16 * X; idx += nthreads) {
-        const int r = idx / X, c = idx - r * X;
-        s_gx[r * ld_x + c] = s_dxu[r * ld_xu + c] + s_don[r * ld_x + c] / A.s_std[c];
-      }
-      __syncthreads();
     }
   }
+#undef P
   if (tid < 16) {
     s_scal[tid] = loss_ret;
     s_scal[16 + tid] = loss_lp;
