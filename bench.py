@@ -292,7 +292,7 @@ def main():
         traffic, traffic_note = None, "no PMC measurement committed"
         try:
             pmc = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
-            k = pmc["k_sac_fwd_bwd<64,4>"]
+            k = pmc["k_sac_fwd_bwd<64,4,false>"]
             traffic = int((k["fetch_kb"] + k["write_kb"]) * 1024)
             traffic_note = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes); "
                             "1.64 MB of it are the per-tile gradient slabs (deterministic reduction), reads are L2-absorbed weights")
@@ -317,7 +317,7 @@ def main():
             "sac_updates_per_s": GRAD_UPDATES * args.steps / dt,
             "sac_update_samples_per_s": world * BATCH * GRAD_UPDATES * args.steps / dt,
             "params_finite": finite,
-            "roofline": {"bound": "mfma", "kernel": "k_sac_fwd_bwd<64,4>", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "k_sac_fwd_bwd<64,4,false>", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_us": t_kernel * 1e6, "algorithmic_flop_per_launch": BATCH * flop_per_sample,
                          "launches_per_step": GRAD_UPDATES},

@@ -34,7 +34,16 @@ struct BpttArgs {
   float *slabs, *extras;
   int ld_x, ld_xu, ld_h, ld_y, ld_ye, LH, EC;
   NetShape sh_pi, sh_cr, sh_dyn;
+  unsigned long long *stamps;   // measurement hook (mbpo_debug_set_bptt_stamps): [16] cycles per op kind + [16] op counts, block 0; or NULL
 };
+
+static unsigned long long *g_bptt_stamps = nullptr;
+// Measurement hook (not part of include/mbpo_hip.h): device buffer of 32 uint64; block 0 adds the s_memtime cycles of every op
+// (run + elementwise section + barrier) to [elem code] and counts it in [16 + elem code].  NULL switches it off.
+extern "C" int mbpo_debug_set_bptt_stamps(void *buf) {
+  g_bptt_stamps = (unsigned long long *)buf;
+  return MBPO_OK;
+}
 
 // analytic pendulum step + vector-Jacobian product (dynamics/pendulum_dynamics.py:29-63)
 __device__ __forceinline__ void pend_fwd(const float *x, float u, const float *sp, float *xn) {
@@ -90,11 +99,13 @@ __device__ __forceinline__ float reward_fwd(const BpttArgs &A, const float *xu) 
   for (int d = 0; d < U; ++d) cu += rp[d] * (xu[X + d] * xu[X + d]);
   return -cx - cu;
 }
-// dxu[0..X+U) += g * d reward / d(x,u)
-__device__ __forceinline__ void reward_vjp(const BpttArgs &A, const float *xu, float g, float *dxu) {
-  const int X = A.X, U = A.U;
+// one component (c < X: state, c >= X: action) of g * d reward / d(x,u): lets the (row, column) threads of a section each take one
+__device__ __forceinline__ float reward_grad_comp(const BpttArgs &A, const float *xu, float g, int c) {
+  const int X = A.X;
   if (A.reward_kind == MBPO_REWARD_PENDULUM) {
     const float *rp = A.reward_params;
+    if (c == 2) return g * (-0.2f * xu[2]);
+    if (c >= X) return g * (-2.f * rp[1] * xu[X]);
     const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
     const float theta = atan2f(xu[1], xu[0]);
     float mpy = fmodf(theta - rp[2] + PI_F, TWO_PI_F);
@@ -102,15 +113,10 @@ __device__ __forceinline__ void reward_vjp(const BpttArgs &A, const float *xu, f
     const float d = mpy - PI_F;
     const float r2 = xu[0] * xu[0] + xu[1] * xu[1];
     const float g_th = g * (-2.f * rp[0] * d);
-    dxu[0] += g_th * (-xu[1] / r2);
-    dxu[1] += g_th * (xu[0] / r2);
-    dxu[2] += g * (-0.2f * xu[2]);
-    dxu[X] += g * (-2.f * rp[1] * xu[X]);
-    return;
+    return c == 0 ? g_th * (-xu[1] / r2) : g_th * (xu[0] / r2);
   }
   const float *tp = A.reward_params, *qp = tp + X, *rp = qp + X;
-  for (int c = 0; c < X; ++c) dxu[c] += g * (-2.f * qp[c] * (xu[c] - tp[c]));
-  for (int d = 0; d < U; ++d) dxu[X + d] += g * (-2.f * rp[d] * xu[X + d]);
+  return c < X ? g * (-2.f * qp[c] * (xu[c] - tp[c])) : g * (-2.f * rp[c - X] * xu[c]);
 }
 
 template <int H, bool WIDE>
@@ -173,7 +179,7 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
   }
 
   float *slab = A.slabs + (long long)blockIdx.x * A.pi.n_params;
-  float loss_ret = 0.f, loss_lp = 0.f;   // threads 0..15
+  float loss_ret = 0.f, loss_lp = 0.f;   // loss_ret: threads 0..15; loss_lp: the (row, action-dim) threads of the logits section
   bool first_tile = true;
   const long long n_tiles = (A.n + 15) >> 4;
   const bool ens = A.system_kind == MBPO_SYS_ENSEMBLE;
@@ -190,6 +196,8 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
   // One step of the horizon = a short PROGRAM of ops; an op = (chain run, elementwise section, barrier).  Forward and backward
   // steps walk the same loop body, so every runner (forward / dgrad / wgrad) is instantiated at exactly ONE call site — the
   // per-site copies of the first version were 270 KB of code for a 64 KB instruction cache and spilled 250 VGPRs.
+  // (Requesting the NEXT op's first layer before the current op's elementwise section was tried: the loop-carried chain
+  //  descriptor cost 110 more SGPR spills and the kernel got 0-6% slower; the request stays right in front of its run.)
   //   forward  t: [pi fwd | sample a_t] [member round r fwd | mean += ..]* (or [pendulum step]) [- | reward, normalise x'] [V1,V2 fwd | store, advance]
   //   backward t: [- | reload step t] [pi, V1, V2 recompute | dL/dV] [V dgrad | dL/dx' += ..]
   //               ([member round r recompute | dL/dy_e] [member dgrad | dL/d(x,a) += ..])* (or [- | pendulum vjp])
@@ -217,6 +225,8 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
       for (int op = 0; op < nops; ++op) {
         // per-lane values are re-derived every op: hoisted out of the loops they fill the register file and spill
         const int tid = opaque(tid_), lane = tid & 63;
+        unsigned long long t_op0 = 0;
+        if (A.stamps && blockIdx.x == 0 && tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_op0)::"memory");
         // ---- decode the op (wave-uniform scalars) ----
         int run = R_NONE, elem, rr = 0;
         if (!bwd) {
@@ -468,35 +478,35 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
             s_dxu[tid * ld_xu + X] = du;
           }
         } else if (elem == E_LOGITS) {
-          // reward gradient, action / log-prob terms -> dL/dlogits (total, log-prob path)
-          if (tid < 16) {
-            const int r = tid;
-            const long long i = row0 + r;
-            const bool ok = i < A.n;
-            reward_vjp(A, s_xu + r * ld_xu, ok ? s_gR[t] / r_std : 0.f, s_dxu + r * ld_xu);   // dL/dr_t = dL/dR_t / r_std
-            float lp = 0.f;
-            for (int d = 0; d < U; ++d) {
-              const float mu = s_y[r * ld_y + d], sraw = s_y[r * ld_y + U + d] + A.c0;
-              const float sp = softplus_f(sraw);
-              const bool sin_ = (sp > 1e-6f) && (sp < 1e2f);
-              const float sg = fminf(fmaxf(sp, 1e-6f), 1e2f);
-              const float dsig = sin_ ? sigmoid_f(sraw) : 0.f;
-              const float a = s_a[r * U + d], eps = s_eps[r * U + d];
-              const float th = tanhf(mu + eps * sg);
-              const float dadw = (th > -0.999f && th < 0.999f) ? (1.f - th * th) : 0.f;
-              const float om = 1.f - a * a;
-              const float u = 0.5f * logf((1.f + a) / (1.f - a));            // atanh(a)   (:111-120)
-              const float q = (u - mu) / sg;
-              lp += -0.5f * q * q - logf(sg) - LOG_SQRT_2PI_B - logf(om);
-              const float dlp_da = (-q / sg) / om + 2.f * a / om;
-              const float Ga = s_dxu[r * ld_xu + X + d] + w_lp * dlp_da;
-              const float l_mu = w_lp * (q / sg), l_sr = w_lp * ((q * q - 1.f) / sg) * dsig;
-              const float a_mu = Ga * dadw, a_sr = Ga * dadw * eps * dsig;
-              s_dyl[r * ld_y + d] = ok ? l_mu : 0.f;
-              s_dyl[r * ld_y + U + d] = ok ? l_sr : 0.f;
-              s_dyt[r * ld_y + d] = ok ? l_mu + a_mu : 0.f;
-              s_dyt[r * ld_y + U + d] = ok ? l_sr + a_sr : 0.f;
-            }
+          // reward gradient, action / log-prob terms -> dL/dlogits (total, log-prob path); one (row, column) per thread
+          for (int idx = tid; idx < 16 * X; idx += nthreads) {
+            const int r = idx / X, c = idx - r * X;
+            const bool ok = row0 + r < A.n;
+            s_dxu[r * ld_xu + c] += reward_grad_comp(A, s_xu + r * ld_xu, ok ? s_gR[t] / r_std : 0.f, c);   // dL/dr_t = dL/dR_t / r_std
+          }
+          for (int idx = tid; idx < 16 * U; idx += nthreads) {
+            const int r = idx / U, d = idx - r * U;
+            const bool ok = row0 + r < A.n;
+            const float mu = s_y[r * ld_y + d], sraw = s_y[r * ld_y + U + d] + A.c0;
+            const float sp = softplus_f(sraw);
+            const bool sin_ = (sp > 1e-6f) && (sp < 1e2f);
+            const float sg = fminf(fmaxf(sp, 1e-6f), 1e2f);
+            const float dsig = sin_ ? sigmoid_f(sraw) : 0.f;
+            const float a = s_a[r * U + d], eps = s_eps[r * U + d];
+            const float th = tanhf(mu + eps * sg);
+            const float dadw = (th > -0.999f && th < 0.999f) ? (1.f - th * th) : 0.f;
+            const float om = 1.f - a * a;
+            const float u = 0.5f * logf((1.f + a) / (1.f - a));            // atanh(a)   (:111-120)
+            const float q = (u - mu) / sg;
+            const float lp = -0.5f * q * q - logf(sg) - LOG_SQRT_2PI_B - logf(om);
+            const float dlp_da = (-q / sg) / om + 2.f * a / om;
+            const float Ga = s_dxu[r * ld_xu + X + d] + reward_grad_comp(A, s_xu + r * ld_xu, ok ? s_gR[t] / r_std : 0.f, X + d) + w_lp * dlp_da;
+            const float l_mu = w_lp * (q / sg), l_sr = w_lp * ((q * q - 1.f) / sg) * dsig;
+            const float a_mu = Ga * dadw, a_sr = Ga * dadw * eps * dsig;
+            s_dyl[r * ld_y + d] = ok ? l_mu : 0.f;
+            s_dyl[r * ld_y + U + d] = ok ? l_sr : 0.f;
+            s_dyt[r * ld_y + d] = ok ? l_mu + a_mu : 0.f;
+            s_dyt[r * ld_y + U + d] = ok ? l_sr + a_sr : 0.f;
             if (ok) loss_lp += lp;
           }
         } else {   // E_GXFINAL: dL/dx_t = model/reward x-part + policy-input path (through the state normaliser)
@@ -506,21 +516,28 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
           }
         }
         __syncthreads();
+        if (A.stamps && blockIdx.x == 0 && tid == 0) {
+          unsigned long long t_op1;
+          asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_op1)::"memory");
+          A.stamps[elem] += t_op1 - t_op0;
+          A.stamps[16 + elem] += 1ull;
+        }
       }
     }
   }
 #undef P
-  if (tid < 16) {
-    s_scal[tid] = loss_ret;
-    s_scal[16 + tid] = loss_lp;
+  {
+    float lpw = loss_lp;   // fixed shuffle tree per wave, waves in order: deterministic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lpw += __shfl_down(lpw, o, 64);
+    if (tid < 16) s_scal[tid] = loss_ret;
+    if (lane == 0) s_scal[16 + wave] = lpw;
   }
   __syncthreads();
   if (tid == 0) {
     float a = 0.f, b = 0.f;
-    for (int i = 0; i < 16; ++i) {
-      a += s_scal[i];
-      b += s_scal[16 + i];
-    }
+    for (int i = 0; i < 16; ++i) a += s_scal[i];
+    for (int w = 0; w < (int)(nthreads >> 6); ++w) b += s_scal[16 + w];
     A.extras[blockIdx.x * 2 + 0] = a;
     A.extras[blockIdx.x * 2 + 1] = b;
   }
@@ -537,16 +554,10 @@ struct BpttReduceArgs {
 __global__ void __launch_bounds__(256) k_bptt_reduce(BpttReduceArgs A) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < A.P) {
-    float g = 0.f;
-    for (int s = 0; s < A.n_slabs; ++s) g += A.slabs[(long long)s * A.P + i];
-    A.grads[i] = g;
+    A.grads[i] = slab_sum<16>(A.slabs, A.P, A.n_slabs, i);
   }
   if (i == 0) {
-    float a = 0.f, b = 0.f;
-    for (int s = 0; s < A.n_slabs; ++s) {
-      a += A.extras[s * 2 + 0];
-      b += A.extras[s * 2 + 1];
-    }
+    const float a = slab_sum<16>(A.extras, 2, A.n_slabs, 0), b = slab_sum<16>(A.extras, 2, A.n_slabs, 1);
     const float invNH = 1.0f / ((float)A.n * (float)A.H);
     const float ent = -b * invNH;                 // entropy_loss = -mean log_prob
     A.metrics[0] = -a * invNH + A.ent_coef * ent; // actor_loss (:352)
@@ -700,6 +711,7 @@ extern "C" int mbpo_bptt_actor_grads(const mbpo_bptt_desc *d, void *stream) {
   A.w_xs = ws + pl.o_xs; A.w_as = ws + pl.o_as; A.w_eps = ws + pl.o_eps; A.w_rs = ws + pl.o_rs; A.w_vs = ws + pl.o_vs;
   A.w_km = ws + pl.o_km; A.slabs = ws + pl.o_slabs; A.extras = ws + pl.o_extras;
   A.ld_x = pl.ld_x; A.ld_xu = pl.ld_xu; A.ld_h = pl.ld_h; A.ld_y = pl.ld_y; A.ld_ye = pl.ld_ye; A.LH = pl.LH; A.EC = pl.EC;
+  A.stamps = g_bptt_stamps;
   A.sh_pi = NetShape{A.pi.dims[0], A.pi.n_layers, A.pi.dims[A.pi.n_layers], A.pi.act};
   A.sh_cr = NetShape{A.cr.dims[0], A.cr.n_layers, A.cr.dims[A.cr.n_layers], A.cr.act};
   if (A.system_kind == MBPO_SYS_ENSEMBLE) A.sh_dyn = NetShape{A.dyn.dims[0], A.dyn.n_layers, A.dyn.dims[A.dyn.n_layers], A.dyn.act};
@@ -800,13 +812,10 @@ __global__ void __launch_bounds__(256) k_critic_reduce(const float *slabs, const
                                                         float *grads, float *metrics) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < C2) {
-    float g = 0.f;
-    for (int s = 0; s < n_slabs; ++s) g += slabs[(long long)s * C2 + i];
-    grads[i] = g;
+    grads[i] = slab_sum<16>(slabs, C2, n_slabs, i);
   }
   if (i == 0) {
-    float a = 0.f;
-    for (int s = 0; s < n_slabs; ++s) a += extras[s];
+    const float a = slab_sum<16>(extras, 1, n_slabs, 0);
     metrics[0] = 0.5f * a / (float)batch;     // 0.5 * (mean l2(v1) + mean l2(v2))
   }
 }

@@ -105,13 +105,10 @@ __global__ void __launch_bounds__(256) k_ens_reduce(const float *slabs, const fl
   const int e = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n_params) {
-    float g = 0.f;
-    for (int s = 0; s < n_slots; ++s) g += slabs[((long long)e * n_slots + s) * n_params + i];
-    grads[(long long)e * n_params + i] = g;
+    grads[(long long)e * n_params + i] = slab_sum<16>(slabs + (long long)e * n_slots * n_params, n_params, n_slots, i);
   }
   if (i == 0) {
-    float a = 0.f;
-    for (int s = 0; s < n_slots; ++s) a += extras[(long long)e * n_slots + s];
+    const float a = slab_sum<16>(extras + (long long)e * n_slots, 1, n_slots, 0);
     metrics[e] = a / (float)batch;
   }
 }

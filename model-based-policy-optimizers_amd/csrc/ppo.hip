@@ -115,6 +115,42 @@ __global__ void k_moments_final(const float *partial, int n_parts, long long n, 
   }
 }
 
+// minibatches up to PPO_MOM_FUSED_MAX elements: both passes in ONE workgroup of 1024 threads (3 kernel boundaries of ~4.5 us less
+// per minibatch_step; the data is a few KB).  Fixed strides and a fixed shuffle/LDS tree: deterministic.
+#define PPO_MOM_FUSED_MAX 65536
+__global__ void __launch_bounds__(1024) k_moments_fused(const float *x, long long n, float *mom) {
+  __shared__ float s_w[16];
+  __shared__ float s_mean;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float acc = 0.f;
+  for (long long i = tid; i < n; i += 1024) acc += x[i];
+  acc = ppo_wave_sum(acc);
+  if (lane == 0) s_w[w] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f;
+    for (int k = 0; k < 16; ++k) a += s_w[k];
+    s_mean = a / (float)n;
+  }
+  __syncthreads();
+  const float mean = s_mean;
+  acc = 0.f;
+  for (long long i = tid; i < n; i += 1024) {
+    const float d = x[i] - mean;
+    acc += d * d;
+  }
+  acc = ppo_wave_sum(acc);
+  __syncthreads();
+  if (lane == 0) s_w[w] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f;
+    for (int k = 0; k < 16; ++k) a += s_w[k];
+    mom[0] = mean;
+    mom[1] = sqrtf(a / (float)n);                          // population std (jnp.std)
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ loss fwd/bwd
 template <int H, int SP, bool WIDE>   // 4 chains x SP waves; WIDE: chain_run.hpp fast_shape
 __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
@@ -279,17 +315,11 @@ struct PpoReduceArgs {
 __global__ void __launch_bounds__(256) k_ppo_reduce(PpoReduceArgs A) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < A.NPV) {
-    float g = 0.f;
-    for (int s = 0; s < A.n_slabs; ++s) g += A.slabs[(long long)s * A.NPV + i];
-    A.grads[i] = g;
+    A.grads[i] = slab_sum<16>(A.slabs, A.NPV, A.n_slabs, i);
   }
   if (i == 0) {
-    float a = 0.f, b = 0.f, c = 0.f;
-    for (int s = 0; s < A.n_slabs; ++s) {
-      a += A.extras[s * 4 + 0];
-      b += A.extras[s * 4 + 1];
-      c += A.extras[s * 4 + 2];
-    }
+    const float a = slab_sum<16>(A.extras, 4, A.n_slabs, 0), b = slab_sum<16>(A.extras, 4, A.n_slabs, 1),
+                c = slab_sum<16>(A.extras, 4, A.n_slabs, 2);
     const float invM = 1.0f / (float)A.M;
     const float pl = a * invM, vl = b * invM, el = A.entropy_cost * -(c * invM);
     A.metrics[0] = pl + vl + el;   // total_loss
@@ -462,10 +492,13 @@ extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
     float *part = ws + pl.off_part;
     long long blocks = (pl.M + 255) / 256;
     int g = (int)(blocks < PPO_MOM_WGS ? blocks : PPO_MOM_WGS);
+    if (pl.M <= PPO_MOM_FUSED_MAX) hipLaunchKernelGGL(k_moments_fused, dim3(1), dim3(1024), 0, st, (const float *)A.adv, pl.M, A.mom);
+    else {
     hipLaunchKernelGGL(k_moments_partial<0>, dim3(g), dim3(256), 0, st, (const float *)A.adv, pl.M, (const float *)A.mom, part);
     hipLaunchKernelGGL(k_moments_final<0>, dim3(1), dim3(64), 0, st, (const float *)part, g, pl.M, A.mom);
     hipLaunchKernelGGL(k_moments_partial<1>, dim3(g), dim3(256), 0, st, (const float *)A.adv, pl.M, (const float *)A.mom, part);
     hipLaunchKernelGGL(k_moments_final<1>, dim3(1), dim3(64), 0, st, (const float *)part, g, pl.M, A.mom);
+    }
   }
   // 4. loss forward/backward
   if (pl.H == 64) {

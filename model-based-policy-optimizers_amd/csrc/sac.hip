@@ -414,22 +414,6 @@ __device__ __forceinline__ void group_sumsq(float g, int i, int P, int Q2, int N
   if (tid < 3) ss_part[blockIdx.x * 3 + tid] = s_ss[tid][0] + s_ss[tid][1] + s_ss[tid][2] + s_ss[tid][3];
 }
 
-// sum over the tiles' slabs in tile order, the loads of 8 tiles in flight at a time (a plain `g += slab[t]` loop with a runtime
-// trip count issues load, wait, add, load, ...: 16 dependent HBM/L2 round trips)
-__device__ __forceinline__ float slab_sum(const float *slab, long long stride, int n_tiles, int i) {
-  float g = 0.f;
-  int t = 0;
-  for (; t + 8 <= n_tiles; t += 8) {
-    float v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = slab[(long long)(t + k) * stride + i];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) g += v[k];
-  }
-  for (; t < n_tiles; ++t) g += slab[(long long)t * stride + i];
-  return g;
-}
-
 __global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
   const int NP = A.P + A.Q2 + 1;
   const int i = blockIdx.x * 256 + threadIdx.x;
