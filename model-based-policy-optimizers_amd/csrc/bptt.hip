@@ -552,11 +552,10 @@ struct BpttReduceArgs {
 };
 
 __global__ void __launch_bounds__(256) k_bptt_reduce(BpttReduceArgs A) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < A.P) {
-    A.grads[i] = slab_sum<16>(A.slabs, A.P, A.n_slabs, i);
-  }
-  if (i == 0) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const float gsum = slab_sum_wg64(A.slabs, A.P, A.n_slabs, i, i < A.P);
+  if (threadIdx.x < 64 && i < A.P) A.grads[i] = gsum;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     const float a = slab_sum<16>(A.extras, 2, A.n_slabs, 0), b = slab_sum<16>(A.extras, 2, A.n_slabs, 1);
     const float invNH = 1.0f / ((float)A.n * (float)A.H);
     const float ent = -b * invNH;                 // entropy_loss = -mean log_prob
@@ -725,7 +724,7 @@ extern "C" int mbpo_bptt_actor_grads(const mbpo_bptt_desc *d, void *stream) {
   BpttReduceArgs R;
   R.slabs = A.slabs; R.extras = A.extras; R.n_slabs = pl.n_slabs; R.P = pl.P; R.H = d->horizon; R.n = d->n; R.ent_coef = d->ent_coef;
   R.grads = d->grads; R.metrics = d->metrics;
-  hipLaunchKernelGGL(k_bptt_reduce, dim3((pl.P + 255) / 256), dim3(256), 0, st, R);
+  hipLaunchKernelGGL(k_bptt_reduce, dim3((pl.P + 63) / 64), dim3(256), 0, st, R);
   MBPO_CHECK_LAUNCH("bptt_actor_grads");
   return MBPO_OK;
 }
@@ -810,11 +809,10 @@ __global__ void __launch_bounds__(256 * SP) k_critic_fwd_bwd(CriticArgs A) {
 
 __global__ void __launch_bounds__(256) k_critic_reduce(const float *slabs, const float *extras, int n_slabs, int C2, long long batch,
                                                         float *grads, float *metrics) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < C2) {
-    grads[i] = slab_sum<16>(slabs, C2, n_slabs, i);
-  }
-  if (i == 0) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const float gsum = slab_sum_wg64(slabs, C2, n_slabs, i, i < C2);
+  if (threadIdx.x < 64 && i < C2) grads[i] = gsum;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     const float a = slab_sum<16>(extras, 1, n_slabs, 0);
     metrics[0] = 0.5f * a / (float)batch;     // 0.5 * (mean l2(v1) + mean l2(v2))
   }
@@ -870,7 +868,7 @@ extern "C" int mbpo_critic_grads(const float *critic_params, int32_t x_dim, int3
   if (wide) hipLaunchKernelGGL((k_critic_fwd_bwd<64, 4, true>), dim3(ns), dim3(1024), lds, st, A);
   else hipLaunchKernelGGL((k_critic_fwd_bwd<64, 4, false>), dim3(ns), dim3(1024), lds, st, A);
   const int C2 = 2 * A.cr.n_params;
-  hipLaunchKernelGGL(k_critic_reduce, dim3((C2 + 255) / 256), dim3(256), 0, st, (const float *)A.slabs, (const float *)A.extras, ns, C2,
+  hipLaunchKernelGGL(k_critic_reduce, dim3((C2 + 63) / 64), dim3(256), 0, st, (const float *)A.slabs, (const float *)A.extras, ns, C2,
                      (long long)batch, grads, metrics);
   MBPO_CHECK_LAUNCH("critic_grads");
   return MBPO_OK;

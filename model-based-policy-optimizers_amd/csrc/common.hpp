@@ -212,3 +212,18 @@ __device__ __forceinline__ float slab_sum(const float *slab, long long stride, i
   return g;
 }
 
+
+// Workgroup form for MANY slabs (n up to the CU count) and few outputs: a 256-thread workgroup produces 64 outputs, wave q sums
+// the q-th quarter of the terms (coalesced: 64 consecutive outputs per wave), the four partials are then added in q order.
+// 4x the workgroups of one-output-per-thread (a 10 k-parameter gradient is 40 workgroups otherwise: 40 of 256 CUs busy) and a
+// quarter of the dependent batches per thread.  Fixed order: deterministic.  Returns the sum on wave 0 (other waves: 0).
+// i = this thread's output index (blockIdx.x * 64 + (threadIdx.x & 63)), valid = i in range.
+__device__ __forceinline__ float slab_sum_wg64(const float *slab, long long stride, int n, long long i, bool valid) {
+  __shared__ float s_q[4][64];
+  const int p = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int chunk = (n + 3) >> 2;
+  const int t0 = q * chunk, t1 = (t0 + chunk < n) ? t0 + chunk : n;
+  s_q[q][p] = (valid && t1 > t0) ? slab_sum<16>(slab + (long long)t0 * stride, stride, t1 - t0, i) : 0.f;
+  __syncthreads();
+  return q == 0 ? ((s_q[0][p] + s_q[1][p]) + s_q[2][p]) + s_q[3][p] : 0.f;
+}

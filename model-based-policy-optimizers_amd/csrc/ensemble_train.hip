@@ -103,11 +103,10 @@ __global__ void __launch_bounds__(128 * SP) k_ens_nll_fwd_bwd(EnsTrainArgs A) {
 __global__ void __launch_bounds__(256) k_ens_reduce(const float *slabs, const float *extras, int n_slots, int n_params, long long batch,
                                                      float *grads, float *metrics) {
   const int e = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_params) {
-    grads[(long long)e * n_params + i] = slab_sum<16>(slabs + (long long)e * n_slots * n_params, n_params, n_slots, i);
-  }
-  if (i == 0) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const float gsum = slab_sum_wg64(slabs + (long long)e * n_slots * n_params, n_params, n_slots, i, i < n_params);
+  if (threadIdx.x < 64 && i < n_params) grads[(long long)e * n_params + i] = gsum;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     const float a = slab_sum<16>(extras + (long long)e * n_slots, 1, n_slots, 0);
     metrics[e] = a / (float)batch;
   }
@@ -187,7 +186,7 @@ extern "C" int mbpo_ens_nll_grads(const mbpo_ens_train_desc *d, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (wide) hipLaunchKernelGGL((k_ens_nll_fwd_bwd<4, true>), dim3(E * pl.n_slots), dim3(512), pl.lds, st, A);
   else hipLaunchKernelGGL((k_ens_nll_fwd_bwd<4, false>), dim3(E * pl.n_slots), dim3(512), pl.lds, st, A);
-  hipLaunchKernelGGL(k_ens_reduce, dim3((pl.dyn.n_params + 255) / 256, E), dim3(256), 0, st, (const float *)A.slabs, (const float *)A.extras,
+  hipLaunchKernelGGL(k_ens_reduce, dim3((pl.dyn.n_params + 63) / 64, E), dim3(256), 0, st, (const float *)A.slabs, (const float *)A.extras,
                      pl.n_slots, pl.dyn.n_params, (long long)d->batch, d->grads, d->metrics);
   MBPO_CHECK_LAUNCH("ens_nll_grads");
   return MBPO_OK;

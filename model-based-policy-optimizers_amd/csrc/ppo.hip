@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(1024) k_moments_fused(const float *x, long lon
   __shared__ float s_mean;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   float acc = 0.f;
+#pragma unroll 4
   for (long long i = tid; i < n; i += 1024) acc += x[i];
   acc = ppo_wave_sum(acc);
   if (lane == 0) s_w[w] = acc;
@@ -135,6 +136,7 @@ __global__ void __launch_bounds__(1024) k_moments_fused(const float *x, long lon
   __syncthreads();
   const float mean = s_mean;
   acc = 0.f;
+#pragma unroll 4
   for (long long i = tid; i < n; i += 1024) {
     const float d = x[i] - mean;
     acc += d * d;
@@ -313,11 +315,10 @@ struct PpoReduceArgs {
 };
 
 __global__ void __launch_bounds__(256) k_ppo_reduce(PpoReduceArgs A) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < A.NPV) {
-    A.grads[i] = slab_sum<16>(A.slabs, A.NPV, A.n_slabs, i);
-  }
-  if (i == 0) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const float gsum = slab_sum_wg64(A.slabs, A.NPV, A.n_slabs, i, i < A.NPV);
+  if (threadIdx.x < 64 && i < A.NPV) A.grads[i] = gsum;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     const float a = slab_sum<16>(A.extras, 4, A.n_slabs, 0), b = slab_sum<16>(A.extras, 4, A.n_slabs, 1),
                 c = slab_sum<16>(A.extras, 4, A.n_slabs, 2);
     const float invM = 1.0f / (float)A.M;
@@ -516,7 +517,7 @@ extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
   PpoReduceArgs R;
   R.slabs = A.slabs; R.extras = A.extras; R.n_slabs = pl.n_slabs; R.NPV = pl.NPV; R.M = pl.M; R.entropy_cost = d->entropy_cost;
   R.grads = d->grads; R.metrics = d->metrics; R.metrics_accum = d->metrics_accum; R.step_count = d->step_count;
-  hipLaunchKernelGGL(k_ppo_reduce, dim3((pl.NPV + 255) / 256), dim3(256), 0, st, R);
+  hipLaunchKernelGGL(k_ppo_reduce, dim3((pl.NPV + 63) / 64), dim3(256), 0, st, R);
   MBPO_CHECK_LAUNCH("ppo_grads");
   return MBPO_OK;
 }
