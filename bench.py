@@ -221,23 +221,23 @@ def main():
             one_step()
         torch.cuda.synchronize()
         log(f"{max(args.warmup, 1)} eager warm-up steps done")
+        # Collectives inside the captured step: only the peer-memory exchange (plain kernels) is captured.  A capture that a
+        # library collective invalidates cannot be recovered from in-process (torch's allocator and stream state stay in
+        # capture mode; measured here: the next launches fail or the process segfaults), so with torch.distributed
+        # all_reduce in the step the launches are issued eagerly — at ~35 us of GPU work per sgd_step plus the collective
+        # the host keeps ahead of the GPU anyway.  MBPO_BENCH_CAPTURE_COLLECTIVES=1 forces the capture (fatal if it fails).
+        if (use_graph and pg is not None and getattr(trainer, "p2p", None) is None
+                and os.environ.get("MBPO_BENCH_CAPTURE_COLLECTIVES") != "1"):
+            log("gradient exchange is torch.distributed all_reduce: issuing the step eagerly (no hipGraph)")
+            use_graph = False
         if use_graph:
-            # With ranks > 1 the captured step contains the RCCL all-reduces; if this RCCL/torch build cannot capture them
-            # every rank falls back to eager launches together (the capture fails identically on all ranks).
-            try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    trainer.training_step(ts, env_state, buffer_state, 29)
-                log("graph captured")
-                graph.replay()   # one untimed replay
-                torch.cuda.synchronize()
-                log("graph replayed once")
-            except Exception as e:  # noqa: BLE001
-                if pg is None:
-                    raise
-                log(f"hipGraph capture with collectives failed ({type(e).__name__}: {e}); running eagerly")
-                graph = None
-                torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                trainer.training_step(ts, env_state, buffer_state, 29)
+            log("graph captured")
+            graph.replay()   # one untimed replay
+            torch.cuda.synchronize()
+            log("graph replayed once")
 
         def barrier():
             if pg is not None:
