@@ -256,3 +256,26 @@ def test_oracle_reproduces_sac_step_golden():
     out = mod.evaluate(cfg, st, batch, noise, nm, ns)
     for k, v in out.items():
         np.testing.assert_allclose(v, gold[k], rtol=1e-12, atol=1e-13, err_msg=k)
+
+
+def test_oracle_reproduces_ppo_and_bptt_goldens():
+    """tests/golden/ppo_step_small.npz and bptt_actor_small.npz (tests/golden/make_ppo_bptt_golden.py): the fp64 oracles must
+    reproduce the committed gradients / losses / scans — an edit to oracle/ppo.py, oracle/bptt.py, oracle/scans.py or
+    oracle/nets.py that changes the arithmetic shows up here."""
+    import importlib.util
+    from pathlib import Path
+    import numpy as np
+    gdir = Path(__file__).resolve().parent / "golden"
+    spec = importlib.util.spec_from_file_location("make_ppo_bptt_golden", gdir / "make_ppo_bptt_golden.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gold = np.load(gdir / "ppo_step_small.npz")
+    cfg, params, data, noise, nm, ns = mod.build_ppo()
+    np.testing.assert_array_equal(params.numpy(), gold["params"])
+    for k, v in mod.eval_ppo(cfg, params, data, noise, nm, ns).items():
+        np.testing.assert_allclose(v, gold[k], rtol=1e-12, atol=1e-13, err_msg=f"ppo {k}")
+    gold = np.load(gdir / "bptt_actor_small.npz")
+    args = mod.build_bptt()
+    np.testing.assert_array_equal(args[1].numpy(), gold["actor_params"])
+    for k, v in mod.eval_bptt(*args).items():
+        np.testing.assert_allclose(v, gold[k], rtol=1e-12, atol=1e-13, err_msg=f"bptt {k}")

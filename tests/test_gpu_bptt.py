@@ -233,3 +233,26 @@ def test_bptt_normalizer_matches_reference_form(dev):
     st = nz.update(torch.full((8, 4), 2.5, device=dev), nz.initialize_normalizer_state(dev))
     assert torch.allclose(st.std.cpu(), torch.full((4,), 1e-8))
     assert torch.allclose(st.mean.cpu(), torch.full((4,), 2.5))
+
+
+def test_bptt_actor_against_committed_golden(dev):
+    """HIP actor gradient vs tests/golden/bptt_actor_small.npz (fp64 oracle on fixed inputs: pendulum, horizon 6, 16 trajectories,
+    64x2 nets).  Rollout quantities 2e-4, lambda-returns 5e-4, losses rtol 1e-4, gradients atol 5e-6 + rtol 1e-3."""
+    from pathlib import Path
+    from mbpo import _hip, ops
+    gold = np.load(Path(__file__).resolve().parent / "golden" / "bptt_actor_small.npz")
+    X, U, H, n = 3, 1, 6, 16
+    op = ops.BpttActorGrad(x_dim=X, u_dim=U, horizon=H, actor_dims=[X, 64, 64, 2 * U], critic_dims=[X, 64, 64, 1], n=n, device=dev,
+                           init_stddev=1.0, discount=0.97, lambda_=0.9, ent_coef=0.05)
+    f = lambda k: torch.from_numpy(gold[k]).float().to(dev).contiguous()
+    pp = osys.PendulumParams()
+    op(actor_params=f("actor_params"), target_critic_params=f("critic_params"), init_states=f("x0"), state_mean=f("state_mean"),
+       state_std=f("state_std"), reward_mean_std=f("reward_mean_std"), act_noise=f("noise"), system_kind=_hip.SYS_PENDULUM,
+       reward_kind=_hip.REWARD_PENDULUM, reward_params=torch.tensor(pp.reward_vector()).to(dev), sys_params=torch.tensor(pp.sys_vector()).to(dev))
+    torch.cuda.synchronize()
+    rows = op.transitions.cpu().double().reshape(n, H, -1)
+    np.testing.assert_allclose(rows[..., X + U + 2:].numpy(), gold["next_observation"], atol=2e-4, rtol=2e-4)
+    np.testing.assert_allclose(rows[..., X + U].numpy(), gold["reward"], atol=5e-4, rtol=5e-4)
+    np.testing.assert_allclose(op.lambda_values.cpu().double().reshape(n, H).numpy(), gold["lambda_values"], atol=5e-4, rtol=5e-4)
+    np.testing.assert_allclose(op.metrics.cpu().numpy(), gold["losses"], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(op.grads.cpu().double(), torch.from_numpy(gold["grads"]), atol=5e-6, rtol=1e-3)

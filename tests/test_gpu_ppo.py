@@ -103,3 +103,21 @@ def test_ppo_bad_args(dev):
     from mbpo import ops, _hip
     with pytest.raises(_hip.MbpoHipError):
         ops.PpoUpdater(x_dim=3, u_dim=1, policy_dims=[3, 64, 128, 2], value_dims=[3, 64, 64, 1], batch_size=8, unroll_length=4, device=dev)
+
+
+def test_ppo_step_against_committed_golden(dev):
+    """HIP minibatch gradient vs tests/golden/ppo_step_small.npz (fp64 oracle outputs on fixed inputs; one-hidden-layer nets,
+    B=8, T=6).  Gradients atol 2e-6 + rtol 3e-4, loss terms 2e-5."""
+    from pathlib import Path
+    from mbpo import ops
+    gold = np.load(Path(__file__).resolve().parent / "golden" / "ppo_step_small.npz")
+    X, U, B, T = 3, 1, 8, 6
+    up = ops.PpoUpdater(x_dim=X, u_dim=U, policy_dims=[X, 64, 2 * U], value_dims=[X, 64, 1], batch_size=B, unroll_length=T, device=dev,
+                        entropy_cost=1e-2, discounting=0.97, reward_scaling=0.5, gae_lambda=0.9, clipping_epsilon=0.2,
+                        normalize_advantage=True, lr=1e-3, wd=1e-4)
+    f = lambda k: torch.from_numpy(gold[k]).float().to(dev).contiguous()
+    up.load_state(f("params"))
+    up.minibatch_step(f("data"), f("norm_mean"), f("norm_std"), f("noise"))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(up.grads.cpu().double(), torch.from_numpy(gold["grads"]), atol=2e-6, rtol=3e-4)
+    np.testing.assert_allclose(up.metrics.cpu().numpy(), gold["losses"], rtol=2e-5, atol=1e-5)
