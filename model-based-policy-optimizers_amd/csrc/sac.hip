@@ -424,12 +424,9 @@ __global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
     const int j = i - A.P;
     g = slab_sum(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
-    float ce = 0.f, ac = 0.f, al = 0.f;
-    for (int t = 0; t < A.n_tiles; ++t) {
-      ce += A.slab_ex[t * 4 + 0];
-      ac += A.slab_ex[t * 4 + 1];
-      al += A.slab_ex[t * 4 + 2];
-    }
+    // (all loads of the three sums in flight together: this one thread is the kernel's critical path)
+    const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
+                al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
     const float invB = 1.0f / (float)A.B;
     g = al * invB;                          // d alpha_loss / d log_alpha
     A.metrics[0] = 0.5f * ce * (0.5f * invB);  // critic_loss = 0.5 * mean over [B,2]
@@ -459,12 +456,9 @@ __global__ void __launch_bounds__(256) k_sac_reduce_push(SacReduceArgs A, P2pDev
     const int j = i - A.P;
     g = slab_sum(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
-    float ce = 0.f, ac = 0.f, al = 0.f;
-    for (int t = 0; t < A.n_tiles; ++t) {
-      ce += A.slab_ex[t * 4 + 0];
-      ac += A.slab_ex[t * 4 + 1];
-      al += A.slab_ex[t * 4 + 2];
-    }
+    // (all loads of the three sums in flight together: this one thread is the kernel's critical path)
+    const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
+                al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
     const float invB = 1.0f / (float)A.B;
     g = al * invB;
     A.metrics[0] = 0.5f * ce * (0.5f * invB);
@@ -512,6 +506,7 @@ struct SacApplyArgs {
 
 __global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
   __shared__ float s_scale[3];
+  __shared__ float s_corr[2];
   const int tid = threadIdx.x;
   // the element's own operands are requested first: their latency overlaps the norm reduction below
   const int NP_ = A.P + A.Q2 + 1;
@@ -529,6 +524,11 @@ __global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
       ss = wave_sum64(ss);
       // [3P optax.clip_by_global_norm] g_norm = sqrt(sum g^2); g <- g if g_norm < max_norm else (g / g_norm) * max_norm
       if (lane == 0) s_scale[w] = sqrtf(ss) * A.grad_scale;
+    } else if (lane == 0) {
+      // the Adam bias corrections are the same for every element: the fourth wave forms them (two powf, ~300 instructions)
+      // beside the three norm reductions instead of every wave after the barrier
+      s_corr[0] = 1.f - powf(0.9f, count_in);
+      s_corr[1] = 1.f - powf(0.999f, count_in);
     }
   }
   __syncthreads();
@@ -541,14 +541,13 @@ __global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
   if (!(gnorm < A.max_norm)) g = (g / gnorm) * A.max_norm;
   // [3P optax.adamw] scale_by_adam(b1=.9,b2=.999,eps=1e-8) -> add_decayed_weights(wd) -> scale(-lr)
   const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-  const float count = count_in;  // already incremented for this step
-  // optax forms (1 - decay) in Python double and only then casts: f32(0.1), f32(0.001) — not 1.f - 0.999f
+  // (count_in is already incremented for this step)  optax forms (1 - decay) in Python double and only then casts: f32(0.1), f32(0.001) — not 1.f - 0.999f
   const float mu = b1 * m_in + 0.1f * g;
   const float nu = b2 * v_in + 0.001f * (g * g);
   A.adam_m[i] = mu;
   A.adam_v[i] = nu;
-  const float mu_hat = mu / (1.f - powf(b1, count));
-  const float nu_hat = nu / (1.f - powf(b2, count));
+  const float mu_hat = mu / s_corr[0];   // 1 - b1^count, 1 - b2^count
+  const float nu_hat = nu / s_corr[1];
   float upd = mu_hat / (sqrtf(nu_hat) + eps);
   const float p = p_in;
   upd = upd + A.wd[grp] * p;
@@ -594,12 +593,9 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacFusedArgs F) {
     const int j = i - A.P;
     g = slab_sum(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
-    float ce = 0.f, ac = 0.f, al = 0.f;
-    for (int t = 0; t < A.n_tiles; ++t) {
-      ce += A.slab_ex[t * 4 + 0];
-      ac += A.slab_ex[t * 4 + 1];
-      al += A.slab_ex[t * 4 + 2];
-    }
+    // (all loads of the three sums in flight together: this one thread is the kernel's critical path)
+    const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
+                al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
     const float invB = 1.0f / (float)A.B;
     g = al * invB;
     A.metrics[0] = 0.5f * ce * (0.5f * invB);
