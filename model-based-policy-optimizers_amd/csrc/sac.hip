@@ -419,10 +419,10 @@ __global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   float g = 0.f;
   if (i < A.P) {
-    g = slab_sum(A.slab_pi, A.P, A.n_tiles, i);
+    g = slab_sum<16>(A.slab_pi, A.P, A.n_tiles, i);
   } else if (i < A.P + A.Q2) {
     const int j = i - A.P;
-    g = slab_sum(A.slab_q, A.Q2, A.n_tiles, j);
+    g = slab_sum<16>(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
     // (all loads of the three sums in flight together: this one thread is the kernel's critical path)
     const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
@@ -451,10 +451,10 @@ __global__ void __launch_bounds__(256) k_sac_reduce_push(SacReduceArgs A, P2pDev
   const unsigned epoch = X.epoch[0];
   float g = 0.f;
   if (i < A.P) {
-    g = slab_sum(A.slab_pi, A.P, A.n_tiles, i);
+    g = slab_sum<16>(A.slab_pi, A.P, A.n_tiles, i);
   } else if (i < A.P + A.Q2) {
     const int j = i - A.P;
-    g = slab_sum(A.slab_q, A.Q2, A.n_tiles, j);
+    g = slab_sum<16>(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
     // (all loads of the three sums in flight together: this one thread is the kernel's critical path)
     const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
@@ -515,6 +515,8 @@ __global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
   const float g_in = in_ ? A.grads[i_] : 0.f, m_in = in_ ? A.adam_m[i_] : 0.f, v_in = in_ ? A.adam_v[i_] : 0.f,
               p_in = in_ ? A.params[i_] : 0.f;
   const float count_in = A.step_count[0];
+  const bool crit_ = in_ && i_ >= A.P && i_ < A.P + A.Q2;
+  const float tq_in = crit_ ? A.target_q[i_ - A.P] : 0.f;
   {
     // wave w < 3 reduces optimizer group w's sum-of-squares partials (fixed shuffle tree -> deterministic)
     const int w = tid >> 6, lane = tid & 63;
@@ -555,7 +557,7 @@ __global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
   A.params[i] = pn;
   if (grp == 1) {
     const int j = i - A.P;
-    A.target_q[j] = A.target_q[j] * A.one_minus_tau + pn * A.tau;   // sac.py:260-261 ((1 - tau) formed in double on the host)
+    A.target_q[j] = tq_in * A.one_minus_tau + pn * A.tau;           // sac.py:260-261 ((1 - tau) formed in double on the host)
   } else if (grp == 2) {
     A.metrics[3] = expf(pn);                                      // 'alpha': exp(alpha_params) (sac.py:267)
     if (A.metrics_accum) A.metrics_accum[3] += A.metrics[3];
@@ -588,10 +590,10 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacFusedArgs F) {
   const float count = F.step_count[0] + 1.0f;   // every block reads the old count before it arrives anywhere
   float g = 0.f;
   if (i < A.P) {
-    g = slab_sum(A.slab_pi, A.P, A.n_tiles, i);
+    g = slab_sum<16>(A.slab_pi, A.P, A.n_tiles, i);
   } else if (i < A.P + A.Q2) {
     const int j = i - A.P;
-    g = slab_sum(A.slab_q, A.Q2, A.n_tiles, j);
+    g = slab_sum<16>(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
     // (all loads of the three sums in flight together: this one thread is the kernel's critical path)
     const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
