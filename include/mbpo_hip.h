@@ -410,6 +410,10 @@ int mbpo_p2p_all_reduce_sum(const mbpo_p2p_desc *d, float *buf, int64_t n, void 
  * over ranks in rank order, clip-norm partials)  ->  mbpo_sac_apply (grad_scale = 1/N).  n_max >= NP. */
 int mbpo_sac_grads_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream);
 int mbpo_sac_gather_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream);
+/* The same exchange in ONE reduction launch (= mbpo_sac_grads_p2p + mbpo_sac_gather_p2p): the reduction kernel stores the rank's
+ * gradient into every region, waits inside the kernel for every rank's arrivals and leaves grads = sum over ranks and the
+ * clip-norm partials.  Then mbpo_sac_apply (grad_scale = 1/N).  Needs the reduction's workgroups (NP/256) co-resident. */
+int mbpo_sac_grads_exchange_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream);
 int mbpo_p2p_status(const mbpo_p2p_desc *d, int32_t *status_out);
 
 #ifdef __cplusplus

@@ -489,6 +489,46 @@ __global__ void __launch_bounds__(256) k_sac_gather(P2pDev X, float *grads, int 
   group_sumsq(g, i, P, Q2, NP, ss_part);
 }
 
+// multi-GPU, one launch: local slab reduction -> stores into every rank's region -> wait for every rank's arrivals -> sum of the
+// world slots in rank order -> clip-norm partials.  All workgroups of the grid (NP/256 ~ 100) are co-resident, so waiting inside
+// the producing kernel for the peers' same kernel cannot deadlock; compared with k_sac_reduce_push + k_sac_gather this removes a
+// kernel boundary from every sgd_step and leaves the xGMI store latency as the only cost of the exchange.
+__global__ void __launch_bounds__(256) k_sac_reduce_exchange(SacReduceArgs A, P2pDev X) {
+  const int NP = A.P + A.Q2 + 1;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned epoch = X.epoch[0], want = X.epoch[1];
+  float g = 0.f;
+  if (i < A.P) {
+    g = slab_sum<16>(A.slab_pi, A.P, A.n_tiles, i);
+  } else if (i < A.P + A.Q2) {
+    const int j = i - A.P;
+    g = slab_sum<16>(A.slab_q, A.Q2, A.n_tiles, j);
+  } else if (i == NP - 1) {
+    const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
+                al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
+    const float invB = 1.0f / (float)A.B;
+    g = al * invB;
+    A.metrics[0] = 0.5f * ce * (0.5f * invB);
+    A.metrics[1] = ac * invB;
+    A.metrics[2] = al * invB;
+    if (A.metrics_accum) {
+      A.metrics_accum[0] += A.metrics[0];
+      A.metrics_accum[1] += A.metrics[1];
+      A.metrics_accum[2] += A.metrics[2];
+      A.metrics_accum[4] += 1.0f;
+    }
+    A.step_count[0] = A.step_count[0] + 1.0f;
+  }
+  p2p_push(X, epoch, i, NP, g);
+  const bool ok = p2p_wait(X, want);
+  float gs = 0.f;
+  if (i < NP) {
+    gs = ok ? p2p_sum(X, epoch, i) : NAN;
+    A.grads[i] = gs;
+  }
+  group_sumsq(gs, i, A.P, A.Q2, NP, A.ss_part);
+}
+
 __global__ void __launch_bounds__(256) k_sac_sumsq(const float *grads, int P, int Q2, float *ss_part) {
   const int NP = P + Q2 + 1;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -828,7 +868,8 @@ static void sac_chain_table(const SacPlan &pl, int D, SacArgs *A) {
       }
 }
 
-static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, const mbpo_p2p_desc *xd = nullptr) {
+static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, const mbpo_p2p_desc *xd = nullptr,
+                          bool exchange_in_reduce = false) {
   SacPlan pl;
   int rc = sac_plan(d, &pl, true);
   if (rc != MBPO_OK) return rc;
@@ -887,7 +928,8 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
   R.slab_pi = A.slab_pi; R.slab_q = A.slab_q; R.slab_ex = A.slab_ex;
   R.n_tiles = pl.n_tiles; R.P = pl.P; R.Q2 = 2 * pl.Q; R.B = d->batch_size;
   R.grads = d->grads; R.metrics = d->metrics; R.metrics_accum = d->metrics_accum; R.ss_part = d->workspace + pl.off_ss; R.step_count = d->step_count;
-  if (xd) hipLaunchKernelGGL(k_sac_reduce_push, dim3(pl.n_red), dim3(256), 0, st, R, X);
+  if (xd && exchange_in_reduce) hipLaunchKernelGGL(k_sac_reduce_exchange, dim3(pl.n_red), dim3(256), 0, st, R, X);
+  else if (xd) hipLaunchKernelGGL(k_sac_reduce_push, dim3(pl.n_red), dim3(256), 0, st, R, X);
   else hipLaunchKernelGGL(k_sac_reduce, dim3(pl.n_red), dim3(256), 0, st, R);
   MBPO_CHECK_LAUNCH("sac_grads");
   return MBPO_OK;
@@ -896,6 +938,17 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
 extern "C" int mbpo_sac_grads_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream) {
   MBPO_REQUIRE(x, MBPO_ERR_ARG, "sac_grads_p2p: null exchange descriptor");
   return sac_grads_impl(d, 3, stream, x);
+}
+
+extern "C" int mbpo_sac_grads_exchange_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream) {
+  MBPO_REQUIRE(x, MBPO_ERR_ARG, "sac_grads_exchange_p2p: null exchange descriptor");
+  SacPlan pl;
+  int rc = sac_plan(d, &pl, true);
+  if (rc != MBPO_OK) return rc;
+  // every workgroup of the reduction waits inside the kernel: they must all be resident at once
+  MBPO_REQUIRE(pl.n_red <= 1024, MBPO_ERR_UNSUPPORTED, "sac_grads_exchange_p2p: %d workgroups cannot be assumed co-resident; use "
+               "mbpo_sac_grads_p2p + mbpo_sac_gather_p2p", pl.n_red);
+  return sac_grads_impl(d, 3, stream, x, true);
 }
 
 extern "C" int mbpo_sac_gather_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream) {

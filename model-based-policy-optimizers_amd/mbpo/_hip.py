@@ -235,7 +235,8 @@ def _bind_optional(lib: C.CDLL) -> None:
                            ("mbpo_p2p_all_reduce_sum", [C.POINTER(P2pDesc), vp, i64, vp]),
                            ("mbpo_p2p_status", [C.POINTER(P2pDesc), C.POINTER(C.c_int32)]),
                            ("mbpo_sac_grads_p2p", [C.POINTER(SacDesc), C.POINTER(P2pDesc), vp]),
-                           ("mbpo_sac_gather_p2p", [C.POINTER(SacDesc), C.POINTER(P2pDesc), vp])):
+                           ("mbpo_sac_gather_p2p", [C.POINTER(SacDesc), C.POINTER(P2pDesc), vp]),
+                           ("mbpo_sac_grads_exchange_p2p", [C.POINTER(SacDesc), C.POINTER(P2pDesc), vp])):
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = argtypes

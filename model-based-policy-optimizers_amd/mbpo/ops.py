@@ -6,6 +6,7 @@ Inputs must be contiguous CUDA(HIP) tensors — there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -294,6 +295,7 @@ class SacUpdater:
         self.step_count, self.grads, self.metrics, self.metrics_accum = f(1), f(self.NP), f(4), f(5)
         self.all_reduce, self.world_size = all_reduce, world_size
         self.p2p = p2p      # mbpo.parallel.P2PExchange: gradient exchange through peer memory instead of `all_reduce`
+        self.p2p_fused = os.environ.get("MBPO_P2P_FUSED", "1") != "0"   # exchange inside the reduction kernel (default) or split
         d = _hip.SacDesc()
         d.x_dim, d.u_dim = x_dim, u_dim
         d.policy_layers, d.q_layers = len(policy_dims) - 1, len(q_dims) - 1
@@ -364,8 +366,11 @@ class SacUpdater:
             check(self.lib.mbpo_sac_reduce_apply(C.byref(d), st), "mbpo_sac_reduce_apply")
             return
         if self.p2p is not None:
-            check(self.lib.mbpo_sac_grads_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_grads_p2p")
-            check(self.lib.mbpo_sac_gather_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_gather_p2p")
+            if self.p2p_fused:      # the slab reduction also exchanges: one launch less per sgd_step
+                check(self.lib.mbpo_sac_grads_exchange_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_grads_exchange_p2p")
+            else:
+                check(self.lib.mbpo_sac_grads_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_grads_p2p")
+                check(self.lib.mbpo_sac_gather_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_gather_p2p")
             check(self.lib.mbpo_sac_apply(C.byref(d), st), "mbpo_sac_apply")
             return
         check(self.lib.mbpo_sac_grads(C.byref(d), st), "mbpo_sac_grads")

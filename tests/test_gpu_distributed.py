@@ -131,7 +131,7 @@ def test_p2p_all_reduce_two_ranks_one_gpu(tmp_path):
     assert all((tmp_path / f"p2p_ok{r}").exists() for r in range(world))
 
 
-def _p2p_sac_worker(rank, world, port, tmpdir):
+def _p2p_sac_worker(rank, world, port, tmpdir, fused):
     _setup_paths()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -149,11 +149,12 @@ def _p2p_sac_worker(rank, world, port, tmpdir):
         ex = P2PExchange.create(dp, up.NP, dev)
         assert ex is not None
         up.p2p = ex
+        up.p2p_fused = fused
         ref_rccl = _updater(cfg, B, dev, all_reduce=dp.all_reduce_fn(), world_size=world)     # library-collective path (gloo here)
         ref = _updater(cfg, world * B, dev)                                                   # single process, global minibatch
         for u in (up, ref_rccl, ref):
             u.load_state(st.params.to(dev))
-        for it in range(3):       # three chained steps: both slot parities, re-armed flags
+        for it in range(4):       # chained steps: both slot parities, re-armed flags
             g = torch.Generator().manual_seed(100 + it)
             D = batch.shape[1]
             b = torch.randn(world * B, D, generator=g)
@@ -175,12 +176,15 @@ def _p2p_sac_worker(rank, world, port, tmpdir):
 
 
 @pytest.mark.timeout(180)
-def test_sac_sgd_step_over_peer_memory_two_ranks(tmp_path):
-    """mbpo_sac_grads_p2p -> mbpo_sac_gather_p2p -> mbpo_sac_apply on two ranks (half a minibatch each) equals the
-    all-reduce path bit for bit and the single-process step on the whole minibatch within fp32 rounding."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_sac_sgd_step_over_peer_memory_two_ranks(tmp_path, fused):
+    """SAC sgd_step with the gradient exchanged through peer memory on two ranks (half a minibatch each) — fused
+    (mbpo_sac_grads_exchange_p2p -> mbpo_sac_apply: the reduction kernel stores, waits and sums) and split (mbpo_sac_grads_p2p ->
+    mbpo_sac_gather_p2p -> mbpo_sac_apply) — equals the all-reduce path bit for bit and the single-process step on the whole
+    minibatch within fp32 rounding."""
     world = 2
-    port = 35500 + (os.getpid() % 2000)
-    mp.spawn(_p2p_sac_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    port = 35500 + (os.getpid() % 2000) + (7 if fused else 0)
+    mp.spawn(_p2p_sac_worker, args=(world, port, str(tmp_path), fused), nprocs=world, join=True)
     assert all((tmp_path / f"p2psac_ok{r}").exists() for r in range(world))
 
 
