@@ -210,6 +210,20 @@ def main():
     attempt(rollout_case, 4096, 4, 1, 5, 5, (256, 256), (256, 256), 20)
     attempt(rollout_case, 4096, 17, 6, 10, 5, (64, 64, 64), (64, 64, 64), 20)     # C5 shape through the rollout kernel
 
+    # ---------------------------------------------------------------- R2: vmapped ensemble forward (System.step outside the fused rollout)
+    def ens_fwd_case(N, X, U, E, hid, reps):
+        dd = [X + U, *hid, 2 * X]
+        spec = ops.MlpSpec(dd, "swish", E)
+        dp = lecun_flat(dd, g, E).to(dev)
+        xu = torch.randn(N, X + U, generator=g).to(dev)
+        t, te = both(lambda: ops.ensemble_mlp_forward(dp, spec, xu), reps)
+        out.append(mfma_entry("k_ensemble_forward", "mbpo_ensemble_mlp_forward", {"N": N, "x": X, "u": U, "E": E, "member": list(hid)}, t,
+                              N * 2 * E * mlp_macs(dd), "2*E*M FLOP per row (shared input)", {"rows_per_s": N / t}))
+        log(f"ensemble forward N={N} E={E} {hid}: {t * 1e6:.1f} us")
+
+    attempt(ens_fwd_case, 4096, 4, 1, 5, (64, 64, 64), 100)
+    attempt(ens_fwd_case, 32768, 4, 1, 5, (64, 64, 64), 50)
+
     # ---------------------------------------------------------------- S3-S8: SAC sgd_step
     def sac_case(X, U, hidden, B, reps):
         pd, qd = [X, *hidden, 2 * U], [X + U, *hidden, 1]
