@@ -12,7 +12,8 @@ dp = (torch.randn(dyn.total_params, generator=g) * 0.05).to(dev)
 rp = torch.cat([torch.zeros(X), torch.ones(X), 0.1 * torch.ones(U)]).to(dev)
 lib = _hip.load()
 stamps = torch.zeros(16, dtype=torch.int64, device=dev)
-names = ["A: inputs", "policy chain", "(stamp)", "B: sample", "model chains", "C: reward + next state", "D: bookkeeping", "row write-out"]
+names = ["A: inputs (normalise, first-layer request)", "policy chain", "B: sample action, member first-layer request", "model chains (all members, one round)",
+         "C: member mean, reward, next state", "D: episode bookkeeping, auto-reset", "row write-out"]
 acc = None
 for it in range(12):
     obs = torch.randn(N, X, generator=g).to(dev)
@@ -30,4 +31,4 @@ acc = acc.double() / 10
 t = acc[:8]
 print("one env step (cycles):", round(float(t[7] - t[0])))
 for i in range(1, 8):
-    print(f"  {names[i-1] if i != 3 else 'B0'}: {float(t[i] - t[i-1]):8.0f}")
+    print(f"  {names[i - 1]:58s} {float(t[i] - t[i - 1]):8.0f}")
