@@ -179,9 +179,11 @@ class BPTTOptimizer(BaseOptimizer):
                  sampling_buffer_size: int = 10_000_000,
                  device=None,
                  process_group=None,
+                 use_graph: bool = True,
                  *args, **kwargs):
         super().__init__(*args, **kwargs)
         _hip.load()                                   # fail loudly without the HIP library
+        self.use_graph = bool(use_graph)              # replay the train step as a hipGraph (single rank; see train())
         # data-parallel ranks: every rank runs num_samples_per_gradient_update trajectories from its own sampling
         # buffer; actor and critic gradients and the normalisers' sums are summed over the ranks (the mean through grad_scale),
         # parameters start identical (rank-0 broadcast in init) and stay identical
@@ -424,10 +426,27 @@ class BPTTOptimizer(BaseOptimizer):
         best_reward = torch.full((), -math.inf, device=self.device)
         best: Optional[BPTTState] = None
         state_key = train_key
+        # Every launch of a train step reads its Philox offset / Adam counts / buffer positions from device memory, so the step
+        # is captured once into a hipGraph (after one eager step that also sizes every workspace) and replayed: ~25 launches
+        # per step cost more host time than GPU time at the reference's sizes (n = 50, H = 20).  Library collectives are
+        # not captured (a failed capture is not recoverable); evaluation runs eagerly between replays.
+        graph = None
+        can_capture = self.use_graph and self._all_reduce is None and self.train_steps >= 3
+        n_rows = self._actor_grad.transitions.shape[0]
         for i in range(self.train_steps):
             sampling_key, state_key = K.split(state_key, 2)
             critic_training_key, state_key = K.split(state_key, 2)
-            buff = self._train_step(w, buff, seeds)
+            if can_capture and i >= 1:
+                if graph is None:
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        self._train_step(w, buff, seeds)
+                graph.replay()
+                if self.sample_simulated_transitions:
+                    buff = self.sampling_buffer.insert_mirror(buff, n_rows)
+            else:
+                buff = self._train_step(w, buff, seeds)
             if self.evaluate_agent:
                 if i % self.evaluation_frequency == 0 or i == self.train_steps - 1:
                     reward = self._evaluate(w, eval_obs)

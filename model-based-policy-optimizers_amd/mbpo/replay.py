@@ -73,7 +73,11 @@ class UniformSamplingQueue:
         if n > self.max_replay_size:
             raise ValueError(f"cannot insert {n} rows into a buffer of {self.max_replay_size}")
         ops.replay_insert(bs.data, bs.state, rows.to(self.device).contiguous())
-        # host mirror — same integer arithmetic as csrc/replay.hip:replay_plan / k_replay_advance
+        return self.insert_mirror(bs, n)
+
+    def insert_mirror(self, bs: ReplayBufferState, n: int) -> ReplayBufferState:
+        """Host mirror of one insert of n rows — same integer arithmetic as csrc/replay.hip:replay_plan / k_replay_advance
+        (also used alone when the insert itself ran inside a replayed hipGraph)."""
         mx = self.max_replay_size
         roll = min(0, mx - bs.insert_position - n)
         pos = bs.insert_position + roll
