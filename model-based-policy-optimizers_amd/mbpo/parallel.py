@@ -181,7 +181,31 @@ class P2PExchange:
             self.all_reduce_sum(x)
             torch.cuda.synchronize()
             ok = ok and self.status() == 0 and bool(torch.isfinite(x).all()) and torch.allclose(x, ref, rtol=1e-5, atol=1e-5)
-        return ok
+        if not ok:
+            return False
+        # a mapping that works but is pathologically slow (e.g. peer stores routed over PCIe) must not replace the library
+        # collective: time both on a gradient-sized vector; every rank runs the same loops (the exchange is a collective)
+        n = self.n_max
+        x = torch.zeros(n, device=self.device)
+        y = torch.zeros(n, device=self.device)
+        reps = 10
+
+        def timed(fn):
+            fn()
+            dist.barrier(group=self.dp.group)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        t_p2p = timed(lambda: self.all_reduce_sum(x))
+        t_lib = timed(lambda: dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.dp.group))
+        self.timing_ms = (t_p2p, t_lib)
+        return self.status() == 0 and t_p2p <= 4.0 * t_lib + 0.05
 
     def close(self):
         for p in self.peers.values():
