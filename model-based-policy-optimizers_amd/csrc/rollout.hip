@@ -510,6 +510,13 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
   float *s_scr = s_rew + 16;                     // [16 * max(X, U)] scratch: next state / per-dim log-prob
   const int SC = X > U ? X : U;
   (void)SC;
+  // reward parameters staged once: section C read them from global memory inside a runtime-trip loop (one exposed scalar
+  // load per term: ~1.5 k of that section's 3.6 k cycles)
+  float *s_rp = s_scr + ((16 * (X + U) + 16 + 3) & ~3);   // [2X+U] quadratic (target, q, r) or [3] pendulum
+  {
+    const int n_rp = (A.reward_kind == MBPO_REWARD_PENDULUM) ? 3 : 2 * X + U;
+    for (int idx = tid_; idx < n_rp; idx += nthreads) s_rp[idx] = A.reward_params[idx];
+  }
 
   const unsigned long long rng_off = A.offset + (A.offset_dev ? (unsigned long long)A.offset_dev[0] : 0ull);
   const long long n_tiles = (N + 15) >> 4;
@@ -634,9 +641,9 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
           const float *xr = s_xu + r * ld_xu;
           float rew;
           if (A.reward_kind == MBPO_REWARD_PENDULUM) {
-            rew = pendulum_reward(xr, xr[X], A.reward_params);
+            rew = pendulum_reward(xr, xr[X], s_rp);
           } else {
-            const float *tp = A.reward_params, *qp = tp + X, *rp = qp + X;
+            const float *tp = s_rp, *qp = tp + X, *rp = qp + X;
             float cx = 0.f, cu = 0.f;
             for (int c = 0; c < X; ++c) { float dd = xr[c] - tp[c]; cx += qp[c] * (dd * dd); }
             for (int d = 0; d < U; ++d) { float uu = xr[X + d]; cu += rp[d] * (uu * uu); }
@@ -837,7 +844,7 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   A.ld_y = up4(ymax) + 4;
   const int scr = 16 * (X + U) + 16;
   const size_t fixed_f = 3ull * 16 * A.ld_x + 16ull * A.ld_xu + (size_t)A.n_out * 16 * A.ld_y + 2ull * 16 * up4(d->row_len) + 80 +
-                         (size_t)up4(scr);
+                         (size_t)up4(scr) + (size_t)up4(2 * X + U + 4);   // + staged reward parameters (k_model_rollout64)
   A.n_chains = pick_chains(E, fixed_f, A.ld_h);
   MBPO_REQUIRE(A.n_chains >= 1, MBPO_ERR_UNSUPPORTED, "model_rollout: shapes do not fit 160 KiB of LDS");
   size_t lds = (fixed_f + 2ull * A.n_chains * 16 * A.ld_h) * sizeof(float);
