@@ -201,19 +201,19 @@ def main():
         trainer = build_trainer(device, pg, use_graph=not args.no_graph)
         from mbpo.utils import keys as K
         ts = trainer.init_training_state(7)
-        env_state = trainer.reset_envs(trainer.env, 11 + rank, N_ENVS)
-        buffer_state = trainer.replay_buffer.init(13 + rank)
-        ts, env_state, buffer_state, _ = trainer.prefill_replay_buffer(ts, env_state, buffer_state, 17 + rank)
+        rk = trainer.dp.rank_key       # per-rank data keys, as SAC.run_training derives them
+        env_state = trainer.reset_envs(trainer.env, rk(11), N_ENVS)
+        buffer_state = trainer.replay_buffer.init(rk(13))
+        ts, env_state, buffer_state, _ = trainer.prefill_replay_buffer(ts, env_state, buffer_state, rk(17))
         torch.cuda.synchronize()
         log("prefill done")
 
         use_graph = trainer.use_graph
-        key = 23 + rank
+        trainer.rekey(rk(23))      # seed word of the device RNG control; the step index counts on the device from here on
 
         def one_step():
-            nonlocal ts, env_state, buffer_state, key
-            key, k = K.split(key)
-            ts, env_state, buffer_state = trainer.training_step(ts, env_state, buffer_state, k)
+            nonlocal ts, env_state, buffer_state
+            ts, env_state, buffer_state = trainer.training_step(ts, env_state, buffer_state)
 
         graph = None
         # warm-up: W eager steps (also compiles/loads every kernel), then capture
@@ -221,19 +221,17 @@ def main():
             one_step()
         torch.cuda.synchronize()
         log(f"{max(args.warmup, 1)} eager warm-up steps done")
-        # Collectives inside the captured step: only the peer-memory exchange (plain kernels) is captured.  A capture that a
-        # library collective invalidates cannot be recovered from in-process (torch's allocator and stream state stay in
-        # capture mode; measured here: the next launches fail or the process segfaults), so with torch.distributed
-        # all_reduce in the step the launches are issued eagerly — at ~35 us of GPU work per sgd_step plus the collective
-        # the host keeps ahead of the GPU anyway.  MBPO_BENCH_CAPTURE_COLLECTIVES=1 forces the capture (fatal if it fails).
-        if (use_graph and pg is not None and getattr(trainer, "p2p", None) is None
-                and os.environ.get("MBPO_BENCH_CAPTURE_COLLECTIVES") != "1"):
-            log("gradient exchange is torch.distributed all_reduce: issuing the step eagerly (no hipGraph)")
+        # Collectives inside the captured step: the peer-memory exchange (plain kernels) and RCCL collectives (stream-ordered
+        # kernels) are captured; a host-side collective (gloo) is NEVER put inside a capture — it invalidates the capture and
+        # the process cannot recover from that (round 1: hipErrorStreamCaptureInvalidated, then SIGSEGV in the same process;
+        # DESIGN §6) — such a step is issued eagerly.  The decision is the trainer's (SAC._capturable).
+        if use_graph and not trainer._capturable():
+            log("gradient exchange is a host-side collective: issuing the step eagerly (no hipGraph)")
             use_graph = False
         if use_graph:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                trainer.training_step(ts, env_state, buffer_state, 29)
+                trainer.training_step(ts, env_state, buffer_state)
             log("graph captured")
             graph.replay()   # one untimed replay
             torch.cuda.synchronize()
@@ -313,7 +311,13 @@ def main():
                        "hipgraph": graph is not None, "parallelism": f"dp{world} (envs+minibatch sharded, flat grad all-reduce per sgd_step)",
                        "grad_exchange": ("none" if world == 1 and pg is None else
                                          "peer-memory one-shot (xGMI stores, csrc/p2p.hpp)" if getattr(trainer, "p2p", None) is not None
-                                         else "torch.distributed all_reduce")},
+                                         else "torch.distributed all_reduce"),
+                       # diagnostics for the multi-GPU run: what the start-up check measured and what the process group is
+                       "p2p_timing_ms": (dict(zip(("p2p", "library"), trainer.p2p.timing_ms))
+                                         if getattr(trainer, "p2p", None) is not None and hasattr(trainer.p2p, "timing_ms") else None),
+                       "p2p_fused_exchange": bool(getattr(trainer.updater, "p2p_fused", False)) if getattr(trainer, "p2p", None) is not None else None,
+                       "pg_backend": (None if pg is None else __import__("torch.distributed").distributed.get_backend(pg)),
+                       "pg_world_size": (None if pg is None else __import__("torch.distributed").distributed.get_world_size(pg))},
             "sac_updates_per_s": GRAD_UPDATES * args.steps / dt,
             "sac_update_samples_per_s": world * BATCH * GRAD_UPDATES * args.steps / dt,
             "params_finite": finite,

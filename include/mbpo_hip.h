@@ -52,6 +52,18 @@ typedef struct mbpo_mlp_desc {
 int mbpo_version(void);
 const char *mbpo_last_error(void);
 
+/* ---- randomness ---------------------------------------------------------------------------------
+ * The reference threads jax.random keys through every call and splits them (sac/sac.py:289,309-311; ppo/ppo.py:190-193).
+ * JAX's threefry streams cannot be reproduced without JAX, so every drawing entry point here is keyed by
+ * (seed, offset, stream id, element index) -> Philox4x32-10 (csrc/common.hpp; stream ids are fixed per consumer).
+ * `rng_dev` (optional, device uint64[2] = {seed word, step counter}) is ADDED to the host-side (seed, offset):
+ *   seed_eff = seed + rng_dev[0],   offset_eff = offset + rng_dev[1].
+ * A training step captured into a hipGraph bakes its host-side seed/offset constants; everything that changes from step
+ * to step lives in the two device words, so a replayed graph draws bit for bit what the eagerly issued step draws.
+ * Convention used by the trainers: offset = (call-site id << 32), rng_dev = {epoch key, training-step index}.
+ * mbpo_rng_advance: rng_dev[1] += inc (one tiny launch, graph-capturable). */
+int mbpo_rng_advance(uint64_t *rng_dev, uint64_t inc, void *stream);
+
 /* ---- R2: ensemble MLP forward -------------------------------------------------------------
  * replaces: the (new) learned Dynamics.next_state evaluated under vmap —
  *           mbpo/systems/dynamics/base_dynamics.py:15-20 called from
@@ -109,8 +121,7 @@ typedef struct mbpo_rollout_desc {
   const float *model_noise;    /* [S, action_repeat, N, x_dim] standard normal */
   const int32_t *member_idx;   /* [S, action_repeat, N] in [0, E) for MBPO_ENS_TS1 */
   uint64_t seed, offset;
-  const float *offset_dev;     /* optional device scalar added to `offset` at run time (e.g. the optimizer step count):
-                                  lets a captured hipGraph draw fresh numbers on every replay */
+  const uint64_t *rng_dev;     /* optional device uint64[2] {seed word, step counter} added to (seed, offset): see "randomness" */
   /* env state, updated in place (brax State.obs / info['steps'] / done / info['first_obs']) */
   float *obs;             /* [N, x_dim] */
   const float *first_obs; /* [N, x_dim] */
@@ -123,6 +134,45 @@ typedef struct mbpo_rollout_desc {
 } mbpo_rollout_desc;
 
 int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream);
+
+/* ---- R1/R4-R7 for a USER-DEFINED System: the non-fused env step ------------------------------------
+ * replaces: the same reference lines as mbpo_model_rollout, split at the reference's own plug-in seam — System.step
+ *           (systems/base_systems.py:40-52 -> Dynamics.next_state, dynamics/base_dynamics.py:15-20 / Reward.__call__,
+ *           rewards/base_rewards.py:15-21) stays the caller's code (a batched torch function on the device); per env step the
+ *           host issues  mbpo_policy_act -> System.step (x action_repeat) -> mbpo_episode_step.
+ * mbpo_policy_act   : make_inference_fn (sac_networks.py:58-73 / ppo_network.py:59-84): logits = MLP(normalize(obs)),
+ *                     NormalTanh sample / mode (sac/parametric_distribution.py:66-124); raw_action [n,u] and log_prob [n] are
+ *                     optional (PPO's policy extras).  Noise: explicit [n,u] or Philox(seed, offset [+ rng_dev], stream 1,
+ *                     element elem_base + i*u + d) — with elem_base = s*N*u this IS the fused kernel's stream at step s.
+ *                     workspace: n * (x_dim + 2*u_dim) floats.
+ * mbpo_episode_step : EpisodeWrapper.step + AutoResetWrapper.step bookkeeping (brax_utils/training.py:91-137) and the
+ *                     Transition row of actor_step (sac/acting.py:46-55) for step `step_index` of an unroll of `n_steps`;
+ *                     `reward` is already summed over action_repeat, `sys_done` (optional) is SystemState.done.
+ *                     Updates obs/steps/done in place, exactly like mbpo_model_rollout. */
+int mbpo_policy_act(const mbpo_mlp_desc *policy, const float *obs, int64_t n, const float *norm_mean, const float *norm_std,
+                    int32_t deterministic, float action_clip, const float *noise, uint64_t seed, uint64_t offset,
+                    const uint64_t *rng_dev, uint64_t elem_base, float *action, float *raw_action, float *log_prob,
+                    float *workspace, void *stream);
+
+typedef struct mbpo_episode_step_desc {
+  int32_t x_dim, u_dim;
+  int64_t n_envs;
+  int32_t episode_length, action_repeat;
+  int32_t ppo_extras, env_major;   /* as in mbpo_rollout_desc */
+  int32_t step_index, n_steps;     /* s and S: the row is s*N + i (or i*S + s with env_major) */
+  const float *action;             /* [N, u] */
+  const float *raw_action;         /* [N, u] (ppo_extras) */
+  const float *log_prob;           /* [N]    (ppo_extras) */
+  const float *reward;             /* [N] */
+  const float *x_next;             /* [N, x] */
+  const float *sys_done;           /* [N] or NULL (= 0) */
+  const float *first_obs;          /* [N, x] */
+  float *obs, *steps, *done;       /* env state, updated in place */
+  float *transitions;              /* [S*N, row_len] */
+  int32_t row_len;
+} mbpo_episode_step_desc;
+
+int mbpo_episode_step(const mbpo_episode_step_desc *d, void *stream);
 
 /* ---- R9: replay buffer (brax UniformSamplingQueue semantics, INT32-exact) --------------------
  * replaces: replay_buffer.insert / .sample as called at sac/sac.py:303,318 and systems/brax_wrapper.py:29,
@@ -138,10 +188,16 @@ int mbpo_replay_insert(float *data, int64_t max_size, int32_t row_len, int32_t *
 int mbpo_replay_gather(const float *data, int64_t max_size, int32_t row_len, const int32_t *state, const int32_t *idx,
                        int64_t n, float *out, void *stream);
 /* idx[j] = randint(sample_position, insert_position) from Philox(seed, offset, stream=REPLAY, j), then gather.
- * idx_out may be NULL; offset_dev (optional device scalar) is added to offset at run time.
+ * idx_out may be NULL; rng_dev (optional device uint64[2], see "randomness") is added to (seed, offset) at run time.
  * Fused sample+gather: sac/sac.py:318 (UniformSamplingQueue.sample). */
 int mbpo_replay_sample(const float *data, int64_t max_size, int32_t row_len, const int32_t *state, uint64_t seed,
-                       uint64_t offset, const float *offset_dev, int64_t n, int32_t *idx_out, float *out, void *stream);
+                       uint64_t offset, const uint64_t *rng_dev, int64_t n, int32_t *idx_out, float *out, void *stream);
+
+/* perm = stable argsort of key_i = Philox(seed, offset [+ rng_dev], stream PERM, i).word0, i in [0, n): the ONE shared
+ * permutation of PPO.sgd_step (ppo/ppo.py:166-171: jr.permutation with the same key for every leaf); gather whole
+ * trajectories with mbpo_replay_gather(idx = perm).  workspace: n uint32.  n <= 2^20. */
+int mbpo_philox_permutation(uint64_t seed, uint64_t offset, const uint64_t *rng_dev, int64_t n, int32_t *perm,
+                            uint32_t *workspace, void *stream);
 
 /* ---- R8: running_statistics.update ([3P] brax.training.acme.running_statistics; call sites
  * sac/sac.py:298-301, ppo/ppo.py:216-219), in the reference's own two-pass form, split so that a multi-GPU
@@ -186,7 +242,9 @@ int mbpo_gae_scan_discounts(const float *truncation, const float *termination, c
  *
  * Flat train state (device, fp32), NP = P + 2*Q + 1 with P = policy params, Q = params of one critic:
  *   params   [NP] = [ policy | critic 0 | critic 1 | log_alpha ]
- *   target_q [2Q];  adam_m [NP];  adam_v [NP];  step_count [1] (optimizer step count, as float)
+ *   target_q [2Q];  adam_m [NP];  adam_v [NP];  step_count [1] (optax's count, kept as a float: it only feeds Adam's bias
+ *                   corrections 1 - b^count, which are exactly 1.0f long before a float stops counting at 2^24; it plays NO part
+ *                   in the random streams)
  *   grads    [NP]   written by mbpo_sac_grads, read by mbpo_sac_apply (all-reduce it in between for N>1 ranks —
  *                   the live form of the reference's dead jax.lax.pmean, sac/utils.py:29-33)
  * Three entry points so that the multi-GPU exchange sits at the reference's pmean position:
@@ -196,7 +254,8 @@ int mbpo_gae_scan_discounts(const float *truncation, const float *termination, c
  *   mbpo_sac_grad_norms : recompute those partials from `grads` (call after an all-reduce changed it).
  *   mbpo_sac_apply      : grads *= grad_scale; clip_by_global_norm per optimizer; AdamW; target <- (1-tau) target + tau q_new;
  *                         metrics[3] = exp(new log_alpha).
- * Noise: explicit standard-normal tensors [B,u] or NULL -> Philox(seed, offset + step_count), streams 5/6/7.
+ * Noise: explicit standard-normal tensors [B,u] or NULL -> Philox(seed, offset [+ rng_dev]), streams 5/6/7: the caller
+ *        advances `offset` (or the device counter) between sgd_steps.
  */
 typedef struct mbpo_sac_desc {
   int32_t x_dim, u_dim;
@@ -215,6 +274,7 @@ typedef struct mbpo_sac_desc {
   const float *norm_mean, *norm_std;         /* [x_dim] or NULL */
   const float *noise_alpha, *noise_critic, *noise_actor; /* [batch_size, u_dim] or NULL */
   uint64_t seed, offset;
+  const uint64_t *rng_dev;                   /* optional device uint64[2], see "randomness" */
   float discounting, reward_scaling, target_entropy, tau;
   float lr_policy, lr_q, lr_alpha, wd_policy, wd_q, wd_alpha, max_grad_norm;
   float grad_scale;                          /* 1/world_size when grads were all-reduced with SUM, else 1 */
@@ -247,7 +307,7 @@ int mbpo_sac_reduce_apply(const mbpo_sac_desc *d, void *stream);
  *   mbpo_ppo_grads : grads, metrics[0..3] = total_loss, policy_loss, v_loss, entropy_loss (losses.py:121-126); bumps step_count
  *   mbpo_ppo_apply : grads *= grad_scale; AdamW.   All-reduce `grads` in between for N>1 ranks (ppo.py:149-154's pmean).
  * data: one minibatch [batch_size, unroll_length, row_len] of PPO rows (row_len = 2x+2u+4), i.e. the rollout kernel's
- *       env_major output after the permutation gather.  entropy_noise [B,T,u] or NULL -> Philox(seed, offset+step_count, stream 9).
+ *       env_major output after the permutation gather.  entropy_noise [B,T,u] or NULL -> Philox(seed, offset [+ rng_dev], stream 9).
  */
 typedef struct mbpo_ppo_desc {
   int32_t x_dim, u_dim;
@@ -265,6 +325,7 @@ typedef struct mbpo_ppo_desc {
   const float *norm_mean, *norm_std;         /* [x_dim] or NULL */
   const float *entropy_noise;                /* [B,T,u] or NULL */
   uint64_t seed, offset;
+  const uint64_t *rng_dev;                   /* optional device uint64[2], see "randomness" */
   float entropy_cost, discounting, reward_scaling, gae_lambda, clipping_epsilon;
   int32_t normalize_advantage;
   float lr, wd, grad_scale;
@@ -305,9 +366,9 @@ typedef struct mbpo_bptt_desc {
   const float *reward_mean_std;              /* [2] reward normaliser {mean, std} */
   const float *init_states;                  /* [n, x_dim] */
   int64_t n;
-  const float *act_noise;                    /* [n, horizon, u_dim] or NULL -> Philox(seed, offset(+offset_dev), stream 1) */
+  const float *act_noise;                    /* [n, horizon, u_dim] or NULL -> Philox(seed, offset [+ rng_dev], stream 1) */
   uint64_t seed, offset;
-  const float *offset_dev;
+  const uint64_t *rng_dev;                   /* optional device uint64[2], see "randomness" */
   float discount, lambda_, ent_coef;
   float *transitions, *lambda_values, *grads, *metrics;
   float *workspace;                          /* >= mbpo_bptt_workspace_floats() floats */
@@ -375,7 +436,7 @@ int mbpo_ens_nll_grads(const mbpo_ens_train_desc *d, void *stream);
  *   go to prev_elites (:227).  workspace: n_candidates int32.  State vectors are [horizon*u_dim] device floats. */
 int mbpo_icem_sample(const float *mean, const float *std, const float *prev_elites, const float *u_min, const float *u_max,
                      int32_t n_samples, int32_t n_prev, int32_t horizon, int32_t u_dim, int32_t n_particles, float exponent,
-                     uint64_t seed, uint64_t offset, const float *offset_dev, float *actions, float *candidates, void *stream);
+                     uint64_t seed, uint64_t offset, const uint64_t *rng_dev, float *actions, float *candidates, void *stream);
 int mbpo_icem_update(const float *rows, int32_t row_len, int32_t reward_col, int32_t n_candidates, int32_t n_particles,
                      int32_t horizon, int32_t u_dim, const float *candidates, int32_t n_elites, int32_t n_prev, float alpha,
                      int32_t use_max, float *mean, float *std, float *best_value, float *best_sequence, float *prev_elites,

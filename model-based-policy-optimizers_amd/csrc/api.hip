@@ -43,3 +43,15 @@ int mbpo_make_mlp_dev(const mbpo_mlp_desc *d, MlpDev *out, const char *name) {
   out->n_params = off;
   return MBPO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- device RNG control words
+__global__ void k_rng_advance(unsigned long long *rng, unsigned long long inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += inc;
+}
+
+extern "C" int mbpo_rng_advance(uint64_t *rng_dev, uint64_t inc, void *stream) {
+  MBPO_REQUIRE(rng_dev, MBPO_ERR_ARG, "rng_advance: null rng_dev");
+  hipLaunchKernelGGL(k_rng_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long *)rng_dev, (unsigned long long)inc);
+  MBPO_CHECK_LAUNCH("rng_advance");
+  return MBPO_OK;
+}

@@ -27,7 +27,7 @@ struct BpttArgs {
   const float *reward_params, *sys_params, *s_mean, *s_std, *r_ms;
   const float *init_states, *act_noise;
   unsigned long long seed, offset;
-  const float *offset_dev;
+  const unsigned long long *rng_dev;
   float c0, discount, lambda_, ent_coef;
   float *transitions, *lambda_values;
   float *w_xs, *w_as, *w_eps, *w_rs, *w_vs, *w_km;
@@ -162,7 +162,8 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
   const float r_mean = A.r_ms[0], r_std = A.r_ms[1];
   const float invNH = 1.0f / ((float)A.n * (float)HZ);
   const float w_lp = -A.ent_coef * invNH;      // dL/d log_prob_t   (entropy_loss = -mean_t lp, weight ent_coef)
-  const unsigned long long rng_off = A.offset + (A.offset_dev ? (unsigned long long)A.offset_dev[0] : 0ull);
+  const RngKey rk_ = rng_resolve(A.seed, A.offset, A.rng_dev);
+  const unsigned long long rng_off = rk_.offset, rng_seed = rk_.seed;
   const int PL = A.pi.n_layers, CL = A.cr.n_layers, DL = A.dyn.n_layers;
   const float *cr1 = A.cr.params, *cr2 = A.cr.params + A.cr.net_stride;
   const int chain2 = wave >> 1, sub2 = wave & 1;   // SP = 2 grouping
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
             float eps = 0.f;
             if (i < A.n) {
               const long long nidx = (i * HZ + t) * U + d;
-              eps = A.act_noise ? A.act_noise[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
+              eps = A.act_noise ? A.act_noise[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
               A.w_eps[nidx] = eps;
             }
             const float a = fminf(fmaxf(tanhf(mu + eps * sg), -0.999f), 0.999f);   // squash_action (:313-317)
@@ -701,7 +702,7 @@ extern "C" int mbpo_bptt_actor_grads(const mbpo_bptt_desc *d, void *stream) {
   A.system_kind = d->system_kind; A.predict_delta = d->ens_predict_delta; A.reward_kind = d->reward_kind;
   A.reward_params = d->reward_params; A.sys_params = d->sys_params; A.s_mean = d->state_mean; A.s_std = d->state_std;
   A.r_ms = d->reward_mean_std; A.init_states = d->init_states; A.act_noise = d->act_noise;
-  A.seed = d->seed; A.offset = d->offset; A.offset_dev = d->offset_dev;
+  A.seed = d->seed; A.offset = d->offset; A.rng_dev = (const unsigned long long *)d->rng_dev;
   const double s0 = (double)d->init_stddev;
   A.c0 = (float)(s0 < 20.0 ? log(exp(s0) - 1.0) : s0);            // inv_softplus (:107-108)
   A.discount = d->discount; A.lambda_ = d->lambda_; A.ent_coef = d->ent_coef;

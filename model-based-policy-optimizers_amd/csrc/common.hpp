@@ -174,6 +174,20 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
 #define MBPO_STREAM_ENTROPY 9u
 #define MBPO_STREAM_ICEM 10u
 
+// Device-resident RNG control (optional on every Philox-drawing entry point): rng_dev = uint64[2] {seed word, step counter}.
+// The effective key is (seed + rng_dev[0], offset + rng_dev[1]): a captured hipGraph whose host-side seed/offset are baked
+// constants draws exactly what the eager path draws, because everything that changes between steps lives in these two
+// device words (mbpo_rng_advance bumps the counter).  Integer arithmetic only: no 2^24 float-counter saturation.
+struct RngKey {
+  unsigned long long seed, offset;
+};
+__device__ __forceinline__ RngKey rng_resolve(unsigned long long seed, unsigned long long offset, const unsigned long long *rng_dev) {
+  RngKey k;
+  k.seed = seed + (rng_dev ? rng_dev[0] : 0ull);
+  k.offset = offset + (rng_dev ? rng_dev[1] : 0ull);
+  return k;
+}
+
 // standard normal for element `idx` of stream `stream` at call counter `offset` under `seed`
 // (Box-Muller on two of the four Philox words; one Philox call per element keeps draws order-independent).
 __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx) {

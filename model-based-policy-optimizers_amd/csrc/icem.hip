@@ -16,7 +16,7 @@ struct IcemSampleArgs {
   int S, Kp, H, U, P;
   float exponent;
   unsigned long long seed, offset;
-  const float *offset_dev;
+  const unsigned long long *rng_dev;
   float *actions;      // [H][(S+Kp)*P][U]
   float *candidates;   // [S+Kp][H][U]
 };
@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(256) k_icem_sample(IcemSampleArgs A) {
     wsum += w * w;
   }
   const float sigma = 2.0f * sqrtf(wsum) / (float)H;
-  const unsigned long long off = A.offset + (A.offset_dev ? (unsigned long long)A.offset_dev[0] : 0ull);
+  const RngKey rk_ = rng_resolve(A.seed, A.offset, A.rng_dev);
+  const unsigned long long off = rk_.offset, rng_seed = rk_.seed;
   const int NC = A.S + A.Kp, N = NC * A.P;
   for (int sd = blockIdx.x * blockDim.x + threadIdx.x; sd < NC * U; sd += gridDim.x * blockDim.x) {
     const int c = sd / U, d = sd - c * U;
@@ -60,8 +61,8 @@ __global__ void __launch_bounds__(256) k_icem_sample(IcemSampleArgs A) {
     float sr[65], si[65];
     for (int k = 0; k < K; ++k) {
       const unsigned long long base = ((unsigned long long)sd * K + k) * 2ull;
-      sr[k] = philox_normal(A.seed, off, MBPO_STREAM_ICEM, base) * s_scale[k];
-      si[k] = philox_normal(A.seed, off, MBPO_STREAM_ICEM, base + 1ull) * s_scale[k];
+      sr[k] = philox_normal(rng_seed, off, MBPO_STREAM_ICEM, base) * s_scale[k];
+      si[k] = philox_normal(rng_seed, off, MBPO_STREAM_ICEM, base + 1ull) * s_scale[k];
     }
     if (!(H % 2)) {        // even length: the Nyquist coefficient is real (:193-197)
       si[K - 1] = 0.f;
@@ -86,12 +87,12 @@ __global__ void __launch_bounds__(256) k_icem_sample(IcemSampleArgs A) {
 
 extern "C" int mbpo_icem_sample(const float *mean, const float *std, const float *prev_elites, const float *u_min, const float *u_max,
                                 int32_t n_samples, int32_t n_prev, int32_t horizon, int32_t u_dim, int32_t n_particles, float exponent,
-                                uint64_t seed, uint64_t offset, const float *offset_dev, float *actions, float *candidates, void *stream) {
+                                uint64_t seed, uint64_t offset, const uint64_t *rng_dev, float *actions, float *candidates, void *stream) {
   MBPO_REQUIRE(mean && std && u_min && u_max && actions && candidates, MBPO_ERR_ARG, "icem_sample: null pointer");
   MBPO_REQUIRE(n_samples > 0 && n_prev >= 0 && u_dim > 0 && n_particles > 0, MBPO_ERR_ARG, "icem_sample: bad sizes");
   MBPO_REQUIRE(horizon >= 2 && horizon <= 128, MBPO_ERR_UNSUPPORTED, "icem_sample: horizon must be in [2, 128]");
   MBPO_REQUIRE(n_prev == 0 || prev_elites, MBPO_ERR_ARG, "icem_sample: prev_elites is NULL");
-  IcemSampleArgs A{mean, std, prev_elites, u_min, u_max, n_samples, n_prev, horizon, u_dim, n_particles, exponent, seed, offset, offset_dev,
+  IcemSampleArgs A{mean, std, prev_elites, u_min, u_max, n_samples, n_prev, horizon, u_dim, n_particles, exponent, seed, offset, (const unsigned long long *)rng_dev,
                    actions, candidates};
   const int K = horizon / 2 + 1;
   const size_t lds = sizeof(float) * (2ull * horizon * K + K);

@@ -23,7 +23,7 @@ struct PpoArgs {
   int X, U, B, T, D;
   const float *data, *norm_mean, *norm_std, *ent_noise;
   unsigned long long seed, offset;
-  const float *step_count;
+  const unsigned long long *rng_dev;
   float entropy_cost, discounting, reward_scaling, gae_lambda, clip_eps;
   int normalize_advantage;
   // workspace pieces
@@ -180,7 +180,8 @@ __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
   const float invM = 1.0f / (float)M;
   const float adv_mean = A.normalize_advantage ? A.mom[0] : 0.f;
   const float adv_istd = A.normalize_advantage ? 1.0f / (A.mom[1] + 1e-8f) : 1.f;          // losses.py:101-102
-  const unsigned long long rng_off = A.offset + (unsigned long long)A.step_count[0];
+  const RngKey rk_ = rng_resolve(A.seed, A.offset, A.rng_dev);
+  const unsigned long long rng_off = rk_.offset, rng_seed = rk_.seed;
   float *slab = A.slabs + (long long)blockIdx.x * (A.pi.n_params + A.v.n_params);
   float *slab_pi = slab, *slab_v = slab + A.pi.n_params;
   float loss_pol = 0.f, loss_v = 0.f, loss_ent = 0.f;     // thread 0..15 partials, reduced at the end
@@ -235,7 +236,7 @@ __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
         float eps = 0.f;
         if (ok) {
           const long long nidx = i * U + d;
-          eps = A.ent_noise ? A.ent_noise[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_ENTROPY, (unsigned long long)nidx);
+          eps = A.ent_noise ? A.ent_noise[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_ENTROPY, (unsigned long long)nidx);
         }
         const float zf = loc + sg * eps;
         ent += 0.5f + LOG_SQRT_2PI + logf(sg) + 2.0f * (LOG_2 - zf - softplus_f(-2.0f * zf));           // entropy (:117)
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
         float eps = 0.f;
         if (ok) {
           const long long nidx = i * U + d;
-          eps = A.ent_noise ? A.ent_noise[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_ENTROPY, (unsigned long long)nidx);
+          eps = A.ent_noise ? A.ent_noise[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_ENTROPY, (unsigned long long)nidx);
         }
         const float th = tanhf(loc + sg * eps);
         // lp_t: d/dloc = q/sg, d/dsigma = (q*q - 1)/sg ; entropy: d/dloc = -2 tanh(zf), d/dsigma = 1/sg - 2 tanh(zf) eps
@@ -464,7 +465,7 @@ extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
   A.sh_v = NetShape{pl.v.dims[0], pl.v.n_layers, pl.v.dims[pl.v.n_layers], pl.v.act};
   A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.T = d->unroll_length; A.D = d->row_len;
   A.data = d->data; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std; A.ent_noise = d->entropy_noise;
-  A.seed = d->seed; A.offset = d->offset; A.step_count = d->step_count;
+  A.seed = d->seed; A.offset = d->offset; A.rng_dev = (const unsigned long long *)d->rng_dev;
   A.entropy_cost = d->entropy_cost; A.discounting = d->discounting; A.reward_scaling = d->reward_scaling;
   A.gae_lambda = d->gae_lambda; A.clip_eps = d->clipping_epsilon; A.normalize_advantage = d->normalize_advantage;
   A.baseline = ws + pl.off_baseline; A.boot = ws + pl.off_boot; A.trunc = ws + pl.off_trunc; A.term = ws + pl.off_term;

@@ -71,8 +71,12 @@ extern "C" int mbpo_replay_insert(float *data, int64_t max_size, int32_t row_len
 template <bool SAMPLE>
 __global__ void __launch_bounds__(256) k_replay_gather(const float *data, long long max_size, int D, const int *state,
                                                         const int *idx, unsigned long long seed, unsigned long long offset,
-                                                        const float *offset_dev, long long n, int *idx_out, float *out) {
-  if (SAMPLE && offset_dev) offset += (unsigned long long)offset_dev[0];
+                                                        const unsigned long long *rng_dev, long long n, int *idx_out, float *out) {
+  if (SAMPLE) {
+    const RngKey rk = rng_resolve(seed, offset, rng_dev);
+    seed = rk.seed;
+    offset = rk.offset;
+  }
   const int head = state[2];
   const int lo = state[1], hi = state[0];
   const long long total = n * D;
@@ -104,13 +108,13 @@ extern "C" int mbpo_replay_gather(const float *data, int64_t max_size, int32_t r
   long long total = n * row_len;
   int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(k_replay_gather<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, (long long)max_size, row_len,
-                     state, idx, 0ull, 0ull, (const float *)nullptr, (long long)n, (int *)nullptr, out);
+                     state, idx, 0ull, 0ull, (const unsigned long long *)nullptr, (long long)n, (int *)nullptr, out);
   MBPO_CHECK_LAUNCH("replay_gather");
   return MBPO_OK;
 }
 
 extern "C" int mbpo_replay_sample(const float *data, int64_t max_size, int32_t row_len, const int32_t *state, uint64_t seed,
-                                  uint64_t offset, const float *offset_dev, int64_t n, int32_t *idx_out, float *out,
+                                  uint64_t offset, const uint64_t *rng_dev, int64_t n, int32_t *idx_out, float *out,
                                   void *stream) {
   MBPO_REQUIRE(data && state, MBPO_ERR_ARG, "replay_sample: null pointer");
   MBPO_REQUIRE(max_size > 0 && row_len > 0 && n >= 0, MBPO_ERR_ARG, "replay_sample: bad sizes");
@@ -119,7 +123,7 @@ extern "C" int mbpo_replay_sample(const float *data, int64_t max_size, int32_t r
   long long total = n * row_len;
   int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(k_replay_gather<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, (long long)max_size, row_len,
-                     state, (const int *)nullptr, (unsigned long long)seed, (unsigned long long)offset, offset_dev, (long long)n, idx_out, out);
+                     state, (const int *)nullptr, (unsigned long long)seed, (unsigned long long)offset, (const unsigned long long *)rng_dev, (long long)n, idx_out, out);
   MBPO_CHECK_LAUNCH("replay_sample");
   return MBPO_OK;
 }
@@ -247,5 +251,55 @@ extern "C" int mbpo_running_stats_apply(float *stats, const float *sums, int32_t
   MBPO_REQUIRE(x_dim > 0 && x_dim <= 128, MBPO_ERR_ARG, "running_stats_apply: x_dim out of range");
   hipLaunchKernelGGL(k_stats_apply, dim3(1), dim3(128), 0, (hipStream_t)stream, stats, sums, x_dim, std_min, std_max);
   MBPO_CHECK_LAUNCH("running_stats_apply");
+  return MBPO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Random permutation of [0, n): the shared shuffle of PPO.sgd_step (ppo/ppo.py:166-171, jr.permutation with ONE key for
+// every leaf == one permutation of whole trajectories).  JAX's stream is not reproducible; here
+//   key_i = Philox(seed, offset [+ rng_dev], stream PERM, i).word0,   perm = stable argsort(key)
+// computed as a rank count: perm[#{j : (key_j, j) < (key_i, i)}] = i.  O(n^2) compares, all of them from LDS tiles: n = B*M is
+// 4 k-16 k trajectories (C3: 16384 -> 2.7e8 compares, a few tens of microseconds once per num_minibatches updates); bit-exact
+// against numpy's stable argsort of the same keys (oracle/philox.py:philox_permutation).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_perm_keys(unsigned long long seed, unsigned long long offset, const unsigned long long *rng_dev,
+                                                    long long n, unsigned int *keys) {
+  const RngKey rk = rng_resolve(seed, offset, rng_dev);
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Philox4 p = philox4x32_10((uint32_t)i, (uint32_t)((unsigned long long)i >> 32), MBPO_STREAM_PERM ^ (uint32_t)(rk.offset >> 32) * 0x9E3779B9u,
+                            (uint32_t)rk.offset, (uint32_t)rk.seed, (uint32_t)(rk.seed >> 32));
+  keys[i] = p.v[0];
+}
+
+__global__ void __launch_bounds__(256) k_perm_rank(const unsigned int *keys, long long n, int *perm) {
+  __shared__ unsigned int s_k[1024];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned int ki = i < n ? keys[i] : 0u;
+  int rank = 0;
+  for (long long j0 = 0; j0 < n; j0 += 1024) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < 1024; t += 256) s_k[t] = (j0 + t < n) ? keys[j0 + t] : 0xFFFFFFFFu;
+    __syncthreads();
+    const int m = (int)((n - j0) < 1024 ? (n - j0) : 1024);
+    for (int t = 0; t < m; ++t) {
+      const unsigned int kj = s_k[t];
+      rank += (kj < ki || (kj == ki && j0 + t < i)) ? 1 : 0;
+    }
+  }
+  if (i < n) perm[rank] = (int)i;
+}
+
+extern "C" int mbpo_philox_permutation(uint64_t seed, uint64_t offset, const uint64_t *rng_dev, int64_t n, int32_t *perm,
+                                       uint32_t *workspace, void *stream) {
+  MBPO_REQUIRE(n >= 0 && n <= (1 << 20), MBPO_ERR_ARG, "philox_permutation: n=%lld outside [0, 2^20] (the rank count is O(n^2))", (long long)n);
+  if (n == 0) return MBPO_OK;
+  MBPO_REQUIRE(perm && workspace, MBPO_ERR_ARG, "philox_permutation: null perm/workspace");
+  const int grid = (int)((n + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_perm_keys, dim3(grid), dim3(256), 0, st, (unsigned long long)seed, (unsigned long long)offset,
+                     (const unsigned long long *)rng_dev, (long long)n, workspace);
+  hipLaunchKernelGGL(k_perm_rank, dim3(grid), dim3(256), 0, st, (const unsigned int *)workspace, (long long)n, perm);
+  MBPO_CHECK_LAUNCH("philox_permutation");
   return MBPO_OK;
 }

@@ -152,7 +152,7 @@ struct RolloutArgs {
   const float *policy_noise, *model_noise;
   const int *member_idx;
   unsigned long long seed, offset;
-  const float *offset_dev;
+  const unsigned long long *rng_dev;
   float *obs;
   const float *first_obs;
   float *steps, *done;
@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(512) k_model_rollout(RolloutArgs A) {
   float *s_done = s_steps + 16;                  // [16]
   float *s_rew = s_done + 16;                    // [16]
 
-  const unsigned long long rng_off = A.offset + (A.offset_dev ? (unsigned long long)A.offset_dev[0] : 0ull);
+  const RngKey rk_ = rng_resolve(A.seed, A.offset, A.rng_dev);
+  const unsigned long long rng_off = rk_.offset, rng_seed = rk_.seed;
   const long long n_tiles = (N + 15) >> 4;
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long env0 = tile * 16;
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(512) k_model_rollout(RolloutArgs A) {
         if (!A.deterministic && env < N) {
           long long nidx = ((long long)s * N + env) * U + d;
           eps = A.policy_noise ? A.policy_noise[nidx]
-                               : philox_normal(A.seed, rng_off, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
+                               : philox_normal(rng_seed, rng_off, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
         }
         float z = loc + sigma * eps;
         float a = tanhf(z);
@@ -364,7 +365,7 @@ __global__ void __launch_bounds__(512) k_model_rollout(RolloutArgs A) {
               if (env < N) {
                 if (A.ens_mode == MBPO_ENS_TSINF) mem = (int)(env % E);
                 else mem = A.member_idx ? A.member_idx[eidx]
-                                        : philox_randint(A.seed, rng_off, MBPO_STREAM_MEMBER, (unsigned long long)eidx, 0, E);
+                                        : philox_randint(rng_seed, rng_off, MBPO_STREAM_MEMBER, (unsigned long long)eidx, 0, E);
               }
               float mu = s_y[(mem * 16 + r) * A.ld_y + c];
               v = base + mu;
@@ -372,7 +373,7 @@ __global__ void __launch_bounds__(512) k_model_rollout(RolloutArgs A) {
                 float sg = softplus_f(s_y[(mem * 16 + r) * A.ld_y + X + c]) + A.ens_min_std;
                 long long nidx = eidx * X + c;
                 float eps = A.model_noise ? A.model_noise[nidx]
-                                          : philox_normal(A.seed, rng_off, MBPO_STREAM_MODEL_NOISE, (unsigned long long)nidx);
+                                          : philox_normal(rng_seed, rng_off, MBPO_STREAM_MODEL_NOISE, (unsigned long long)nidx);
                 v += sg * eps;
               }
             }
@@ -518,7 +519,8 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
     for (int idx = tid_; idx < n_rp; idx += nthreads) s_rp[idx] = A.reward_params[idx];
   }
 
-  const unsigned long long rng_off = A.offset + (A.offset_dev ? (unsigned long long)A.offset_dev[0] : 0ull);
+  const RngKey rk_ = rng_resolve(A.seed, A.offset, A.rng_dev);
+  const unsigned long long rng_off = rk_.offset, rng_seed = rk_.seed;
   const long long n_tiles = (N + 15) >> 4;
   const int mchain = wave >> 1, msub = wave & 1;   // member-phase role of this wave
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -592,7 +594,7 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
           if (!A.deterministic && env < N) {
             const long long nidx = ((long long)s * N + env) * U + d;
             eps = A.policy_noise ? A.policy_noise[nidx]
-                                 : philox_normal(A.seed, rng_off, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
+                                 : philox_normal(rng_seed, rng_off, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
           }
           const float z = loc + sigma * eps;
           float a = ro_ftanh(z);
@@ -674,7 +676,7 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
               if (env < N) {
                 if (A.ens_mode == MBPO_ENS_TSINF) mem = (int)(env % E);
                 else mem = A.member_idx ? A.member_idx[eidx]
-                                        : philox_randint(A.seed, rng_off, MBPO_STREAM_MEMBER, (unsigned long long)eidx, 0, E);
+                                        : philox_randint(rng_seed, rng_off, MBPO_STREAM_MEMBER, (unsigned long long)eidx, 0, E);
               }
               const float mu = s_y[(mem * 16 + r) * ld_y + c];
               v = base + mu;
@@ -682,7 +684,7 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
                 const float sg = softplus_f(s_y[(mem * 16 + r) * ld_y + X + c]) + A.ens_min_std;
                 const long long nidx = eidx * X + c;
                 const float eps = A.model_noise ? A.model_noise[nidx]
-                                                : philox_normal(A.seed, rng_off, MBPO_STREAM_MODEL_NOISE, (unsigned long long)nidx);
+                                                : philox_normal(rng_seed, rng_off, MBPO_STREAM_MODEL_NOISE, (unsigned long long)nidx);
                 v += sg * eps;
               }
             }
@@ -833,7 +835,7 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   A.action_clip = d->action_clip;
   if (!has_policy) memset(&A.policy, 0, sizeof(A.policy));
   A.policy_noise = d->policy_noise; A.model_noise = d->model_noise; A.member_idx = d->member_idx;
-  A.seed = d->seed; A.offset = d->offset; A.offset_dev = d->offset_dev;
+  A.seed = d->seed; A.offset = d->offset; A.rng_dev = (const unsigned long long *)d->rng_dev;
   A.obs = d->obs; A.first_obs = d->first_obs; A.steps = d->steps; A.done = d->done;
   A.transitions = d->transitions; A.row_len = d->row_len;
   A.n_out = E > 1 ? E : 1;

@@ -42,7 +42,7 @@ struct SacArgs {
   const float *batch, *norm_mean, *norm_std, *log_alpha;
   const float *noise_alpha, *noise_critic, *noise_actor;
   unsigned long long seed, offset;
-  const float *step_count;
+  const unsigned long long *rng_dev;
   float discounting, reward_scaling, target_entropy;
   int neq;                      // non_equidistant_time (losses.py:90-98)
   float neq_cd, neq_tl, neq_tu, neq_dt;
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
   }
   // requested now, consumed after the first layer phase: the two scalar loads overlap the tile load instead of preceding it
   const float log_alpha_v = A.log_alpha[0];
-  const float step_count_v = A.step_count[0];
+  const RngKey rk_ = rng_resolve(A.seed, A.offset, A.rng_dev);
   const float invB = 1.0f / (float)B;
   const float *pi_p = A.pi.params, *q1_p = A.q.params, *q2_p = A.q.params + A.q.net_stride;
   const float *t1_p = A.qt.params, *t2_p = A.qt.params + A.qt.net_stride;
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
       }
     }
     const float alpha = expf(log_alpha_v);
-    const unsigned long long rng_off = A.offset + (unsigned long long)step_count_v;
+    const unsigned long long rng_off = rk_.offset, rng_seed = rk_.seed;
     if (ph == -1) {
     } else if (role == 0) {
       // ============================== CRITIC (sac/losses.py:74-110) ==============================
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
           long long nidx = (long long)(row0 + r) * U + d;
           float eps = 0.f;
           if (row0 + r < B)
-            eps = A.noise_critic ? A.noise_critic[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_CRITIC, (unsigned long long)nidx);
+            eps = A.noise_critic ? A.noise_critic[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_SAC_CRITIC, (unsigned long long)nidx);
           ActSample sm = normal_tanh_sample(y_pi[r * ld_y + d], y_pi[r * ld_y + U + d], eps);
           s_qin2[r * ld_xu + X + d] = sm.a;  // postprocess(next_action)
           s_lp[idx] = sm.lp;
@@ -317,12 +317,12 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
           const float loc = y_pi[r * ld_y + d], raw = y_pi[r * ld_y + U + d];
           if (second) {
             float e_al = 0.f;
-            if (ok) e_al = A.noise_alpha ? A.noise_alpha[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ALPHA, (unsigned long long)nidx);
+            if (ok) e_al = A.noise_alpha ? A.noise_alpha[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_SAC_ALPHA, (unsigned long long)nidx);
             ActSample sal = normal_tanh_sample(loc, raw, e_al);   // alpha loss sample (:66-68)
             s_lpa[idx] = sal.lp;
           } else {
             float e_ac = 0.f;
-            if (ok) e_ac = A.noise_actor ? A.noise_actor[nidx] : philox_normal(A.seed, rng_off, MBPO_STREAM_SAC_ACTOR, (unsigned long long)nidx);
+            if (ok) e_ac = A.noise_actor ? A.noise_actor[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_SAC_ACTOR, (unsigned long long)nidx);
             ActSample sac = normal_tanh_sample(loc, raw, e_ac);   // actor loss sample (:117-119)
             s_lp[idx] = sac.lp;
             s_eps[idx] = e_ac;
@@ -884,7 +884,7 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
   A.batch = d->batch; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std;
   A.log_alpha = d->params + pl.NP - 1;
   A.noise_alpha = d->noise_alpha; A.noise_critic = d->noise_critic; A.noise_actor = d->noise_actor;
-  A.seed = d->seed; A.offset = d->offset; A.step_count = d->step_count;
+  A.seed = d->seed; A.offset = d->offset; A.rng_dev = (const unsigned long long *)d->rng_dev;
   A.stamps = g_sac_stamps;
   P2pDev X;
   A.p2p_epoch = nullptr;

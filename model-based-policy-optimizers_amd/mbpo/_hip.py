@@ -16,6 +16,7 @@ MBPO_MAX_LAYERS = 8
 ACT_IDS = {"swish": 0, "silu": 0, "relu": 1, "tanh": 2}
 
 SYS_PENDULUM, SYS_ENSEMBLE = 0, 1
+SYS_GENERIC = 100      # host-side only: a user-defined System, stepped outside the fused kernel (ops.generic_rollout)
 ENS_MEAN, ENS_TS1, ENS_TSINF = 0, 1, 2
 REWARD_PENDULUM, REWARD_QUADRATIC = 0, 1
 
@@ -72,7 +73,7 @@ class RolloutDesc(C.Structure):
         ("member_idx", C.c_void_p),
         ("seed", C.c_uint64),
         ("offset", C.c_uint64),
-        ("offset_dev", C.c_void_p),
+        ("rng_dev", C.c_void_p),
         ("obs", C.c_void_p),
         ("first_obs", C.c_void_p),
         ("steps", C.c_void_p),
@@ -80,6 +81,15 @@ class RolloutDesc(C.Structure):
         ("transitions", C.c_void_p),
         ("row_len", C.c_int32),
     ]
+
+
+class EpisodeStepDesc(C.Structure):
+    """mbpo_episode_step_desc"""
+    _fields_ = [("x_dim", C.c_int32), ("u_dim", C.c_int32), ("n_envs", C.c_int64), ("episode_length", C.c_int32),
+                ("action_repeat", C.c_int32), ("ppo_extras", C.c_int32), ("env_major", C.c_int32), ("step_index", C.c_int32),
+                ("n_steps", C.c_int32), ("action", C.c_void_p), ("raw_action", C.c_void_p), ("log_prob", C.c_void_p),
+                ("reward", C.c_void_p), ("x_next", C.c_void_p), ("sys_done", C.c_void_p), ("first_obs", C.c_void_p),
+                ("obs", C.c_void_p), ("steps", C.c_void_p), ("done", C.c_void_p), ("transitions", C.c_void_p), ("row_len", C.c_int32)]
 
 
 class EnsTrainDesc(C.Structure):
@@ -101,7 +111,7 @@ class SacDesc(C.Structure):
         ("batch", C.c_void_p), ("batch_size", C.c_int32), ("row_len", C.c_int32),
         ("norm_mean", C.c_void_p), ("norm_std", C.c_void_p),
         ("noise_alpha", C.c_void_p), ("noise_critic", C.c_void_p), ("noise_actor", C.c_void_p),
-        ("seed", C.c_uint64), ("offset", C.c_uint64),
+        ("seed", C.c_uint64), ("offset", C.c_uint64), ("rng_dev", C.c_void_p),
         ("discounting", C.c_float), ("reward_scaling", C.c_float), ("target_entropy", C.c_float), ("tau", C.c_float),
         ("lr_policy", C.c_float), ("lr_q", C.c_float), ("lr_alpha", C.c_float),
         ("wd_policy", C.c_float), ("wd_q", C.c_float), ("wd_alpha", C.c_float), ("max_grad_norm", C.c_float),
@@ -121,7 +131,7 @@ class PpoDesc(C.Structure):
         ("workspace", C.c_void_p), ("metrics", C.c_void_p), ("metrics_accum", C.c_void_p),
         ("data", C.c_void_p), ("batch_size", C.c_int32), ("unroll_length", C.c_int32), ("row_len", C.c_int32),
         ("norm_mean", C.c_void_p), ("norm_std", C.c_void_p), ("entropy_noise", C.c_void_p),
-        ("seed", C.c_uint64), ("offset", C.c_uint64),
+        ("seed", C.c_uint64), ("offset", C.c_uint64), ("rng_dev", C.c_void_p),
         ("entropy_cost", C.c_float), ("discounting", C.c_float), ("reward_scaling", C.c_float), ("gae_lambda", C.c_float),
         ("clipping_epsilon", C.c_float), ("normalize_advantage", C.c_int32),
         ("lr", C.c_float), ("wd", C.c_float), ("grad_scale", C.c_float),
@@ -140,7 +150,7 @@ class BpttDesc(C.Structure):
         ("reward_kind", C.c_int32), ("reward_params", C.c_void_p), ("sys_params", C.c_void_p),
         ("state_mean", C.c_void_p), ("state_std", C.c_void_p), ("reward_mean_std", C.c_void_p),
         ("init_states", C.c_void_p), ("n", C.c_int64),
-        ("act_noise", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64), ("offset_dev", C.c_void_p),
+        ("act_noise", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64), ("rng_dev", C.c_void_p),
         ("discount", C.c_float), ("lambda_", C.c_float), ("ent_coef", C.c_float),
         ("transitions", C.c_void_p), ("lambda_values", C.c_void_p), ("grads", C.c_void_p), ("metrics", C.c_void_p),
         ("workspace", C.c_void_p),
@@ -192,6 +202,8 @@ def _bind_optional(lib: C.CDLL) -> None:
         "mbpo_lambda_return_scan": [vp, vp, vp, i64, i32, f32, f32, i32, vp],
         "mbpo_critic_grads": [vp, i32, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp],
         "mbpo_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, i32, vp, f32, vp, vp, vp],
+        "mbpo_rng_advance": [vp, u64, vp],
+        "mbpo_philox_permutation": [u64, u64, vp, i64, vp, vp, vp],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name, None)
@@ -216,6 +228,10 @@ def _bind_optional(lib: C.CDLL) -> None:
     if fn is not None:
         fn.restype = C.c_int64
         fn.argtypes = [i32, i32, vp, i64]
+    lib.mbpo_policy_act.restype = C.c_int
+    lib.mbpo_policy_act.argtypes = [C.POINTER(MlpDesc), vp, i64, vp, vp, i32, f32, vp, u64, u64, vp, u64, vp, vp, vp, vp, vp]
+    lib.mbpo_episode_step.restype = C.c_int
+    lib.mbpo_episode_step.argtypes = [C.POINTER(EpisodeStepDesc), vp]
     lib.mbpo_running_stats_workspace_floats.restype = C.c_int64
     lib.mbpo_running_stats_workspace_floats.argtypes = [i32]
     lib.mbpo_ens_nll_workspace_floats.restype = C.c_int64

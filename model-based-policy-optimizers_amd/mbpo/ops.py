@@ -57,6 +57,42 @@ def ensemble_mlp_forward(params: torch.Tensor, spec: MlpSpec, x: torch.Tensor, s
     return y
 
 
+def make_rng(device, seed: int = 0, counter: int = 0) -> torch.Tensor:
+    """Device RNG control words (include/mbpo_hip.h "randomness"): int64[2] holding the uint64 pair {seed word, step counter}."""
+    t = torch.zeros(2, dtype=torch.int64, device=device)
+    set_rng(t, seed, counter)
+    return t
+
+
+def _as_i64(v: int) -> int:
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def set_rng(rng: torch.Tensor, seed: Optional[int] = None, counter: Optional[int] = None) -> None:
+    """Write the seed word and/or the counter (host -> device copy; outside any captured graph)."""
+    if seed is not None and counter is not None:
+        rng.copy_(torch.tensor([_as_i64(seed), _as_i64(counter)], dtype=torch.int64))
+    elif seed is not None:
+        rng[0:1].copy_(torch.tensor([_as_i64(seed)], dtype=torch.int64))
+    elif counter is not None:
+        rng[1:2].copy_(torch.tensor([_as_i64(counter)], dtype=torch.int64))
+
+
+def rng_advance(rng: torch.Tensor, inc: int = 1) -> None:
+    """rng[1] += inc on the device (graph-capturable)."""
+    check(load().mbpo_rng_advance(rng_ptr(rng), int(inc), current_stream_ptr()), "mbpo_rng_advance")
+
+
+def rng_ptr(rng: Optional[torch.Tensor]) -> Optional[int]:
+    if rng is None:
+        return None
+    _req(rng, "rng_dev", torch.int64)
+    if rng.numel() != 2:
+        raise ValueError("rng_dev must be an int64[2] device tensor {seed word, step counter}")
+    return rng.data_ptr()
+
+
 def transition_row_len(x_dim: int, u_dim: int, ppo_extras: bool = False) -> int:
     return 2 * x_dim + u_dim + 3 + ((1 + u_dim) if ppo_extras else 0)
 
@@ -74,7 +110,7 @@ def model_rollout(*, policy_params: Optional[torch.Tensor] = None, policy_spec: 
                   deterministic: bool = False, ppo_extras: bool = False, env_major: bool = False, action_clip: float = 0.0,
                   policy_noise: Optional[torch.Tensor] = None, model_noise: Optional[torch.Tensor] = None,
                   member_idx: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0,
-                  offset_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  rng_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused S-step model rollout for N envs (R1-R8).  Updates obs/steps/done in place; returns rows [S*N, D]."""
     lib = load()
     n_envs = obs.shape[0]
@@ -130,7 +166,7 @@ def model_rollout(*, policy_params: Optional[torch.Tensor] = None, policy_spec: 
             raise ValueError("member_idx must be [S,AR,N]")
     d.policy_noise, d.model_noise, d.member_idx = ptr(policy_noise), ptr(model_noise), ptr(member_idx)
     d.seed, d.offset = seed, offset
-    d.offset_dev = ptr(_req(offset_dev, "offset_dev")) if offset_dev is not None else None
+    d.rng_dev = rng_ptr(rng_dev)
     d.obs, d.first_obs, d.steps, d.done = obs.data_ptr(), first_obs.data_ptr(), steps.data_ptr(), done.data_ptr()
     d.transitions, d.row_len = out.data_ptr(), D
     check(lib.mbpo_model_rollout(C.byref(d), current_stream_ptr()), "mbpo_model_rollout")
@@ -159,7 +195,7 @@ def replay_gather(data: torch.Tensor, state: torch.Tensor, idx: torch.Tensor) ->
 
 
 def replay_sample(data: torch.Tensor, state: torch.Tensor, n: int, seed: int, offset: int, return_idx: bool = False,
-                  out: Optional[torch.Tensor] = None, offset_dev: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None, rng_dev: Optional[torch.Tensor] = None,
                   idx_out: Optional[torch.Tensor] = None):
     """UniformSamplingQueue.sample: Philox randint in [sample_position, insert_position) + gather, one launch."""
     lib = load()
@@ -173,8 +209,28 @@ def replay_sample(data: torch.Tensor, state: torch.Tensor, n: int, seed: int, of
             raise ValueError(f"idx_out must have {n} entries")
         idx = idx_out
     check(lib.mbpo_replay_sample(data.data_ptr(), data.shape[0], data.shape[1], state.data_ptr(), seed, offset,
-                                 ptr(offset_dev), n, ptr(idx), out.data_ptr(), current_stream_ptr()), "mbpo_replay_sample")
+                                 rng_ptr(rng_dev), n, ptr(idx), out.data_ptr(), current_stream_ptr()), "mbpo_replay_sample")
     return (out, idx) if return_idx else out
+
+
+def philox_permutation(n: int, seed: int, offset: int = 0, rng_dev: Optional[torch.Tensor] = None,
+                       out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Random permutation of range(n) as int32 (PPO.sgd_step's shared shuffle, ppo/ppo.py:166-171): stable argsort of Philox keys."""
+    lib = load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if out is None:
+        out = torch.empty(n, dtype=torch.int32, device=dev)
+    else:
+        _req(out, "out", torch.int32)
+    if workspace is None:
+        workspace = torch.empty(n, dtype=torch.int32, device=out.device)
+    else:
+        _req(workspace, "workspace", torch.int32)
+    if out.numel() != n or workspace.numel() < n:
+        raise ValueError("out / workspace must hold n int32")
+    check(lib.mbpo_philox_permutation(seed, offset, rng_ptr(rng_dev), n, out.data_ptr(), workspace.data_ptr(), current_stream_ptr()),
+          "mbpo_philox_permutation")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ running statistics (R8)
@@ -344,8 +400,10 @@ class SacUpdater:
         self.step_count.fill_(count)
 
     def sgd_step(self, batch: torch.Tensor, norm_mean=None, norm_std=None, noise_alpha=None, noise_critic=None,
-                 noise_actor=None, offset: int = 0) -> None:
-        """One SAC.sgd_step (sac/sac.py:227-281) on `batch` [B, 2x+u+3]; metrics land in self.metrics (device)."""
+                 noise_actor=None, offset: int = 0, seed: Optional[int] = None, rng_dev: Optional[torch.Tensor] = None) -> None:
+        """One SAC.sgd_step (sac/sac.py:227-281) on `batch` [B, 2x+u+3]; metrics land in self.metrics (device).
+        Noise that is not given explicitly is Philox(seed, offset [+ rng_dev]): vary `offset` (or advance the device counter)
+        between steps — the optimizer step count plays no part in the streams."""
         _req(batch, "batch")
         if batch.shape != (self.batch_size, self.desc.row_len):
             raise ValueError(f"batch must be [{self.batch_size},{self.desc.row_len}], got {tuple(batch.shape)}")
@@ -359,6 +417,9 @@ class SacUpdater:
                     raise ValueError(f"{nm} must be [B,u]")
         d.noise_alpha, d.noise_critic, d.noise_actor = ptr(noise_alpha), ptr(noise_critic), ptr(noise_actor)
         d.offset = offset
+        if seed is not None:
+            d.seed = seed
+        d.rng_dev = rng_ptr(rng_dev)
         st = current_stream_ptr()
         if self.all_reduce is None and self.fused_apply:
             # single rank: fwd/bwd, then ONE launch for slab reduction + norms + clip + AdamW + Polyak
@@ -436,7 +497,8 @@ class PpoUpdater:
         self.adam_v.zero_() if adam_v is None else self.adam_v.copy_(adam_v)
         self.step_count.fill_(count)
 
-    def minibatch_step(self, data: torch.Tensor, norm_mean=None, norm_std=None, entropy_noise=None, offset: int = 0) -> None:
+    def minibatch_step(self, data: torch.Tensor, norm_mean=None, norm_std=None, entropy_noise=None, offset: int = 0,
+                       seed: Optional[int] = None, rng_dev: Optional[torch.Tensor] = None) -> None:
         """One PPO.minibatch_step (ppo.py:142-156) on data [B, T, 2x+2u+4]."""
         _req(data, "data")
         if tuple(data.shape) != (self.batch_size, self.unroll_length, self.desc.row_len):
@@ -450,6 +512,9 @@ class PpoUpdater:
                 raise ValueError("entropy_noise must be [B,T,u]")
         d.entropy_noise = ptr(entropy_noise)
         d.offset = offset
+        if seed is not None:
+            d.seed = seed
+        d.rng_dev = rng_ptr(rng_dev)
         st = current_stream_ptr()
         check(self.lib.mbpo_ppo_grads(C.byref(d), st), "mbpo_ppo_grads")
         if self.all_reduce is not None:
@@ -490,7 +555,7 @@ class BpttActorGrad:
 
     def __call__(self, *, actor_params, target_critic_params, init_states, state_mean, state_std, reward_mean_std,
                  system_kind: int, reward_kind: int, reward_params, sys_params=None, dyn_params=None, dyn_spec: Optional[MlpSpec] = None,
-                 ens_predict_delta: bool = True, act_noise=None, offset: int = 0, offset_dev=None):
+                 ens_predict_delta: bool = True, act_noise=None, offset: int = 0, rng_dev=None):
         d = self.desc
         for t, nm in ((actor_params, "actor_params"), (target_critic_params, "target_critic_params"), (init_states, "init_states"),
                       (state_mean, "state_mean"), (state_std, "state_std"), (reward_mean_std, "reward_mean_std"),
@@ -516,7 +581,7 @@ class BpttActorGrad:
                 raise ValueError("act_noise must be [n,H,u]")
         d.act_noise = ptr(act_noise)
         d.offset = offset
-        d.offset_dev = ptr(offset_dev)
+        d.rng_dev = rng_ptr(rng_dev)
         d.transitions, d.lambda_values = self.transitions.data_ptr(), self.lambda_values.data_ptr()
         d.grads, d.metrics = self.grads.data_ptr(), self.metrics.data_ptr()
         if self.workspace is None:

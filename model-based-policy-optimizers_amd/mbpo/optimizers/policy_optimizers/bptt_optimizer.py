@@ -254,7 +254,7 @@ class BPTTOptimizer(BaseOptimizer):
         self._critic_rows = f(Kc * self.critic_batch, self.row_len)
         self._traj_state = torch.tensor([self.num_transitions, 0, 0, self.num_transitions], device=dev, dtype=torch.int32)
         self._reward_ms = f(2)
-        self._step_dev = f(1)
+        self._rng = ops.make_rng(dev)      # device RNG words {seed word = 0, train-step index}: the Philox offset of every draw
         self._stats_sums_x, self._stats_ws_x = f(1 + 2 * X), f(ops.stats_workspace_floats(X))
         self._stats_sums_r, self._stats_ws_r = f(3), f(ops.stats_workspace_floats(1))
 
@@ -332,7 +332,7 @@ class BPTTOptimizer(BaseOptimizer):
         obs_seed, act_seed, critic_seed = seeds
         # initial states: sampling_buffer.sample -> .observation   (:455-458)
         ops.replay_sample(buff.data, buff.state, self.num_samples_per_gradient_update, seed=obs_seed, offset=0,
-                          offset_dev=self._step_dev, out=self._init_rows)
+                          rng_dev=self._rng, out=self._init_rows)
         self._init_obs.copy_(self._init_rows[:, :X])
         # actor: value_and_grad(vmap(actor_loss).mean)   (:361-372)
         self._reward_ms[0:1].copy_(w.reward_norm.vec[1:2])
@@ -341,14 +341,14 @@ class BPTTOptimizer(BaseOptimizer):
         ag.desc.seed = act_seed
         ag(actor_params=w.actor_params, target_critic_params=w.target_critic_params, init_states=self._init_obs,
            state_mean=w.state_norm.mean, state_std=w.state_norm.std, reward_mean_std=self._reward_ms, offset=0,
-           offset_dev=self._step_dev, **w.sys_kw)
+           rng_dev=self._rng, **w.sys_kw)
         gs = 1.0 / self.dp.world_size
         if self._all_reduce is not None:
             self._all_reduce(ag.grads)
         self._actor_opt.step(w.actor_params, ag.grads, grad_scale=gs)
         # critic: K minibatches drawn with replacement from the n*H simulated transitions   (:380-419)
         ops.replay_sample(ag.transitions, self._traj_state, self._critic_idx.numel(), seed=critic_seed, offset=0,
-                          offset_dev=self._step_dev, out=self._critic_rows, idx_out=self._critic_idx)
+                          rng_dev=self._rng, out=self._critic_rows, idx_out=self._critic_idx)
         B = self.critic_batch
         for k in range(self.critic_updates_per_policy_updates):
             cg = self._critic_grad(w.critic_params, ag.transitions, ag.lambda_values, self._critic_idx[k * B:(k + 1) * B],
@@ -369,7 +369,7 @@ class BPTTOptimizer(BaseOptimizer):
                                      workspace=self._stats_ws_r, std_min=EPS, std_max=float("inf"))
         if self.sample_simulated_transitions:
             buff = self.sampling_buffer.insert_rows(buff, ag.transitions)
-        self._step_dev.add_(1.0)
+        ops.rng_advance(self._rng)
         return buff
 
     def _evaluate(self, w: "_Work", eval_obs: torch.Tensor) -> torch.Tensor:
@@ -417,7 +417,7 @@ class BPTTOptimizer(BaseOptimizer):
         w = _Work(self, bptt_state.replace(key=train_key))
         self._actor_opt.load_state(bptt_state.actor_opt_state.mu, bptt_state.actor_opt_state.nu, bptt_state.actor_opt_state.count)
         self._critic_opt.load_state(bptt_state.critic_opt_state.mu, bptt_state.critic_opt_state.nu, bptt_state.critic_opt_state.count)
-        self._step_dev.zero_()
+        ops.set_rng(self._rng, 0, 0)
         # per-train() Philox seeds; the step counter is the Philox offset (the reference re-splits a key every step)
         seeds = tuple(self.dp.rank_key(k) for k in K.split(train_key, 4)[:3])    # ranks draw different states / noise / minibatches
         self._last_seeds = seeds                       # (initial-state sampling, action noise, critic minibatch) — for parity tests

@@ -75,7 +75,10 @@ class BraxOptimizer(BaseOptimizer):
                           sample_buffer_state=opt_state.true_buffer_state, sample_buffer=self.true_buffer)
         trainer = self.agent_class(environment=env, **self.agent_kwargs)
         key, new_key = K.split(opt_state.key)
-        policy_params, metrics = trainer.run_training(key=new_key)
+        try:
+            policy_params, metrics = trainer.run_training(key=new_key)
+        finally:
+            trainer.close()      # the captured graph and the peer-memory regions belong to this trainer (one per train())
         new_opt_state = opt_state.replace(policy_params=policy_params, key=new_key)
         return BraxOutput(optimizer_state=new_opt_state, summary=metrics)
 
@@ -88,8 +91,5 @@ class SACOptimizer(BraxOptimizer):
 
 class PPOOptimizer(BraxOptimizer):
     def __init__(self, true_buffer: UniformSamplingQueue, system: Optional[System] = None, **ppo_kwargs):
-        try:
-            from mbpo.optimizers.policy_optimizers.ppo.ppo import PPO
-        except ImportError as e:   # pragma: no cover
-            raise NotImplementedError("PPO trainer is not built yet in this round (SURVEY §8a rows P1-P3)") from e
+        from mbpo.optimizers.policy_optimizers.ppo.ppo import PPO
         super().__init__(agent_class=PPO, system=system, true_buffer=true_buffer, **ppo_kwargs)

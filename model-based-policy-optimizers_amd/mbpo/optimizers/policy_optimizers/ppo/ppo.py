@@ -5,8 +5,11 @@ Where the reference has                               this file issues
   scan of brax acting.generate_unroll (:194-208)  ->  K x mbpo_model_rollout (ppo_extras, env_major): rows land as
                                                       data[B*M, T, D] directly — no swapaxes/reshape (:210-213)
   running_statistics.update (:216-219)            ->  mbpo_running_stats_reduce x2 + _apply
-  jr.permutation + reshape (:166-171)             ->  device permutation + mbpo_replay_gather on [B*M] rows of T*D floats
+  jr.permutation + reshape (:166-171)             ->  mbpo_philox_permutation + mbpo_replay_gather on [B*M] rows of T*D floats
   scan of minibatch_step (:172-176)               ->  M x (mbpo_ppo_grads [+ all-reduce] + mbpo_ppo_apply)
+
+Randomness: as in the SAC trainer, every draw is Philox(seed word, (call-site id << 32) + step index, stream, element) with
+the seed word (epoch key) and the training-step index in two device words (`self._rng`).
 """
 from __future__ import annotations
 
@@ -27,6 +30,9 @@ from mbpo.systems.ensemble_system import lecun_uniform_flat
 from mbpo.utils import keys as K
 
 Metrics = Dict[str, Any]
+
+# Philox call-site ids (high 32 bits of the offset): unroll k, update epoch e (the permutation), minibatch (e, m)
+SITE_UNROLL, SITE_PERM, SITE_MINIBATCH = 1, 1024, 65536
 
 
 @dataclass
@@ -133,7 +139,9 @@ class PPO:
         self._stats_vec = torch.zeros(1 + 3 * self.x_dim, device=self.device)
         self._stats_sums = torch.zeros(1 + 2 * self.x_dim, device=self.device)
         self._stats_ws = torch.empty(ops.stats_workspace_floats(self.x_dim), device=self.device)
-        self._call_counter = 0
+        self._perm = torch.zeros(n_traj, dtype=torch.int32, device=self.device)
+        self._perm_ws = torch.zeros(n_traj, dtype=torch.int32, device=self.device)
+        self._rng = ops.make_rng(self.device)       # device uint64[2]: {epoch key, training-step index}
 
     # ------------------------------------------------------------------------------------------------ policy / state
     def _norm(self, normalizer_params: RunningStatisticsState):
@@ -141,9 +149,9 @@ class PPO:
             return None, None
         return normalizer_params.mean.contiguous(), normalizer_params.std.contiguous()
 
-    def _next_offset(self) -> int:
-        self._call_counter += 1
-        return self._call_counter << 32
+    def rekey(self, key: int) -> None:
+        """Start a fresh random stream: seed word <- key, step index <- 0."""
+        ops.set_rng(self._rng, K.PRNGKey(key), 0)
 
     def make_policy(self, params, deterministic: bool = False):
         """make_inference_fn (ppo_network.py:59-84)."""
@@ -176,56 +184,62 @@ class PPO:
                              normalizer_params=RunningStatisticsState(self._stats_vec, self.x_dim), env_steps=env_steps)
 
     # ------------------------------------------------------------------------------------------------ hot loops
-    def minibatch_step(self, data: torch.Tensor, normalizer_params: RunningStatisticsState, key: int) -> None:
-        """ppo.py:142-156 on one minibatch [B, T, D]."""
+    def minibatch_step(self, data: torch.Tensor, normalizer_params: RunningStatisticsState, key: Optional[int] = None,
+                       e: int = 0, m: int = 0) -> None:
+        """ppo.py:142-156 on one minibatch [B, T, D]; (e, m) = its position in the update-epoch / minibatch scans."""
+        if key is not None:
+            self.rekey(key)
         nm, ns = self._norm(normalizer_params)
-        self.updater.desc.seed = key
-        self.updater.minibatch_step(data, nm, ns, offset=self._call_counter << 32)
+        self.updater.minibatch_step(data, nm, ns, seed=0, offset=(SITE_MINIBATCH + e * self.num_minibatches + m) << 32,
+                                    rng_dev=self._rng)
 
-    def sgd_step(self, data: torch.Tensor, normalizer_params: RunningStatisticsState, key: int) -> None:
+    def sgd_step(self, data: torch.Tensor, normalizer_params: RunningStatisticsState, key: Optional[int] = None, e: int = 0) -> None:
         """ppo.py:158-177: one shared permutation of the B*M trajectories, then M minibatch updates."""
-        key, key_perm, key_grad = K.split(key, 3)
+        if key is not None:
+            self.rekey(key)
         n = data.shape[0]
-        gen = torch.Generator(device=self.device).manual_seed(key_perm % (2 ** 63))
-        perm = torch.randperm(n, device=self.device, generator=gen, dtype=torch.int64).to(torch.int32)
+        perm = ops.philox_permutation(n, seed=0, offset=(SITE_PERM + e) << 32, rng_dev=self._rng, out=self._perm,
+                                      workspace=self._perm_ws)
         # every leaf is permuted with the SAME key (ppo.py:166-169) == one row gather of whole trajectories
         flat = data.reshape(n, -1)
         shuffled = ops.replay_gather(flat, self._ring_state, perm).reshape(self.num_minibatches, self.batch_size,
                                                                             self.unroll_length, self.row_len)
         for m in range(self.num_minibatches):
-            self.minibatch_step(shuffled[m], normalizer_params, key_grad)
+            self.minibatch_step(shuffled[m], normalizer_params, e=e, m=m)
 
-    def training_step(self, training_state: TrainingState, state: State, key: int):
-        """ppo.py:179-233."""
-        key_sgd, key_generate_unroll, new_key = K.split(key, 3)
+    def training_step(self, training_state: TrainingState, state: State, key: Optional[int] = None):
+        """ppo.py:179-233.  `key` given: re-key the device stream; None: the next step of the running stream."""
+        new_key = None
+        if key is not None:
+            _, _, new_key = K.split(key, 3)
+            self.rekey(key)
         nm, ns = self._norm(training_state.normalizer_params)
         spec = self.env.system.rollout_spec(state.system_params, self.device)
         n_unrolls = self.batch_size * self.num_minibatches // self.num_envs
         N, T = self.num_envs, self.unroll_length
-        cur_key = key_generate_unroll
         for k in range(n_unrolls):                                                               # scan :194-208
-            cur_key, next_key = K.split(cur_key)
             ops.model_rollout(policy_params=training_state.params.policy, policy_spec=self.policy_spec, x_dim=self.x_dim,
                               u_dim=self.u_dim, obs=state.obs, first_obs=state.info['first_obs'], steps=state.info['steps'],
                               done=state.done, n_steps=T, episode_length=self.episode_length, action_repeat=self.action_repeat,
-                              norm_mean=nm, norm_std=ns, ppo_extras=True, env_major=True, seed=cur_key,
-                              offset=self._next_offset(), out=self._data[k * N:(k + 1) * N].reshape(N * T, self.row_len), **spec)
-            cur_key = next_key
+                              norm_mean=nm, norm_std=ns, ppo_extras=True, env_major=True, seed=0,
+                              offset=(SITE_UNROLL + k) << 32, rng_dev=self._rng,
+                              out=self._data[k * N:(k + 1) * N].reshape(N * T, self.row_len), **spec)
         # running_statistics.update(normalizer_params, data.observation)   (:216-219)
         rows = self._data.reshape(-1, self.row_len)
         ops.running_stats_update(rows, 0, self.x_dim, training_state.normalizer_params.vec, all_reduce=self._all_reduce,
                                  sums=self._stats_sums, workspace=self._stats_ws)
-        for _ in range(self.num_updates_per_batch):                                              # scan :222-226
-            key_sgd, k = K.split(key_sgd)
-            self.sgd_step(self._data, training_state.normalizer_params, k)
+        for e in range(self.num_updates_per_batch):                                              # scan :222-226
+            self.sgd_step(self._data, training_state.normalizer_params, e=e)
+        ops.rng_advance(self._rng)
         training_state = training_state.replace(env_steps=training_state.env_steps + self.env_step_per_training_step)
         return training_state, state, new_key
 
     def training_epoch(self, training_state: TrainingState, state: State, key: int):
         """ppo.py:235-247."""
         self.updater.metrics_accum.zero_()
+        self.rekey(key)
         for _ in range(self.num_training_steps_per_epoch):
-            training_state, state, key = self.training_step(training_state, state, key)
+            training_state, state, _ = self.training_step(training_state, state)
         acc = self.updater.metrics_accum.cpu()
         if self.p2p is not None and self.p2p.status() != 0:
             raise _hip.MbpoHipError("PPO: the peer-memory gradient exchange timed out on this rank; "
@@ -251,7 +265,8 @@ class PPO:
         key, subkey = K.split(key)
         training_state = self.init_training_state(subkey)
         key, rb_key, env_key, eval_key = K.split(key, 4)
-        env_state = self.env.reset(K.split(env_key, self.num_envs))
+        rk = self.dp.rank_key      # data-generating keys differ per rank; the init key above is shared (parameters are broadcast)
+        env_state = self.env.reset(K.split(rk(env_key), self.num_envs))
         evaluator = Evaluator(self, self.env, num_eval_envs=self.num_eval_envs, episode_length=self.episode_length,
                               action_repeat=self.action_repeat, key=eval_key)
         all_metrics: List[Metrics] = []
@@ -263,12 +278,17 @@ class PPO:
         current_step = 0
         for _ in range(self.num_evals_after_init):
             key, epoch_key = K.split(key)
-            training_state, env_state, training_metrics = self.training_epoch_with_timing(training_state, env_state, epoch_key)
+            training_state, env_state, training_metrics = self.training_epoch_with_timing(training_state, env_state, rk(epoch_key))
             current_step = training_state.env_steps
             metrics = evaluator.run_evaluation(self._snapshot(training_state), training_metrics)
             all_metrics.append(metrics)
             progress_fn(current_step, metrics)
         return self._snapshot(training_state), all_metrics
+
+    def close(self) -> None:
+        if self.p2p is not None:
+            self.p2p.close()
+            self.p2p = None
 
     def _snapshot(self, training_state: TrainingState):
         return (RunningStatisticsState(training_state.normalizer_params.vec.clone(), self.x_dim),

@@ -8,14 +8,16 @@ Where the reference has                      this file issues
   lax.scan of sgd_step (:324)            ->  G x (mbpo_sac_grads [+ all-reduce] + mbpo_sac_apply)
   jit(training_epoch) (:347-361)         ->  one captured hipGraph of a training_step, replayed per step
 
-Randomness: the reference splits a threefry key per call; here each epoch derives three integer seeds from the epoch
-key and the device-resident optimizer step count is added to the Philox offset inside the kernels, so a replayed graph
-draws fresh numbers every step (see utils/keys.py).
+Randomness: the reference splits a threefry key per call (sac.py:289,309-311,354-356).  Here every draw of a training_step
+is Philox(seed word, (call-site id << 32) + step index, stream, element) with the seed word (the epoch / prefill key) and
+the step index in two DEVICE words (`self._rng`, include/mbpo_hip.h "randomness"): the captured hipGraph bakes only the
+call-site constants, so a replayed step draws bit for bit what the same step draws when issued eagerly.
 """
 from __future__ import annotations
 
 import dataclasses
 import math
+import os
 import time
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
@@ -32,6 +34,9 @@ from mbpo.types import Transition
 from mbpo.utils import keys as K
 
 Metrics = Dict[str, Any]
+
+# Philox call-site ids (high 32 bits of the offset; the low 32 bits count training steps on the device)
+SITE_ROLLOUT, SITE_SAMPLE, SITE_SGD = 1, 2, 16
 
 
 @dataclass
@@ -213,7 +218,9 @@ class SAC:
         self.use_graph = use_graph
         self._graph = None
         self._graph_key = None
-        self._call_counter = 0     # host part of the Philox offset (high 32 bits)
+        self._graph_refs = None
+        self._rng = ops.make_rng(self.device)      # device uint64[2]: {key of the running epoch / prefill, step index}
+        self._eval_calls = 0
 
     # ------------------------------------------------------------------------------------------------ policy
     def make_policy(self, params, deterministic: bool = False):
@@ -257,20 +264,23 @@ class SAC:
                              alpha_params=u.log_alpha, normalizer_params=RunningStatisticsState(self._stats_vec, self.x_dim))
 
     # ------------------------------------------------------------------------------------------------ hot loops
-    def _next_offset(self) -> int:
-        self._call_counter += 1
-        return self._call_counter << 32
+    def rekey(self, key: int) -> None:
+        """Start a fresh random stream: seed word <- key, step index <- 0 (host -> device write; never inside a capture)."""
+        ops.set_rng(self._rng, K.PRNGKey(key), 0)
 
     def get_experience(self, normalizer_params: RunningStatisticsState, policy_params: torch.Tensor, env_state: State,
-                       buffer_state: ReplayBufferState, key: int):
-        """sac.py:283-304."""
+                       buffer_state: ReplayBufferState, key: Optional[int] = None):
+        """sac.py:283-304.  `key` given: re-key the device stream first; None: continue it (the step index is advanced by
+        the caller, once per training / prefill step)."""
+        if key is not None:
+            self.rekey(key)
         nm, ns = self._norm(normalizer_params)
         spec = self.env.system.rollout_spec(env_state.system_params, self.device)
         rows = ops.model_rollout(policy_params=policy_params, policy_spec=self.policy_spec, x_dim=self.x_dim, u_dim=self.u_dim,
                                  obs=env_state.obs, first_obs=env_state.info['first_obs'], steps=env_state.info['steps'],
                                  done=env_state.done, n_steps=self.num_env_steps_between_updates,
                                  episode_length=self.episode_length, action_repeat=self.action_repeat, norm_mean=nm,
-                                 norm_std=ns, seed=key, offset=self._next_offset(), offset_dev=self.updater.step_count,
+                                 norm_std=ns, seed=0, offset=SITE_ROLLOUT << 32, rng_dev=self._rng,
                                  out=self._rollout_rows, **spec)
         # running_statistics.update(normalizer_params, transitions.observation, pmap_axis_name)   (:298-301)
         ops.running_stats_update(rows, 0, self.x_dim, normalizer_params.vec, all_reduce=self._all_reduce,
@@ -278,35 +288,43 @@ class SAC:
         buffer_state = self.replay_buffer.insert_rows(buffer_state, rows)                       # :303
         return normalizer_params, env_state, buffer_state
 
-    def sgd_step(self, transitions_rows: torch.Tensor, normalizer_params: RunningStatisticsState, key: int) -> None:
-        """sac.py:227-281 on one minibatch [B, D] (alpha, critic, actor updates at the old params + Polyak)."""
+    def sgd_step(self, transitions_rows: torch.Tensor, normalizer_params: RunningStatisticsState, key: Optional[int] = None,
+                 g: int = 0) -> None:
+        """sac.py:227-281 on one minibatch [B, D] (alpha, critic, actor updates at the old params + Polyak); `g` is the
+        position inside training_step's scan (:324) — the reference hands every sgd_step its own split of the key."""
+        if key is not None:
+            self.rekey(key)
         nm, ns = self._norm(normalizer_params)
-        self.updater.desc.seed = key
-        self.updater.sgd_step(transitions_rows, nm, ns, offset=self._call_counter << 32)
+        self.updater.sgd_step(transitions_rows, nm, ns, seed=0, offset=(SITE_SGD + g) << 32, rng_dev=self._rng)
 
-    def training_step(self, training_state: TrainingState, env_state: State, buffer_state: ReplayBufferState, key: int):
-        """sac.py:306-327."""
-        experience_key, training_key = K.split(key)
+    def training_step(self, training_state: TrainingState, env_state: State, buffer_state: ReplayBufferState,
+                      key: Optional[int] = None):
+        """sac.py:306-327.  `key` given: re-key the device stream (eager use); None: the next step of the running stream —
+        what training_epoch issues, eagerly or as a hipGraph replay, with identical results."""
+        if key is not None:
+            self.rekey(key)
         normalizer_params, env_state, buffer_state = self.get_experience(
-            training_state.normalizer_params, training_state.policy_params, env_state, buffer_state, experience_key)
+            training_state.normalizer_params, training_state.policy_params, env_state, buffer_state)
         training_state = training_state.replace(
             env_steps=training_state.env_steps + self.env_steps_per_actor_step * self.num_env_steps_between_updates)
-        buffer_state, rows = self.replay_buffer.sample_rows(buffer_state, out=self._batch_rows,
-                                                            offset_dev=self.updater.step_count)   # :318
+        buffer_state, rows = self.replay_buffer.sample_rows(buffer_state, out=self._batch_rows, seed=0,
+                                                            offset=SITE_SAMPLE << 32, rng_dev=self._rng)   # :318
         B = self.batch_size
         for g in range(self.grad_updates_per_step):                                                # scan :324
-            self.sgd_step(rows[g * B:(g + 1) * B], normalizer_params, training_key)
+            self.sgd_step(rows[g * B:(g + 1) * B], normalizer_params, g=g)
+        ops.rng_advance(self._rng)
         return training_state, env_state, buffer_state
 
     def prefill_replay_buffer(self, training_state: TrainingState, env_state: State, buffer_state: ReplayBufferState, key: int):
         """sac.py:329-345."""
+        key, new_key = K.split(key)
+        self.rekey(key)
         for _ in range(self.num_prefill_actor_steps):
-            key, new_key = K.split(key)
             _, env_state, buffer_state = self.get_experience(training_state.normalizer_params, training_state.policy_params,
-                                                             env_state, buffer_state, key)
+                                                             env_state, buffer_state)
+            ops.rng_advance(self._rng)
             training_state = training_state.replace(env_steps=training_state.env_steps + self.env_steps_per_actor_step)
-            key = new_key
-        return training_state, env_state, buffer_state, key
+        return training_state, env_state, buffer_state, new_key
 
     def training_epoch(self, training_state: TrainingState, env_state: State, buffer_state: ReplayBufferState, key: int):
         """sac.py:347-361: num_training_steps_per_epoch training_steps; metrics averaged over the epoch.
@@ -317,17 +335,18 @@ class SAC:
         n = self.num_training_steps_per_epoch
         env_steps_per = self.env_steps_per_actor_step * self.num_env_steps_between_updates
         done_steps = 0
-        if self.use_graph and n >= 3 and (self.dp.group is None or self.p2p is not None):
-            k1, k2 = K.split(key)
-            training_state, env_state, buffer_state = self.training_step(training_state, env_state, buffer_state, k1)
+        self.rekey(key)
+        if self.use_graph and n >= 3 and self._capturable():
+            training_state, env_state, buffer_state = self.training_step(training_state, env_state, buffer_state)
             done_steps = 1
-            gkey = (id(env_state.obs), id(buffer_state.data))
+            gkey, refs = self._graph_signature(env_state, buffer_state)
             if self._graph is None or self._graph_key != gkey:
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    self.training_step(training_state, env_state, buffer_state, k2)
-                self._graph, self._graph_key = graph, gkey
+                    self.training_step(training_state, env_state, buffer_state)
+                # the graph holds raw device pointers: keep every tensor it was captured against alive with it
+                self._graph, self._graph_key, self._graph_refs = graph, gkey, refs
             # capture does not execute: every step from here on is a replay
             for _ in range(n - 1):
                 self._graph.replay()
@@ -337,8 +356,7 @@ class SAC:
                 buffer_state = _advance_mirror(self.replay_buffer, buffer_state, self._rollout_rows.shape[0])
             training_state = training_state.replace(env_steps=training_state.env_steps + (n - 1) * env_steps_per)
         while done_steps < n:
-            key, k = K.split(key)
-            training_state, env_state, buffer_state = self.training_step(training_state, env_state, buffer_state, k)
+            training_state, env_state, buffer_state = self.training_step(training_state, env_state, buffer_state)
             done_steps += 1
         acc = self.updater.metrics_accum.cpu()
         if self.p2p is not None and self.p2p.status() != 0:
@@ -349,6 +367,32 @@ class SAC:
         metrics = {'critic_loss': float(acc[0]) / cnt, 'actor_loss': float(acc[1]) / cnt, 'alpha_loss': float(acc[2]) / cnt,
                    'alpha': float(acc[3]) / cnt, 'buffer_current_size': float(self.replay_buffer.size(buffer_state))}
         return training_state, env_state, buffer_state, metrics
+
+    def _capturable(self) -> bool:
+        """A training_step can be captured when it holds plain kernels only: single rank, the peer-memory exchange, or an
+        RCCL process group (RCCL collectives are stream-ordered kernels and capture; a gloo collective is host code and
+        would invalidate the capture — never attempted)."""
+        if self.dp.group is None or self.p2p is not None:
+            return True
+        import torch.distributed as dist
+        return dist.get_backend(self.dp.group) == "nccl" and os.environ.get("MBPO_GRAPH_NCCL", "1") != "0"
+
+    def _graph_signature(self, env_state: State, buffer_state: ReplayBufferState):
+        """Every device address a captured training_step bakes in (`id()` of two tensors can be recycled)."""
+        spec = self.env.system.rollout_spec(env_state.system_params, self.device)
+        tensors = [env_state.obs, env_state.info['first_obs'], env_state.info['steps'], env_state.done, buffer_state.data,
+                   buffer_state.state, self._rollout_rows, self._batch_rows, self._stats_vec, self._rng]
+        tensors += [v for v in spec.values() if isinstance(v, torch.Tensor)]
+        return tuple(t.data_ptr() for t in tensors), tensors
+
+    def close(self) -> None:
+        """Release the graph and the peer-memory regions (one P2PExchange per trainer: BraxOptimizer.train builds a trainer
+        per call, brax_optimizers.py:95)."""
+        self._graph = self._graph_key = self._graph_refs = None
+        if self.p2p is not None:
+            self.updater.p2p = None
+            self.p2p.close()
+            self.p2p = None
 
     def training_epoch_with_timing(self, training_state, env_state, buffer_state, key):
         """sac.py:363-374 (note: like the reference, `sps` omits the num_env_steps_between_updates factor)."""
@@ -370,8 +414,11 @@ class SAC:
         key, subkey = K.split(key)
         training_state = self.init_training_state(subkey)
         key, rb_key, env_key, eval_key = K.split(key, 4)
-        env_state = self.reset_envs(self.env, env_key, self.num_envs)
-        buffer_state = self.replay_buffer.init(rb_key)
+        # the init key above is shared (rank 0's parameters are broadcast); everything that generates DATA is per rank, or
+        # N ranks would roll out the same envs with the same noise and all-reduce N copies of one gradient
+        rk = self.dp.rank_key
+        env_state = self.reset_envs(self.env, rk(env_key), self.num_envs)
+        buffer_state = self.replay_buffer.init(rk(rb_key))
         evaluator = Evaluator(self, self.eval_env, num_eval_envs=self.num_eval_envs, episode_length=self.episode_length_eval,
                               action_repeat=self.action_repeat, key=eval_key)
         all_metrics: List[Metrics] = []
@@ -385,13 +432,14 @@ class SAC:
             all_metrics.append(metrics)
             progress_fn(0, metrics)
         key, prefill_key = K.split(key)
-        training_state, env_state, buffer_state, _ = self.prefill_replay_buffer(training_state, env_state, buffer_state, prefill_key)
+        training_state, env_state, buffer_state, _ = self.prefill_replay_buffer(training_state, env_state, buffer_state,
+                                                                                 rk(prefill_key))
         if self.eval_key_fixed:
             key, eval_key = K.split(key)
         for _ in range(self.num_evals_after_init):
             key, epoch_key = K.split(key)
             training_state, env_state, buffer_state, training_metrics = self.training_epoch_with_timing(
-                training_state, env_state, buffer_state, epoch_key)
+                training_state, env_state, buffer_state, rk(epoch_key))
             if not self.eval_key_fixed:
                 key, eval_key = K.split(key)
             metrics = evaluator.run_evaluation(training_state.get_policy_params(), training_metrics, unroll_key=eval_key)
@@ -460,11 +508,25 @@ class Evaluator:
         rows = ops.model_rollout(policy_params=pol, policy_spec=t.policy_spec, x_dim=t.x_dim, u_dim=t.u_dim, obs=st.obs,
                                  first_obs=st.info['first_obs'], steps=st.info['steps'], done=st.done, n_steps=n_steps,
                                  episode_length=self.episode_length, action_repeat=self.action_repeat, norm_mean=nm,
-                                 norm_std=ns, deterministic=t.deterministic_eval, seed=unroll_key, offset=t._next_offset(), **spec)
-        rew = rows[:, t.x_dim + t.u_dim].reshape(n_steps, self.num_eval_envs).sum(dim=0)
-        episode_reward = float(rew.mean())
+                                 norm_std=ns, deterministic=t.deterministic_eval, seed=unroll_key, offset=0, **spec)
+        episode_reward, episode_steps = eval_metrics_from_rows(rows, t.x_dim, t.u_dim, n_steps, self.num_eval_envs, self.action_repeat)
+        self.last_episode_rewards, self.last_episode_steps = episode_reward, episode_steps
         epoch_eval_time = time.time() - t0
         self._eval_walltime += epoch_eval_time
-        return {'eval/walltime': self._eval_walltime, **training_metrics, 'eval/episode_reward': episode_reward,
-                'eval/avg_episode_length': float(self.episode_length), 'eval/epoch_eval_time': epoch_eval_time,
+        return {'eval/walltime': self._eval_walltime, **training_metrics, 'eval/episode_reward': float(episode_reward.mean()),
+                'eval/avg_episode_length': float(episode_steps.mean()), 'eval/epoch_eval_time': epoch_eval_time,
                 'eval/sps': self._steps_per_unroll / max(epoch_eval_time, 1e-9)}
+
+
+def eval_metrics_from_rows(rows: torch.Tensor, x_dim: int, u_dim: int, n_steps: int, n_envs: int, action_repeat: int):
+    """EvalWrapper's bookkeeping (brax_utils/training.py:156-199) from the step-major transition rows of one unroll:
+        active_0 = 1;  episode_reward += reward_t * active_t;  episode_steps = info['steps'] while active_t;
+        active_{t+1} = active_t * (1 - done_t)                       (rows carry discount_t = 1 - done_t, sac/acting.py:50)
+    info['steps'] counts action_repeat per env step from the reset (training.py:98), so while an episode is active it is
+    (t + 1) * action_repeat.  Returns (episode_reward [N], episode_steps [N])."""
+    rew = rows[:, x_dim + u_dim].reshape(n_steps, n_envs)
+    disc = rows[:, x_dim + u_dim + 1].reshape(n_steps, n_envs)
+    active = torch.ones_like(disc)
+    if n_steps > 1:
+        active[1:] = torch.cumprod(disc[:-1], dim=0)
+    return (rew * active).sum(dim=0), active.sum(dim=0) * float(action_repeat)

@@ -62,6 +62,22 @@ class DataParallel:
         return range(self.rank * per, (self.rank + 1) * per)
 
 
+def run_agreed_stages(stages, agree) -> bool:
+    """Run `stages` (callables returning a rank-local ok flag; they may contain collectives) one after the other, with an
+    agreement after EVERY stage: `agree(ok)` is a collective that returns True only if every rank's ok was True.  A rank whose
+    stage fails (returns False or raises) still takes part in that stage's agreement and no rank starts the next stage unless
+    all ranks passed this one — so the ranks' collective sequences can never diverge (a rank-local early return
+    before a stage that contains collectives deadlocks the other ranks).  Returns True iff every stage passed everywhere."""
+    for stage in stages:
+        try:
+            ok = bool(stage())
+        except Exception:      # noqa: BLE001 — any local failure means "not ok", never a skipped collective
+            ok = False
+        if not agree(ok):
+            return False
+    return True
+
+
 class P2PExchange:
     """Peer-memory exchange regions for the one-shot all-reduce (csrc/p2p.hpp): every rank allocates a region, the 64-byte IPC
     handles travel through the process group (all_gather_object), every rank maps every peer's region.
@@ -118,14 +134,9 @@ class P2PExchange:
         if not agree(ok):
             ex.close()
             return None
-        # 3. three exchanges against the library all-reduce
-        ok = True
-        try:
-            ok = ex._self_check()
-        except Exception as e:      # noqa: BLE001
-            ok = False
-            ex._err = repr(e)
-        if not agree(ok):
+        # 3. three exchanges against the library all-reduce, then — only if EVERY rank passed them — the timing of both
+        #    (the timing stage contains collectives of its own: it must not start on some ranks only)
+        if not run_agreed_stages([ex._check_correctness, ex._check_timing], agree):
             ex.close()
             return None
         return ex
@@ -169,7 +180,7 @@ class P2PExchange:
         self._hip.check(self.lib.mbpo_p2p_status(C.byref(self.desc), C.byref(v)), "mbpo_p2p_status")
         return int(v.value)
 
-    def _self_check(self) -> bool:
+    def _check_correctness(self) -> bool:
         import torch.distributed as dist
         n = min(self.n_max, 4099)
         ok = True
@@ -177,14 +188,22 @@ class P2PExchange:
             g = torch.Generator().manual_seed(1000 * it + self.dp.rank)
             x = torch.randn(n, generator=g).to(self.device)
             ref = x.clone()
-            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.dp.group)
-            self.all_reduce_sum(x)
-            torch.cuda.synchronize()
-            ok = ok and self.status() == 0 and bool(torch.isfinite(x).all()) and torch.allclose(x, ref, rtol=1e-5, atol=1e-5)
-        if not ok:
-            return False
-        # a mapping that works but is pathologically slow (e.g. peer stores routed over PCIe) must not replace the library
-        # collective: time both on a gradient-sized vector; every rank runs the same loops (the exchange is a collective)
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.dp.group)      # issued on every rank whatever happened before
+            try:
+                self.all_reduce_sum(x)       # bounded waits inside: a missing peer ends in a status flag, not a hang
+                torch.cuda.synchronize()
+                ok = ok and self.status() == 0 and bool(torch.isfinite(x).all()) and torch.allclose(x, ref, rtol=1e-5, atol=1e-5)
+            except Exception as e:      # noqa: BLE001
+                ok = False
+                self._err = repr(e)
+        if os.environ.get("MBPO_P2P_TEST_FAIL_RANK") == str(self.dp.rank):     # test hook: this rank reports a failed check
+            ok = False
+        return ok
+
+    def _check_timing(self) -> bool:
+        """A mapping that works but is pathologically slow (e.g. peer stores routed over PCIe) must not replace the library
+        collective: time both on a gradient-sized vector; every rank runs the same loops (the exchange is a collective)."""
+        import torch.distributed as dist
         n = self.n_max
         x = torch.zeros(n, device=self.device)
         y = torch.zeros(n, device=self.device)

@@ -85,12 +85,16 @@ class UniformSamplingQueue:
                           head=(bs.head - roll) % mx)
 
     def sample_rows(self, bs: ReplayBufferState, n: Optional[int] = None, out: Optional[torch.Tensor] = None,
-                    offset_dev: Optional[torch.Tensor] = None) -> Tuple[ReplayBufferState, torch.Tensor]:
+                    rng_dev: Optional[torch.Tensor] = None, seed: Optional[int] = None, offset: int = 0
+                    ) -> Tuple[ReplayBufferState, torch.Tensor]:
+        """`seed` overrides the key-derived sample seed (the trainers pass 0 and key the draw through `rng_dev`, so that a
+        captured hipGraph and the eager path draw the same indices)."""
         n = self.sample_batch_size if n is None else n
         if self.size(bs) <= 0:
             raise ValueError("cannot sample from an empty replay buffer")
         key, sample_key = K.split(bs.key)          # QueueBase.sample_internal: key, sample_key = split(key)
-        rows = ops.replay_sample(bs.data, bs.state, n, seed=sample_key, offset=0, out=out, offset_dev=offset_dev)
+        rows = ops.replay_sample(bs.data, bs.state, n, seed=sample_key if seed is None else seed, offset=offset, out=out,
+                                 rng_dev=rng_dev)
         return bs.replace(key=key, sample_count=bs.sample_count + 1), rows
 
     def logical_data(self, bs: ReplayBufferState) -> torch.Tensor:

@@ -10,6 +10,8 @@ M1 = np.uint64(0xCD9E8D57)
 W0 = np.uint32(0x9E3779B9)
 W1 = np.uint32(0xBB67AE85)
 
+MASK64 = (1 << 64) - 1
+
 STREAM_POLICY_NOISE = 1
 STREAM_MODEL_NOISE = 2
 STREAM_MEMBER = 3
@@ -71,3 +73,22 @@ def philox_randint(seed: int, offset: int, stream: int, idx: np.ndarray, lo: int
     r0, _, _, _ = philox4x32_10(*_counters(seed, offset, stream, idx))
     span = np.uint64(hi - lo)
     return (np.int64(lo) + ((r0.astype(np.uint64) * span) >> np.uint64(32)).astype(np.int64)).astype(np.int32)
+
+
+def resolve(seed: int, offset: int, rng=None):
+    """csrc/common.hpp:rng_resolve — the device RNG words {seed word, step counter} are ADDED to the host (seed, offset), mod 2^64."""
+    if rng is None:
+        return seed & MASK64, offset & MASK64
+    return (seed + int(rng[0])) & MASK64, (offset + int(rng[1])) & MASK64
+
+
+def philox_u32(seed: int, offset: int, stream: int, idx: np.ndarray) -> np.ndarray:
+    """Word 0 of the Philox block of each element index."""
+    r0, _, _, _ = philox4x32_10(*_counters(seed, offset, stream, idx))
+    return r0
+
+
+def philox_permutation(seed: int, offset: int, n: int) -> np.ndarray:
+    """csrc/replay.hip:mbpo_philox_permutation — stable argsort of the PERM-stream keys."""
+    keys = philox_u32(seed, offset, STREAM_PERM, np.arange(n, dtype=np.uint64))
+    return np.argsort(keys, kind="stable").astype(np.int32)

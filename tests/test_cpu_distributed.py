@@ -94,6 +94,40 @@ def _worker(rank, world, port, tmpdir):
         sv_new = stats[1 + X:1 + 2 * X] + sums[1 + X:].numpy()
         ref = orep.stats_update(stats, obs, dtype=np.float64)
         np.testing.assert_allclose(np.concatenate([[count], mean_new, sv_new]), ref[:1 + 2 * X], rtol=1e-12)
+        # ---- staged agreement (P2PExchange.create): rank 1 fails stage 1; stage 2 holds a collective and must then run on
+        #      NO rank (if rank 0 entered it alone it would pair its all_reduce with rank 1's next collective and hang)
+        from mbpo.parallel import run_agreed_stages
+        ran = []
+
+        def agree(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag) == 1
+
+        def stage1():
+            ran.append(1)
+            return rank != 1
+
+        def stage2():
+            ran.append(2)
+            dist.all_reduce(torch.zeros(1))
+            return True
+
+        assert run_agreed_stages([stage1, stage2], agree) is False and ran == [1]
+        ran.clear()
+
+        def stage_raises():
+            ran.append(1)
+            if rank == 0:
+                raise RuntimeError("local failure")
+            return True
+
+        assert run_agreed_stages([stage_raises, stage2], agree) is False and ran == [1]
+        ran.clear()
+        assert run_agreed_stages([lambda: True, stage2], agree) is True and ran == [2]
+        marker = torch.tensor([float(rank)])
+        dist.all_reduce(marker)                              # the ranks' collective sequences are still aligned
+        assert float(marker) == sum(range(world))
         (Path(tmpdir) / f"ok{rank}").write_text("ok")
     finally:
         dist.destroy_process_group()

@@ -125,50 +125,6 @@ def test_sac_optimizer_learns_pendulum(dev):
     assert abs(rewards[-1]) <= 0.1
 
 
-def test_sac_trainer_graph_path_matches_eager(dev):
-    """training_epoch through the captured hipGraph vs the same epoch run eagerly: same optimizer-step count, same replay
-    positions (device == host mirror), same number of normalised observations, finite parameters, comparable losses.
-    (Not bit-identical: the graph bakes the host seeds of its captured step; the device counters make replays differ.)"""
-    from mbpo.optimizers.policy_optimizers.sac.sac import SAC
-    from mbpo.replay import UniformSamplingQueue
-    from mbpo.systems import EnsembleDynamics, EnsembleSystem, QuadraticReward
-    from mbpo.systems.brax_wrapper import BraxWrapper
-    from mbpo.types import Transition
-    X, U = 4, 1
-    results = []
-    for use_graph in (False, True):
-        dyn = EnsembleDynamics(X, U, n_members=5, device=dev)
-        system = EnsembleSystem(dyn, QuadraticReward(X, U))
-        sp = system.init_params(1)
-        sp.dynamics_params.params.mul_(0.5)
-        dummy = Transition(observation=torch.zeros(X), action=torch.zeros(U), reward=torch.zeros(1), discount=torch.zeros(1),
-                           next_observation=torch.zeros(X))
-        tb = UniformSamplingQueue(256, dummy, 1, device=dev)
-        tbs = tb.insert_rows(tb.init(0), torch.randn(256, 2 * X + U + 2, generator=torch.Generator().manual_seed(0)).to(dev))
-        env = BraxWrapper(system, sp, tbs, tb)
-        tr = SAC(environment=env, num_timesteps=64 * 5 * 6, episode_length=5, num_env_steps_between_updates=5, num_envs=64,
-                 batch_size=32, grad_updates_per_step=4, normalize_observations=True, max_replay_size=1000, min_replay_size=64,
-                 use_graph=use_graph)
-        assert tr.num_training_steps_per_epoch >= 3
-        ts = tr.init_training_state(7)
-        es = tr.reset_envs(env, 11, 64)
-        bs = tr.replay_buffer.init(13)
-        ts, es, bs, _ = tr.prefill_replay_buffer(ts, es, bs, 17)
-        ts, es, bs, metrics = tr.training_epoch(ts, es, bs, 19)
-        torch.cuda.synchronize()
-        assert (tr._graph is not None) == use_graph
-        dev_state = bs.state.cpu().tolist()
-        assert dev_state[0] == bs.insert_position and dev_state[1] == bs.sample_position and dev_state[2] == bs.head
-        results.append((tr.updater.params.cpu().clone(), es.obs.cpu().clone(), tr._stats_vec.cpu().clone(), metrics,
-                        float(tr.updater.step_count.cpu())))
-    (p0, o0, s0, m0, c0), (p1, o1, s1, m1, c1) = results
-    assert c0 == c1   # same number of optimizer steps
-    # the graph epoch uses different host seeds for steps >= 2 (they are baked at capture), so compare statistics, not bits
-    assert torch.isfinite(p1).all() and torch.isfinite(o1).all()
-    assert abs(m0['critic_loss'] - m1['critic_loss']) / max(abs(m0['critic_loss']), 1e-6) < 0.5
-    assert s0[0] == s1[0]                                                      # same number of observations normalised
-
-
 @pytest.mark.timeout(900)
 def test_ppo_optimizer_learns_pendulum(dev):
     """The reference's PPO acceptance test (tests/test_ppo.py:21-89) on the HIP path: the reference's configuration verbatim
