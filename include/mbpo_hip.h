@@ -400,6 +400,9 @@ int mbpo_adamw_step(float *params, const float *grads, float *adam_m, float *ada
                     float wd, float grad_scale, int32_t apply_if_finite, float *target, float tau, float *grad_norm_out,
                     float *workspace, void *stream);
 
+/* soft_update alone (utils/optimizer_utils.py:155-161): out = (1 - tau) * target + tau * online; out may alias target. */
+int mbpo_soft_update(const float *target, const float *online, float *out, int64_t n, float tau, void *stream);
+
 /* ---- N3: ensemble model learning (the step before the rollout path) ------------------------------------
  * Not in the reference (its model would come from the external `bsm` package, setup.py:22).  Gradient of every member's
  * Gaussian negative log-likelihood on its own minibatch of true transitions, with exactly the parameterisation the rollout

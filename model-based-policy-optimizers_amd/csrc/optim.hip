@@ -108,3 +108,22 @@ extern "C" int mbpo_adamw_step(float *params, const float *grads, float *adam_m,
   MBPO_CHECK_LAUNCH("adamw_step");
   return MBPO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ soft_update (Polyak) alone
+// replaces: mbpo/utils/optimizer_utils.py:155-161 — out = (1 - tau) * target + tau * online, with (1 - tau) formed in double on
+// the host exactly as the fused optimizer kernels do (k_sac_apply, k_adamw_step).  out may alias target.
+__global__ void __launch_bounds__(256) k_soft_update(const float *target, const float *online, float *out, long long n, float one_minus_tau, float tau) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i] = one_minus_tau * target[i] + tau * online[i];
+}
+
+extern "C" int mbpo_soft_update(const float *target, const float *online, float *out, int64_t n, float tau, void *stream) {
+  MBPO_REQUIRE(n >= 0, MBPO_ERR_ARG, "soft_update: negative n");
+  if (n == 0) return MBPO_OK;
+  MBPO_REQUIRE(target && online && out, MBPO_ERR_ARG, "soft_update: null pointer");
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_soft_update, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, target, online, out,
+                     (long long)n, (float)(1.0 - (double)tau), tau);
+  MBPO_CHECK_LAUNCH("soft_update");
+  return MBPO_OK;
+}

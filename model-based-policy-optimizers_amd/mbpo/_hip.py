@@ -203,6 +203,7 @@ def _bind_optional(lib: C.CDLL) -> None:
         "mbpo_critic_grads": [vp, i32, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp],
         "mbpo_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, i32, vp, f32, vp, vp, vp],
         "mbpo_rng_advance": [vp, u64, vp],
+        "mbpo_soft_update": [vp, vp, vp, i64, f32, vp],
         "mbpo_philox_permutation": [u64, u64, vp, i64, vp, vp, vp],
     }
     for name, argtypes in sigs.items():

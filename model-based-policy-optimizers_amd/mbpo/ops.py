@@ -110,8 +110,19 @@ def model_rollout(*, policy_params: Optional[torch.Tensor] = None, policy_spec: 
                   deterministic: bool = False, ppo_extras: bool = False, env_major: bool = False, action_clip: float = 0.0,
                   policy_noise: Optional[torch.Tensor] = None, model_noise: Optional[torch.Tensor] = None,
                   member_idx: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0,
-                  rng_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Fused S-step model rollout for N envs (R1-R8).  Updates obs/steps/done in place; returns rows [S*N, D]."""
+                  rng_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                  system=None, system_params=None, system_params_out: Optional[list] = None) -> torch.Tensor:
+    """Fused S-step model rollout for N envs (R1-R8).  Updates obs/steps/done in place; returns rows [S*N, D].
+    system_kind == SYS_GENERIC (a user-defined `system`): the same contract through generic_rollout below."""
+    if system_kind == _hip.SYS_GENERIC:
+        if model_noise is not None or member_idx is not None:
+            raise ValueError("model_noise / member_idx belong to the fused ensemble; a user-defined System draws its own randomness")
+        return generic_rollout(system=system, system_params=system_params, system_params_out=system_params_out,
+                               policy_params=policy_params, policy_spec=policy_spec, x_dim=x_dim, u_dim=u_dim, actions=actions,
+                               obs=obs, first_obs=first_obs, steps=steps, done=done, n_steps=n_steps,
+                               episode_length=episode_length, action_repeat=action_repeat, norm_mean=norm_mean, norm_std=norm_std,
+                               deterministic=deterministic, ppo_extras=ppo_extras, env_major=env_major, action_clip=action_clip,
+                               policy_noise=policy_noise, seed=seed, offset=offset, rng_dev=rng_dev, out=out)
     lib = load()
     n_envs = obs.shape[0]
     D = transition_row_len(x_dim, u_dim, ppo_extras)
@@ -170,6 +181,113 @@ def model_rollout(*, policy_params: Optional[torch.Tensor] = None, policy_spec: 
     d.obs, d.first_obs, d.steps, d.done = obs.data_ptr(), first_obs.data_ptr(), steps.data_ptr(), done.data_ptr()
     d.transitions, d.row_len = out.data_ptr(), D
     check(lib.mbpo_model_rollout(C.byref(d), current_stream_ptr()), "mbpo_model_rollout")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ user-defined System (non-fused)
+def policy_act(policy_params: torch.Tensor, policy_spec: MlpSpec, obs: torch.Tensor, norm_mean=None, norm_std=None,
+               deterministic: bool = False, action_clip: float = 0.0, noise: Optional[torch.Tensor] = None, seed: int = 0,
+               offset: int = 0, rng_dev: Optional[torch.Tensor] = None, elem_base: int = 0, want_extras: bool = False,
+               workspace: Optional[torch.Tensor] = None):
+    """mbpo_policy_act: action [n,u] (and raw_action [n,u], log_prob [n] when want_extras) = policy(obs)."""
+    lib = load()
+    _req(obs, "obs")
+    n, X = obs.shape
+    U = policy_spec.dims[-1] // 2
+    if X != policy_spec.dims[0]:
+        raise ValueError(f"obs must be [n,{policy_spec.dims[0]}]")
+    action = torch.empty(n, U, device=obs.device, dtype=torch.float32)
+    raw = torch.empty(n, U, device=obs.device, dtype=torch.float32) if want_extras else None
+    lp = torch.empty(n, device=obs.device, dtype=torch.float32) if want_extras else None
+    need = n * (X + 2 * U)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 1), device=obs.device, dtype=torch.float32)
+    if noise is not None:
+        _req(noise, "noise")
+        if noise.numel() != n * U:
+            raise ValueError("noise must be [n,u]")
+    d = policy_spec.desc(policy_params)
+    check(lib.mbpo_policy_act(C.byref(d), obs.data_ptr(), n, ptr(norm_mean), ptr(norm_std), int(deterministic), float(action_clip),
+                              ptr(noise), seed, offset, rng_ptr(rng_dev), int(elem_base), action.data_ptr(), ptr(raw), ptr(lp),
+                              workspace.data_ptr(), current_stream_ptr()), "mbpo_policy_act")
+    return (action, raw, lp) if want_extras else action
+
+
+def episode_step(*, x_dim: int, u_dim: int, episode_length: int, action_repeat: int, ppo_extras: bool, env_major: bool,
+                 step_index: int, n_steps: int, action, reward, x_next, first_obs, obs, steps, done, rows, raw_action=None,
+                 log_prob=None, sys_done=None) -> None:
+    """mbpo_episode_step: Episode/AutoReset bookkeeping + the Transition row of env step `step_index`."""
+    lib = load()
+    for t, nm in ((action, "action"), (reward, "reward"), (x_next, "x_next"), (first_obs, "first_obs"), (obs, "obs"), (steps, "steps"),
+                  (done, "done"), (rows, "rows")):
+        _req(t, nm)
+    n = obs.shape[0]
+    if x_next.shape != (n, x_dim) or action.shape != (n, u_dim) or reward.shape != (n,):
+        raise ValueError(f"System.step must return x_next [{n},{x_dim}] and reward [{n}] for actions [{n},{u_dim}]; got "
+                         f"{tuple(x_next.shape)}, {tuple(reward.shape)}, {tuple(action.shape)}")
+    d = _hip.EpisodeStepDesc()
+    d.x_dim, d.u_dim, d.n_envs, d.episode_length, d.action_repeat = x_dim, u_dim, n, episode_length, action_repeat
+    d.ppo_extras, d.env_major, d.step_index, d.n_steps = int(ppo_extras), int(env_major), step_index, n_steps
+    d.action, d.raw_action, d.log_prob = action.data_ptr(), ptr(raw_action), ptr(log_prob)
+    d.reward, d.x_next, d.sys_done, d.first_obs = reward.data_ptr(), x_next.data_ptr(), ptr(sys_done), first_obs.data_ptr()
+    d.obs, d.steps, d.done, d.transitions, d.row_len = obs.data_ptr(), steps.data_ptr(), done.data_ptr(), rows.data_ptr(), rows.shape[1]
+    check(lib.mbpo_episode_step(C.byref(d), current_stream_ptr()), "mbpo_episode_step")
+
+
+def generic_rollout(*, system, system_params, system_params_out: Optional[list] = None, policy_params=None, policy_spec=None,
+                    x_dim: int, u_dim: int, actions=None, obs, first_obs, steps, done, n_steps: int, episode_length: int,
+                    action_repeat: int = 1, norm_mean=None, norm_std=None, deterministic: bool = False, ppo_extras: bool = False,
+                    env_major: bool = False, action_clip: float = 0.0, policy_noise=None, seed: int = 0, offset: int = 0,
+                    rng_dev=None, out=None) -> torch.Tensor:
+    """The contract of model_rollout for a USER-DEFINED System (the reference's plug-in seam, base_systems.py:40-52): per env step
+    mbpo_policy_act (HIP) -> system.step(obs [N,x], action [N,u], system_params) x action_repeat (the user's batched torch code on
+    the device; rewards summed, brax_utils/training.py:92-97) -> mbpo_episode_step (HIP).  Same Philox stream as the fused kernel.
+    The final system_params are appended to `system_params_out` (the reference carries them in the env State)."""
+    if system is None or system_params is None:
+        raise ValueError("a user-defined System needs `system` and `system_params`")
+    for t, nm in ((obs, "obs"), (first_obs, "first_obs"), (steps, "steps"), (done, "done")):
+        _req(t, nm)
+    N = obs.shape[0]
+    D = transition_row_len(x_dim, u_dim, ppo_extras)
+    if out is None:
+        out = torch.empty((n_steps * N, D), device=obs.device, dtype=torch.float32)
+    elif out.shape != (n_steps * N, D):
+        raise ValueError(f"out must be [{n_steps * N},{D}]")
+    if actions is None and (policy_params is None or policy_spec is None):
+        raise ValueError("need either a policy (policy_params, policy_spec) or open-loop actions")
+    if actions is not None:
+        _req(actions, "actions")
+        if ppo_extras:
+            raise ValueError("ppo_extras needs a policy")
+        actions = actions.reshape(n_steps, N, u_dim)
+    if policy_noise is not None:
+        policy_noise = policy_noise.reshape(n_steps, N, u_dim)
+    ws = torch.empty(max(N * (x_dim + 2 * u_dim), 1), device=obs.device, dtype=torch.float32)
+    sp = system_params
+    for s in range(n_steps):
+        raw = lp = None
+        if actions is not None:
+            act = actions[s].contiguous()
+        else:
+            res = policy_act(policy_params, policy_spec, obs, norm_mean, norm_std, deterministic, action_clip,
+                             None if policy_noise is None else policy_noise[s].contiguous(), seed, offset, rng_dev,
+                             elem_base=s * N * u_dim, want_extras=ppo_extras, workspace=ws)
+            act, raw, lp = res if ppo_extras else (res, None, None)
+        x, reward, sys_done = obs, None, None
+        for _ in range(action_repeat):                              # EpisodeWrapper.step :92-97
+            st = system.step(x, act, sp)
+            x, sp = st.x_next, st.system_params
+            r = torch.as_tensor(st.reward, device=obs.device, dtype=torch.float32).reshape(-1).expand(N)
+            reward = r if reward is None else reward + r
+            sys_done = st.done
+        sys_done = None if isinstance(sys_done, (int, float)) and sys_done == 0 else \
+            torch.as_tensor(sys_done, device=obs.device, dtype=torch.float32).reshape(-1).expand(N).contiguous()
+        episode_step(x_dim=x_dim, u_dim=u_dim, episode_length=episode_length, action_repeat=action_repeat, ppo_extras=ppo_extras,
+                     env_major=env_major, step_index=s, n_steps=n_steps, action=act, reward=reward.contiguous(),
+                     x_next=x.to(torch.float32).contiguous(), first_obs=first_obs, obs=obs, steps=steps, done=done, rows=out,
+                     raw_action=raw, log_prob=lp, sys_done=sys_done)
+    if system_params_out is not None:
+        system_params_out.append(sp)
     return out
 
 

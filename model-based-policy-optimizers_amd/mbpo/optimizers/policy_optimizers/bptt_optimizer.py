@@ -317,6 +317,10 @@ class BPTTOptimizer(BaseOptimizer):
     # -- one train step on the working buffers ----------------------------------------------------------------------
     def _system_kwargs(self, system_params):
         spec = self.system.rollout_spec(system_params, self.device)
+        if spec["system_kind"] == _hip.SYS_GENERIC:
+            raise _hip.MbpoHipError("BPTT differentiates THROUGH the model inside one kernel (csrc/bptt.hip): the system must exist as "
+                                    "device code (PendulumSystem, EnsembleSystem in 'mean' mode); a user-defined torch System cannot be "
+                                    "back-propagated through on this path (INTEGRATION.md)")
         if spec["system_kind"] == _hip.SYS_ENSEMBLE and spec.get("ens_mode", _hip.ENS_MEAN) != _hip.ENS_MEAN:
             raise _hip.MbpoHipError("BPTT needs a differentiable model: EnsembleSystem mode must be 'mean'")
         if spec.get("ens_sample_noise", False):

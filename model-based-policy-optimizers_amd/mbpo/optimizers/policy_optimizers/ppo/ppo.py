@@ -217,13 +217,17 @@ class PPO:
         spec = self.env.system.rollout_spec(state.system_params, self.device)
         n_unrolls = self.batch_size * self.num_minibatches // self.num_envs
         N, T = self.num_envs, self.unroll_length
+        sp_out: list = []
         for k in range(n_unrolls):                                                               # scan :194-208
             ops.model_rollout(policy_params=training_state.params.policy, policy_spec=self.policy_spec, x_dim=self.x_dim,
                               u_dim=self.u_dim, obs=state.obs, first_obs=state.info['first_obs'], steps=state.info['steps'],
                               done=state.done, n_steps=T, episode_length=self.episode_length, action_repeat=self.action_repeat,
                               norm_mean=nm, norm_std=ns, ppo_extras=True, env_major=True, seed=0,
                               offset=(SITE_UNROLL + k) << 32, rng_dev=self._rng,
-                              out=self._data[k * N:(k + 1) * N].reshape(N * T, self.row_len), **spec)
+                              out=self._data[k * N:(k + 1) * N].reshape(N * T, self.row_len), system_params_out=sp_out, **spec)
+            if sp_out:
+                state = state.replace(system_params=sp_out[-1])
+                spec = self.env.system.rollout_spec(state.system_params, self.device)
         # running_statistics.update(normalizer_params, data.observation)   (:216-219)
         rows = self._data.reshape(-1, self.row_len)
         ops.running_stats_update(rows, 0, self.x_dim, training_state.normalizer_params.vec, all_reduce=self._all_reduce,

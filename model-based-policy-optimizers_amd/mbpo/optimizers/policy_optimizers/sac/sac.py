@@ -276,12 +276,15 @@ class SAC:
             self.rekey(key)
         nm, ns = self._norm(normalizer_params)
         spec = self.env.system.rollout_spec(env_state.system_params, self.device)
+        sp_out: list = []
         rows = ops.model_rollout(policy_params=policy_params, policy_spec=self.policy_spec, x_dim=self.x_dim, u_dim=self.u_dim,
                                  obs=env_state.obs, first_obs=env_state.info['first_obs'], steps=env_state.info['steps'],
                                  done=env_state.done, n_steps=self.num_env_steps_between_updates,
                                  episode_length=self.episode_length, action_repeat=self.action_repeat, norm_mean=nm,
                                  norm_std=ns, seed=0, offset=SITE_ROLLOUT << 32, rng_dev=self._rng,
-                                 out=self._rollout_rows, **spec)
+                                 out=self._rollout_rows, system_params_out=sp_out, **spec)
+        if sp_out:      # a user-defined System returns its (possibly updated) parameters: carried in the env State, as upstream
+            env_state = env_state.replace(system_params=sp_out[-1])
         # running_statistics.update(normalizer_params, transitions.observation, pmap_axis_name)   (:298-301)
         ops.running_stats_update(rows, 0, self.x_dim, normalizer_params.vec, all_reduce=self._all_reduce,
                                  sums=self._stats_sums, workspace=self._stats_ws)
@@ -372,6 +375,8 @@ class SAC:
         """A training_step can be captured when it holds plain kernels only: single rank, the peer-memory exchange, or an
         RCCL process group (RCCL collectives are stream-ordered kernels and capture; a gloo collective is host code and
         would invalidate the capture — never attempted)."""
+        if not self.env.system.fused:      # user code runs between the kernels: it may synchronise or allocate
+            return False
         if self.dp.group is None or self.p2p is not None:
             return True
         import torch.distributed as dist

@@ -50,8 +50,13 @@ class System(ABC, Generic[DynamicsParams, RewardParams]):
         return SystemParams(dynamics_params=None, reward_params=None, key=axes)
 
     def step(self, x: torch.Tensor, u: torch.Tensor, system_params: SystemParams) -> SystemState:
-        """One fused launch of the rollout kernel with open-loop actions and S=1 (csrc/rollout.hip)."""
+        """Systems that exist as device code (PendulumSystem, EnsembleSystem): one fused launch of the rollout kernel with
+        open-loop actions and S=1 (csrc/rollout.hip).  A user-defined System overrides this with its own BATCHED torch code
+        (x [N, x_dim], u [N, u_dim] on the device -> SystemState with x_next [N, x_dim], reward [N]); the trainers then step it
+        between the HIP policy and bookkeeping kernels (ops.generic_rollout)."""
         from mbpo import ops
+        if not self.fused:
+            raise NotImplementedError(f"{type(self).__name__} must define step(x, u, system_params) itself (batched torch code)")
         dev = _device_of(x)
         single = x.dim() == 1
         xb = x.reshape(-1, self.x_dim).to(dev, torch.float32).contiguous().clone()
@@ -73,11 +78,17 @@ class System(ABC, Generic[DynamicsParams, RewardParams]):
         return SystemParams(dynamics_params=self.dynamics.init_params(keys[0]),
                             reward_params=self.reward.init_params(keys[1]), key=keys[2])
 
-    # MI355X seam: keyword arguments describing this system to ops.model_rollout
+    # MI355X seam: keyword arguments describing this system to ops.model_rollout.  PendulumSystem / EnsembleSystem return the
+    # description of their device code (one fused launch per unroll); the default is the non-fused path for a user-defined
+    # System: its own `step` between the HIP policy and episode-bookkeeping kernels.
     def rollout_spec(self, system_params: SystemParams, device) -> dict:
-        raise NotImplementedError(
-            f"{type(self).__name__} has no fused-kernel form.  The MI355X path supports PendulumSystem and EnsembleSystem; "
-            "a Python-defined System cannot run inside the rollout kernel and there is no CPU fallback.")
+        from mbpo import _hip
+        return dict(system_kind=_hip.SYS_GENERIC, system=self, system_params=system_params)
+
+    @property
+    def fused(self) -> bool:
+        """True when the system runs inside the fused rollout kernel (and a training step can be hipGraph-captured)."""
+        return type(self).rollout_spec is not System.rollout_spec
 
 
 def _device_of(t: torch.Tensor) -> torch.device:

@@ -100,6 +100,16 @@ def lambda_return_t(reward, next_values, discount, lambda_):
     return torch.stack(outs, dim=1)
 
 
+def log_prob_steps(mu, sig, action):
+    """Actor.get_log_prob (:144-152) per step: u = atanh(clip(a)); sum_A logN(u; mu, sig) - sum_A log(1 - a^2).
+    At action_dim = 1 its mean over the horizon equals the mean of the reference's [H,1] - [H] broadcast (SURVEY §8a B5;
+    tests/golden/semantics_kat.json: bptt_log_prob)."""
+    a_c = torch.clamp(action, -1 + EPS, 1 - EPS)
+    u = 0.5 * torch.log((1 + a_c) / (1 - a_c))
+    log_l = (-0.5 * ((u - mu) / sig) ** 2 - torch.log(sig) - 0.5 * math.log(2 * math.pi)).sum(-1)
+    return log_l - torch.log(1 - action ** 2).sum(-1)
+
+
 def actor_loss(cfg: BpttConfig, system, actor_params, target_critic_params, init_states, act_noise, s_mean, s_std, r_mean, r_std):
     """vmap(actor_loss) + .mean() over initial states (:361-372).  `system.step` must be differentiable (oracle systems are).
 
@@ -123,10 +133,7 @@ def actor_loss(cfg: BpttConfig, system, actor_params, target_critic_params, init
     obs_n = normalize(observation, s_mean, s_std)                   # :345  (NOT stop-gradiented)
     disc = torch.cat([torch.ones(1, dtype=lam.dtype), torch.full((H - 1,), cfg.discount, dtype=lam.dtype)]).cumprod(0)   # :346-348
     mu, sig = actor_forward(cfg, actor_params, obs_n)               # get_log_prob :144-152
-    a_c = torch.clamp(action, -1 + EPS, 1 - EPS)
-    u = 0.5 * torch.log((1 + a_c) / (1 - a_c))
-    log_l = (-0.5 * ((u - mu) / sig) ** 2 - torch.log(sig) - 0.5 * math.log(2 * math.pi)).sum(-1)
-    log_l = log_l - torch.log(1 - action ** 2).sum(-1)
+    log_l = log_prob_steps(mu, sig, action)
     entropy_loss = -log_l.mean(dim=1)                               # per initial state :351
     loss = -(lam * disc).mean(dim=1) + entropy_loss * cfg.ent_coef   # :352
     aux = dict(entropy_loss=entropy_loss.mean(), lambda_values=lam, observation=observation, action=action, reward=reward,

@@ -92,3 +92,19 @@ def philox_permutation(seed: int, offset: int, n: int) -> np.ndarray:
     """csrc/replay.hip:mbpo_philox_permutation — stable argsort of the PERM-stream keys."""
     keys = philox_u32(seed, offset, STREAM_PERM, np.arange(n, dtype=np.uint64))
     return np.argsort(keys, kind="stable").astype(np.int32)
+
+
+# ---------------------------------------------------------------------------------------------- host keys
+def _splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & MASK64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+    return z ^ (z >> 31)
+
+
+def split(key: int, num: int = 2):
+    """Restatement of the product's host key derivation (mbpo/utils/keys.py: build-defined — JAX's threefry split cannot be
+    reproduced here): `num` child keys by splitmix64."""
+    base = _splitmix64(int(key) & MASK64)
+    return [_splitmix64((base + i * 0xD1B54A32D192ED03) & MASK64) for i in range(num)]

@@ -49,16 +49,19 @@ def env_step(system, st: EnvState, action: torch.Tensor, episode_length: int, ac
     obs = st.obs
     reward = torch.zeros(N, dtype=obs.dtype)
     env_index = torch.arange(N)
+    sys_done = torch.zeros(N, dtype=obs.dtype)                      # SystemState.done default 0.0 (base_systems.py:25)
     for ar in range(action_repeat):  # Episode.step :92-97 — scan over action_repeat, rewards summed
         kw = {}
         if member_idx is not None:
             kw["member_idx"] = member_idx[s, ar]
         if model_noise is not None:
             kw["model_noise"] = model_noise[s, ar]
-        obs, r = system.step(obs, action, env_index=env_index, **kw)
+        res = system.step(obs, action, env_index=env_index, **kw)
+        obs, r = res[0], res[1]
+        if len(res) > 2:                                            # a System that reports termination (SystemState.done)
+            sys_done = res[2].to(obs.dtype)
         reward = reward + r
     steps = steps + action_repeat                                   # :98
-    sys_done = torch.zeros(N, dtype=obs.dtype)                      # SystemState.done default 0.0 (base_systems.py:25)
     over = steps >= episode_length
     done = torch.where(over, torch.ones_like(sys_done), sys_done)   # :102
     trunc = torch.where(over, 1 - sys_done, torch.zeros_like(sys_done))   # :103-105
@@ -103,3 +106,46 @@ def rollout(system, policy_params: torch.Tensor, policy_dims, st: EnvState, n_st
     if env_major:
         rows = rows.permute(1, 0, 2)           # ppo.py:210-213 swapaxes + reshape -> [N*T, D]
     return st, rows.reshape(n_steps * N, D).contiguous()
+
+
+def brax_wrapper_reset(data_logical, insert_position: int, sample_position: int, keys, x_dim: int, u_dim: int):
+    """BraxWrapper.reset under VmapWrapper.reset (systems/brax_wrapper.py:25-38, brax_utils/training.py:66-69): every env draws ONE
+    transition uniformly from the true buffer and starts at its observation; reward = that row's reward, done = 0.
+    The reference gives each env its own key (vmap over split keys); the build draws all N indices from the first key's
+    first split with the env id as the Philox element index — N independent uniform draws either way.  An empty buffer yields
+    index 0 (randint(0, 0) -> 0: the all-zero dummy row, base_optimizer.py:43-57).
+    Returns (idx int32 [N], EnvState, reward [N], system key)."""
+    import numpy as np
+    from . import philox
+    n = len(keys)
+    k0, k1 = philox.split(keys[0])
+    mx = data_logical.shape[0]
+    if insert_position - sample_position > 0:
+        idx = philox.philox_randint(k0, 0, philox.STREAM_REPLAY, np.arange(n, dtype=np.uint64), sample_position, insert_position)
+    else:
+        idx = np.zeros(n, np.int32)
+    rows = data_logical[torch.from_numpy(np.mod(idx.astype(np.int64), mx))]
+    obs = rows[:, :x_dim].clone()
+    return idx, EnvState(obs, obs.clone(), torch.zeros(n), torch.zeros(n)), rows[:, x_dim + u_dim].clone(), k1
+
+
+def evaluate(system, policy_params, policy_dims, first: EnvState, episode_length: int, action_repeat: int = 1, act: str = "swish",
+             norm_mean=None, norm_std=None, deterministic: bool = True, policy_noise=None):
+    """Evaluator.run_evaluation's unroll under EvalWrapper (sac/acting.py:82-145, brax_utils/training.py:156-199), step by step:
+        episode_reward += reward * active;  episode_steps = where(active, info['steps'], episode_steps);  active *= 1 - done
+    over unroll_length = episode_length // action_repeat steps of AutoReset(Vmap(Episode(env))).
+    Returns (episode_reward [N], episode_steps [N])."""
+    n_steps = episode_length // action_repeat
+    st = first.clone()
+    N = st.obs.shape[0]
+    active, ep_reward, ep_steps = torch.ones(N), torch.zeros(N), torch.zeros(N)
+    for s in range(n_steps):
+        logits = nets.mlp_forward(policy_params, policy_dims, nets.normalize(st.obs, norm_mean, norm_std), act)
+        z = nets.split_logits(logits)[0] if deterministic else nets.sample_no_postprocessing(logits, policy_noise[s])
+        nst, reward, _ = env_step(system, st, nets.postprocess(z), episode_length, action_repeat, s)
+        # info['steps'] of the state AFTER the step, before AutoReset zeroes it at the next step (:176-180)
+        ep_steps = torch.where(active != 0, nst.steps, ep_steps)
+        ep_reward = ep_reward + reward * active
+        active = active * (1 - nst.done)
+        st = nst
+    return ep_reward, ep_steps

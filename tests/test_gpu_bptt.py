@@ -70,6 +70,7 @@ def _run_hip(dev, cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, system, extra, n,
     (4, 1, 5, 48, "ensemble", 5),        # north-star shape, horizon 5
     (4, 2, 6, 17, "ensemble", 3),        # u=2 (sum-over-A log-prob), ragged n
     (17, 6, 8, 16, "ensemble", 10),      # BASELINE config 5 shape (shorter horizon for the oracle)
+    (17, 6, 32, 16, "ensemble", 10),     # BASELINE config 5 at its FULL horizon H=32 (E=10, x=17, u=6), one tile of trajectories
 ])
 def test_bptt_actor_grad_parity(dev, X, U, H, n, system, E):
     cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, tsys, extra = _setup(X, U, H, n, system, E, 0)
@@ -115,6 +116,25 @@ def test_bptt_many_tiles_accumulate(dev):
     many = _run_hip(dev, cfg, ap, cp, x0.repeat(reps, 1), noise.repeat(reps, 1, 1), s_mean, s_std, r_ms, "pendulum", extra, n * reps)
     torch.testing.assert_close(many.grads, one.grads, atol=2e-6, rtol=2e-4)
     torch.testing.assert_close(many.metrics, one.metrics, atol=1e-5, rtol=1e-4)
+
+
+def test_bptt_config5_full_size_replication(dev):
+    """BASELINE configs[4] at full size — E=10, H=32, x=17, u=6, n=4096 initial states per GPU — through the size-independent
+    property: the loss is a mean over trajectories, so 4096 = 256 copies of a 16-trajectory batch must give the gradient, the
+    metrics, the simulated transitions and the lambda-values of ONE copy (which test_bptt_actor_grad_parity's H=32 case
+    compares with the oracle).  Copies land in different workgroups / slabs: the cross-tile reduction is what is exercised."""
+    X, U, H, n, E = 17, 6, 32, 16, 10
+    cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, tsys, extra = _setup(X, U, H, n, "ensemble", E, 0)
+    one = _run_hip(dev, cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, "ensemble", extra, n)
+    reps = 256
+    many = _run_hip(dev, cfg, ap, cp, x0.repeat(reps, 1), noise.repeat(reps, 1, 1), s_mean, s_std, r_ms, "ensemble", extra, n * reps)
+    assert many.transitions.shape[0] == 4096 * 32
+    torch.testing.assert_close(many.grads, one.grads, atol=5e-6, rtol=5e-4)
+    torch.testing.assert_close(many.metrics, one.metrics, atol=1e-5, rtol=1e-4)
+    D = one.transitions.shape[1]
+    assert torch.equal(many.transitions.reshape(reps, n * H, D), one.transitions.reshape(1, n * H, D).expand(reps, -1, -1))
+    assert torch.equal(many.lambda_values.reshape(reps, n * H), one.lambda_values.reshape(1, n * H).expand(reps, -1))
+    assert bool(torch.isfinite(many.grads).all())
 
 
 # ------------------------------------------------------------------------------------------------ B4: critic regression

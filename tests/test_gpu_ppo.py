@@ -47,6 +47,8 @@ def _updater(dev, cfg, B, T, **kw):
     (4, 1, (64, 64, 64), 16, 10, True, False),    # no advantage normalisation
     (4, 2, (128, 128), 24, 7, True, True),        # 128-wide, ragged M = 168 (not a multiple of 16), u=2
     (17, 6, (64, 64), 8, 3, False, True),
+    (3, 1, (64, 64, 64), 512, 40, True, True),    # BASELINE configs[2] at FULL size: B=512, T=40 (20 480 samples per minibatch)
+    (4, 1, (64, 64, 64), 512, 5, True, True),     # the same at horizon-5 unrolls
 ])
 def test_ppo_gradients_and_step(dev, X, U, hidden, B, T, normalize, norm_adv):
     cfg, st, data, noise, nm, ns = _make(X, U, hidden, B, T, 0, normalize, entropy_cost=1e-2, discounting=0.99,

@@ -82,7 +82,7 @@ def _pendulum_obs(N, gen):
 
 def _run_rollout_case(dev, *, N, S, L, AR, X, U, system, E=0, mode="mean", sample_noise=False, ppo=False,
                       env_major=False, normalize=False, deterministic=False, hidden=(64, 64, 64), seed=0,
-                      init_steps=None, atol=2e-4):
+                      init_steps=None, atol=2e-4, replicate=0):
     from mbpo import ops, _hip
     g = torch.Generator().manual_seed(seed)
     pdims = [X, *hidden, 2 * U]
@@ -147,6 +147,26 @@ def _run_rollout_case(dev, *, N, S, L, AR, X, U, system, E=0, mode="mean", sampl
     assert torch.equal(done_d.cpu(), st_ref.done)
     torch.testing.assert_close(rows, rows_ref, atol=atol, rtol=atol)
     torch.testing.assert_close(obs_d.cpu(), st_ref.obs, atol=atol, rtol=atol)
+    if replicate:
+        # full-size property: envs are independent, so `replicate` copies of the N envs (in other tiles / workgroups) must
+        # reproduce the N-env rows bit for bit
+        k = replicate
+        rep = lambda t, dim=0: None if t is None else t.repeat_interleave(1, 0).repeat(*[k if d == dim else 1 for d in range(t.dim())]).to(dev)
+        obs_k, steps_k, done_k = rep(obs0), rep(steps0), rep(done0)
+        rows_k = ops.model_rollout(policy_params=ppar.to(dev), policy_spec=ops.MlpSpec(pdims, "swish", 1), x_dim=X, u_dim=U,
+                                   obs=obs_k, first_obs=rep(first), steps=steps_k, done=done_k, n_steps=S, episode_length=L,
+                                   action_repeat=AR, reward_params=rparams.to(dev),
+                                   norm_mean=None if nm is None else nm.to(dev), norm_std=None if ns is None else ns.to(dev),
+                                   deterministic=deterministic, ppo_extras=ppo, env_major=env_major,
+                                   policy_noise=rep(pnoise, 1), model_noise=rep(mnoise, 2), member_idx=rep(midx, 2), **kw)
+        torch.cuda.synchronize()
+        assert rows_k.shape[0] == S * N * k
+        if env_major:
+            want = rows.reshape(N, S, D).repeat(k, 1, 1)
+        else:
+            want = rows.reshape(S, N, D).repeat(1, k, 1)
+        assert torch.equal(rows_k.cpu().reshape(want.shape), want)
+        assert torch.equal(obs_k.cpu(), obs_d.cpu().repeat(k, 1)) and torch.equal(steps_k.cpu(), steps_d.cpu().repeat(k))
     return rows
 
 
@@ -170,6 +190,18 @@ def test_rollout_pendulum_deterministic_128(dev):
 def test_rollout_ensemble_mean_c2_shape(dev):
     # BASELINE config 2 shape: x=4,u=1, E=5, H=5, S=5 (smaller N for the oracle)
     _run_rollout_case(dev, N=512, S=5, L=5, AR=1, X=4, U=1, system="ensemble", E=5, mode="mean")
+
+
+def test_rollout_c2_full_size_replication(dev):
+    """BASELINE configs[1] at FULL size, N = 4096 envs (x=4, u=1, E=5, H=S=5): the 512-env rows are compared with the oracle,
+    then 8 copies of those envs (4096) must reproduce them exactly."""
+    _run_rollout_case(dev, N=512, S=5, L=5, AR=1, X=4, U=1, system="ensemble", E=5, mode="mean", normalize=True, replicate=8)
+
+
+def test_rollout_c3_full_size_replication(dev):
+    """BASELINE configs[2]: PPO collection, N = 16384 envs, unroll T = 40, PPO row layout, env-major — 128 oracle-checked envs x 128."""
+    _run_rollout_case(dev, N=128, S=40, L=40, AR=1, X=3, U=1, system="pendulum", ppo=True, env_major=True, normalize=True,
+                      replicate=128, atol=2e-3)
 
 
 def test_rollout_ensemble_pendulum_shape(dev):
