@@ -249,7 +249,8 @@ int mbpo_gae_scan_discounts(const float *truncation, const float *termination, c
  *                   the live form of the reference's dead jax.lax.pmean, sac/utils.py:29-33)
  * Three entry points so that the multi-GPU exchange sits at the reference's pmean position:
  *   mbpo_sac_grads      : per-sample forward/backward of the three losses on one minibatch -> grads, metrics[0..2]
- *                         (critic_loss, actor_loss, alpha_loss); also bumps step_count and leaves per-group
+ *                         (critic_loss, actor_loss, alpha_loss); also bumps step_count (at the start of the forward/backward
+ *                         launch) and leaves per-group
  *                         sum-of-squares partials of `grads` in the workspace.
  *   mbpo_sac_grad_norms : recompute those partials from `grads` (call after an all-reduce changed it).
  *   mbpo_sac_apply      : grads *= grad_scale; clip_by_global_norm per optimizer; AdamW; target <- (1-tau) target + tau q_new;
@@ -291,12 +292,19 @@ int mbpo_sac_grads(const mbpo_sac_desc *d, void *stream);
 int mbpo_sac_grads_phase(const mbpo_sac_desc *d, int32_t phase_mask, void *stream);
 int mbpo_sac_grad_norms(const mbpo_sac_desc *d, void *stream);
 int mbpo_sac_apply(const mbpo_sac_desc *d, void *stream);
-/* Single-rank one-launch variant (measured SLOWER than grads + apply on MI355X — the device-wide meeting point costs more than
- * the kernel boundary it removes — kept as an option): after mbpo_sac_grads_phase(d, 1) (the fwd/bwd kernel only), this ONE launch reduces the per-tile
- * slabs, forms the global norms (device-wide arrival counter inside the kernel; bounded spin, metrics[0] = NaN and no update
- * if it is not reached) and applies clip + AdamW + Polyak.  Same results as mbpo_sac_grads + mbpo_sac_apply.  The last 4
- * floats of `workspace` are the counters: they must be zero before the first call (they return to zero by themselves). */
-int mbpo_sac_reduce_apply(const mbpo_sac_desc *d, void *stream);
+/* The default path — ONE sgd_step in TWO launches (mbpo_sac_grads + mbpo_sac_apply is three):
+ *   mbpo_sac_step     : the forward/backward kernel, then ONE launch that reduces the per-tile slabs and applies the optimizer step
+ *                       UNCLIPPED, saving the previous (params, adam_m, adam_v, target_q) in an undo log inside `workspace`.
+ *                       clip_by_global_norm needs the global gradient norm, i.e. every block's partial: instead of a device-wide
+ *                       meeting point inside the launch (measured slower than the kernel boundary it removes), the check is done
+ *                       by the NEXT consumer of the parameters — the prologue of the next mbpo_sac_step / mbpo_sac_grads launch, or
+ *                       mbpo_sac_finalize — which, if a group's norm reached max_grad_norm, recomputes that group's step from the
+ *                       undo log with the clipped gradient: bit-identical to mbpo_sac_grads + mbpo_sac_apply in every case.
+ *   mbpo_sac_finalize : resolves the pending check when no further mbpo_sac_step follows (end of training_step's scan of
+ *                       sgd_steps, sac/sac.py:324; before anything else reads params / target_q / adam state).  Idempotent.
+ * metrics[3] ('alpha') of a step becomes valid when its check has been resolved.  `workspace` must be zero before the first call. */
+int mbpo_sac_step(const mbpo_sac_desc *d, void *stream);
+int mbpo_sac_finalize(const mbpo_sac_desc *d, void *stream);
 
 /* ---- P1-P3: PPO minibatch update (ppo/ppo.py:142-156, ppo/losses.py:56-126) -----------------------
  * replaces: PPO.minibatch_step = value_and_grad(PPOLoss.loss) + optax.adamw(lr, wd) over {policy, value} (ppo.py:128,139-140;
@@ -478,6 +486,9 @@ int mbpo_sac_gather_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *st
  * gradient into every region, waits inside the kernel for every rank's arrivals and leaves grads = sum over ranks and the
  * clip-norm partials.  Then mbpo_sac_apply (grad_scale = 1/N).  Needs the reduction's workgroups (NP/256) co-resident. */
 int mbpo_sac_grads_exchange_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream);
+/* mbpo_sac_step over N ranks: the second launch also exchanges (stores the rank's gradient into every region, waits for every rank,
+ * sums the world slots in rank order) before the unclipped optimizer step (grad_scale = 1/N); mbpo_sac_finalize as above. */
+int mbpo_sac_step_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream);
 int mbpo_p2p_status(const mbpo_p2p_desc *d, int32_t *status_out);
 
 #ifdef __cplusplus

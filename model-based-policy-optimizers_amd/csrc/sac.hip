@@ -8,6 +8,13 @@
 //                   bitwise reproducible).
 //   k_sac_reduce    grads[i] = sum over tiles of slab[t][i]; loss metrics; per-group sum-of-squares partials.
 //   k_sac_apply     clip_by_global_norm + AdamW per optimizer group + Polyak on the critics.
+//   k_sac_reduce_apply  (the default path, 2 launches per sgd_step instead of 3) both of the above in ONE launch: the optimizer step
+//                   is applied UNCLIPPED, the previous state goes to an undo log, and the clip decision — which needs the global
+//                   norm, i.e. every block's partial — is resolved by the NEXT consumer of the parameters: the prologue of the
+//                   next k_sac_fwd_bwd, or k_sac_finalize.  clip_by_global_norm(max_grad_norm = 1e5, the reference default,
+//                   sac/sac.py:96) practically never triggers; when it does, the consumer recomputes the clipped step from the
+//                   undo log (same formulas, same order: bit-identical to the three-launch path).  A device-wide meeting point
+//                   inside one launch was measured SLOWER than the kernel boundary it removes (round 1: 48 vs 40 us).
 //
 // Algorithmic work per sample per sgd_step: 2*(5P + 12Q) FLOP — latency-bound at B=256, hence the
 // few fat launches and the slab scheme instead of a tree of small kernels.
@@ -34,6 +41,112 @@ struct SacChainDesc {
   int pad0, pad1;
 };
 
+// Flat optimizer state + what the clip check needs (shared by k_sac_apply, k_sac_reduce_apply, the fix-up and k_sac_finalize).
+struct SacOptArgs {
+  float *params, *target_q, *adam_m, *adam_v, *grads, *metrics, *metrics_accum;
+  float *undo;                  // [3*NP + Q2]: params | adam_m | adam_v | target_q BEFORE the last speculative step
+  const float *step_count, *ss_part;
+  unsigned int *seq;            // [0] speculative steps issued, [1] ... resolved by k_sac_finalize
+  float *undo_count;            // [0] optax count of the last speculative step (step_count itself is bumped again by the next fwd/bwd
+                                //     launch), [1] metrics_accum[3] before that step added its 'alpha', [2..3] its Adam bias corrections
+  int n_parts, P, Q2;
+  float lr[3], wd[3];
+  float max_norm, tau, one_minus_tau, grad_scale;
+};
+
+struct AdamOut {
+  float p, m, v;
+};
+// [3P optax.adamw] scale_by_adam(b1=.9,b2=.999,eps=1e-8) -> add_decayed_weights(wd) -> scale(-lr); optax forms (1 - decay) in Python
+// double and only then casts: f32(0.1), f32(0.001) — not 1.f - 0.999f.  corr0/corr1 = 1 - b^count.
+__device__ __forceinline__ AdamOut sac_adam(float p, float m, float v, float g, float corr0, float corr1, float lr, float wd) {
+  AdamOut o;
+  o.m = 0.9f * m + 0.1f * g;
+  o.v = 0.999f * v + 0.001f * (g * g);
+  const float mu_hat = o.m / corr0;
+  const float nu_hat = o.v / corr1;
+  float upd = mu_hat / (sqrtf(nu_hat) + 1e-8f);
+  upd = upd + wd * p;
+  o.p = p + (-lr) * upd;  // optax.apply_updates: p + u, u = -lr * upd
+  return o;
+}
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// Waves 0..2 of the calling workgroup: gnorm[w] = sqrt(sum of optimizer group w's partials) * grad_scale — the fixed order of
+// k_sac_apply (lane-strided sum, then the shuffle tree): every caller forms bit-identical norms.  Result in s_gn[3] (LDS), valid
+// after the caller's next barrier.
+__device__ __forceinline__ void sac_group_norms(const SacOptArgs &O, float *s_gn, int tid) {
+  const int w = tid >> 6, lane = tid & 63;
+  if (w < 3) {
+    float ss = 0.f;
+    for (int p = lane; p < O.n_parts; p += 64) ss += O.ss_part[p * 3 + w];
+    ss = wave_sum64(ss);
+    if (lane == 0) s_gn[w] = sqrtf(ss) * O.grad_scale;
+  }
+}
+// The same three sums by ONE wave, in two halves, for k_sac_fwd_bwd: requested at the top of the kernel, added up later by a wave
+// that is idle anyway — the waves of the critical policy chain never wait for them.  Lane l holds terms l and l + 64 of every
+// group (all of them for n_parts <= 128: the 64x3 networks have 103), the rest is read in the second half.
+struct NormReq {
+  float a[3], b[3];
+};
+__device__ __forceinline__ NormReq sac_group_norms_request(const SacOptArgs &O, int lane) {
+  NormReq r;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    r.a[w] = lane < O.n_parts ? O.ss_part[lane * 3 + w] : 0.f;
+    r.b[w] = lane + 64 < O.n_parts ? O.ss_part[(lane + 64) * 3 + w] : 0.f;
+  }
+  return r;
+}
+// sac_group_norms' order per group: ss = 0 + term(l) + term(l + 64) + ..., then the shuffle tree.
+__device__ __forceinline__ void sac_group_norms_finish(const SacOptArgs &O, const NormReq &r, float *s_gn, int lane) {
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    float ss = 0.f;
+    if (lane < O.n_parts) ss += r.a[w];
+    if (lane + 64 < O.n_parts) ss += r.b[w];
+    for (int p = lane + 128; p < O.n_parts; p += 64) ss += O.ss_part[p * 3 + w];
+    ss = wave_sum64(ss);
+    if (lane == 0) s_gn[w] = sqrtf(ss) * O.grad_scale;
+  }
+}
+
+// The clip fix-up: recompute, from the undo log, the optimizer step of every element whose group's norm reached max_norm
+// ([3P optax.clip_by_global_norm] g <- g if g_norm < max_norm else (g / g_norm) * max_norm).  Every workgroup that runs this writes
+// the SAME values to the same addresses (inputs: grads, undo, step_count, ss_part — all final since the previous launch), so
+// concurrent callers are benign and the result does not depend on who ran last.
+// (Tried out of line, `noinline`: a call inside k_sac_fwd_bwd made hipcc cap the kernel at 128 VGPRs with 96 of them spilled —
+// 148 us per launch.  It stays inline and k_sac_fwd_bwd keeps it OUTSIDE its phase loop.)
+__device__ __forceinline__ void sac_clip_fixup(const SacOptArgs &O, const float *s_gn, int tid, int nthreads) {
+  const int NP = O.P + O.Q2 + 1;
+  const float corr0 = O.undo_count[2], corr1 = O.undo_count[3];   // 1 - b^count as the speculative step itself formed them
+  const float *u_p = O.undo, *u_m = O.undo + NP, *u_v = O.undo + 2 * NP, *u_tq = O.undo + 3 * NP;
+  for (int i = tid; i < NP; i += nthreads) {
+    const int grp = (i < O.P) ? 0 : (i < O.P + O.Q2 ? 1 : 2);
+    const float gnorm = s_gn[grp];
+    if (gnorm < O.max_norm) continue;                 // this group's speculative (unclipped) step stands
+    float g = O.grads[i] * O.grad_scale;
+    g = (g / gnorm) * O.max_norm;
+    const AdamOut o = sac_adam(u_p[i], u_m[i], u_v[i], g, corr0, corr1, O.lr[grp], O.wd[grp]);
+    O.params[i] = o.p;
+    O.adam_m[i] = o.m;
+    O.adam_v[i] = o.v;
+    if (grp == 1) {
+      O.target_q[i - O.P] = u_tq[i - O.P] * O.one_minus_tau + o.p * O.tau;
+    } else if (grp == 2) {
+      const float al = expf(o.p);                                    // 'alpha' of the step (sac.py:267), now from the clipped update
+      O.metrics[3] = al;
+      if (O.metrics_accum) O.metrics_accum[3] = O.undo_count[1] + al;
+    }
+  }
+}
+
 struct SacArgs {
   MlpDev pi, q, qt;
   NetShape sh_pi, sh_q;
@@ -51,6 +164,8 @@ struct SacArgs {
   unsigned int *p2p_epoch;      // multi-GPU peer exchange: [0] += 1, [1] += p2p_blocks at the start of every step (or NULL)
   unsigned int p2p_blocks;
   unsigned long long *stamps;   // measurement hook (mbpo_debug_set_stamps): [2 roles][16] s_memtime values of tile 0, or NULL
+  SacOptArgs opt;               // clip check of the previous speculative step
+  float *step_count_rw;         // optimizer count: bumped by block 0 of every fwd/bwd launch
 };
 
 // Timeline stamps for DESIGN.md's phase breakdown: one s_memtime per phase boundary, written by thread 0 of tile 0.
@@ -149,17 +264,31 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
   float *s_lp = s_raw + U4;
   float *s_lpa = s_lp + U4;
   float *s_scal = s_lpa + U4;               // [4][16]
+  float *s_gn = s_scal + 64;                // [4]: group norms of the previous speculative optimizer step
 
   {
     const int tid = tid_;
     SAC_STAMP(0);
-    if (A.p2p_epoch && blockIdx.x == 0 && tid == 0) {   // the exchange's epoch is stable while the reduce/gather kernels read it
-      A.p2p_epoch[0] = A.p2p_epoch[0] + 1u;
-      A.p2p_epoch[1] = A.p2p_epoch[1] + A.p2p_blocks;
-    }
   }
+  // Clip check of the previous speculative optimizer step (k_sac_reduce_apply): the partial sums are requested now, next to the
+  // tile and log_alpha loads, and looked at after the section's barrier.
+  // Nothing here may WAIT for a load: a branch on the sequence words at this point would put a whole cold-miss latency in front of
+  // the tile loads and the first-layer weight request (measured: +2 us per launch).  The partials are requested unconditionally
+  // (the buffer always exists) and the sequence words are looked at after the section's barrier.
+  // (This kernel is short of scalar registers — ~130 are spilled — and every value kept across the phase loop costs the lone
+  // waves spill/reload instructions in every phase: the sequence words and the counters block 0 bumps are read here and used up
+  // right after the first barrier.)
+  const unsigned int seq_issued = A.opt.seq[0], seq_resolved = A.opt.seq[1];
+  const float count_in = A.step_count_rw[0];
+  const unsigned int ep0_in = A.p2p_epoch ? A.p2p_epoch[0] : 0u, ep1_in = A.p2p_epoch ? A.p2p_epoch[1] : 0u;
+  bool spec_pending = false;
+  // The LAST wave of the workgroup forms the norms: it is idle during phase 0 in both roles (critic role: chain 3, actor role:
+  // chains 1-3), so it adds them up there and the decision is taken at the end of phase 0 — in the rare case of a clip the
+  // phase-0 work is thrown away with everything else.
+  NormReq nreq;
+  if (wave == 4 * SP - 1) nreq = sac_group_norms_request(A.opt, tid_ & 63);
   // requested now, consumed after the first layer phase: the two scalar loads overlap the tile load instead of preceding it
-  const float log_alpha_v = A.log_alpha[0];
+  const float log_alpha_top = A.log_alpha[0];   // requested now, consumed after the first layer phase
   const RngKey rk_ = rng_resolve(A.seed, A.offset, A.rng_dev);
   const float invB = 1.0f / (float)B;
   const float *pi_p = A.pi.params, *q1_p = A.q.params, *q2_p = A.q.params + A.q.net_stride;
@@ -185,9 +314,19 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
   int cx = -1, cldx = ld_x, cpp0 = -1, cpp1 = -1, czb = -1, chb = -1, cy = -1, cdx = -1;
 #define P(off) ((off) < 0 ? (float *)nullptr : smem + (off))
   const int nph = role == 0 ? 3 : 4;
+  // At most two passes over the phases: the second one only after a clip fix-up of the previous optimizer step (rare), whose code
+  // sits behind the phase loop so that it costs the loop neither registers nor instruction-cache lines.
+  // The clip decision must not touch the phase loop's control flow: a `break` on it, or a loop bound that depends on it, made hipcc
+  // duplicate the runners' code (+2.8 us per launch).  So the phases always run to the end; the norms (formed on the side by an
+  // idle wave during phase 0) are looked at AFTER the loop, and in the rare case of a clip the optimizer step is fixed up and ALL
+  // phases run a second time — whatever the first pass wrote (slabs, loss partials) is overwritten.
+  // (A loop around the phase loop for the second pass cost the first pass 2 us — hipcc compiles a phase loop nested in another
+  // loop worse than one that stands alone — so the phases are a lambda expanded twice: the second copy is cold code behind the first.)
+  auto run_phases = [&](const float log_alpha_v) __attribute__((always_inline)) {
 #pragma nounroll
   for (int ph = -1; ph < nph; ++ph) {
     const int tid = opaque(tid_), lane = tid & 63;   // keeps per-lane addresses of all phases from being hoisted and spilled
+    if (ph == 0 && wave == 4 * SP - 1) sac_group_norms_finish(A.opt, nreq, s_gn, lane);   // this wave is idle in phase 0 (see above)
     if (ph >= 0) {
       const int len = (role == 0) ? (ph == 0 ? Lmax : QL) : ((ph == 0 || ph == 3) ? PL : QL);
       const NetShape sh = netid == 0 ? A.sh_pi : A.sh_q;
@@ -381,8 +520,33 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
       }
     }
     __syncthreads();
+    if (ph == -1) {
+      // the words requested at the top have arrived with the tile: use them up (idempotent: a second pass repeats the same stores)
+      spec_pending = seq_issued != seq_resolved;
+      if (blockIdx.x == 0 && tid == 0) {
+        // optax's count: one per sgd_step.  Nothing in this kernel uses it; the reduce / apply launches of this step read the final
+        // value (kernel boundary), the clip fix-up of the NEXT launch reads the copy k_sac_reduce_apply keeps.  (A load -> add ->
+        // store chain at the very top made block 0 wait a cold-miss latency before its first tile load.)
+        A.step_count_rw[0] = count_in + 1.0f;
+        if (A.p2p_epoch) {   // multi-GPU peer exchange: the epoch is stable while the reduce / gather launches of this step read it
+          A.p2p_epoch[0] = ep0_in + 1u;
+          A.p2p_epoch[1] = ep1_in + A.p2p_blocks;
+        }
+      }
+    }
+
     SAC_STAMP(2 * ph + 4);
   }
+  };
+  run_phases(log_alpha_top);
+  // s_gn was written during phase 0 and every phase ends in a barrier: valid here.  Common case: every group's norm is below
+  // max_norm and this launch is done.
+  if (!spec_pending) return;
+  if (s_gn[0] < A.opt.max_norm && s_gn[1] < A.opt.max_norm && s_gn[2] < A.opt.max_norm) return;
+  sac_clip_fixup(A.opt, s_gn, opaque(tid_), nthreads);
+  __threadfence();
+  __syncthreads();
+  run_phases(A.log_alpha[0]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,12 +555,6 @@ struct SacReduceArgs {
   int n_tiles, P, Q2, B;
   float *grads, *metrics, *metrics_accum, *ss_part, *step_count;
 };
-
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
-}
 
 // sum-of-squares partials per workgroup and optimizer group (0 policy, 1 critics, 2 alpha), fixed order
 __device__ __forceinline__ void group_sumsq(float g, int i, int P, int Q2, int NP, float *ss_part) {
@@ -438,7 +596,6 @@ __global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
       A.metrics_accum[2] += A.metrics[2];
       A.metrics_accum[4] += 1.0f;
     }
-    A.step_count[0] = A.step_count[0] + 1.0f;  // optimizer count (read by apply; fwd_bwd of this step already ran)
   }
   if (i < NP) A.grads[i] = g;
   group_sumsq(g, i, A.P, A.Q2, NP, A.ss_part);
@@ -470,7 +627,6 @@ __global__ void __launch_bounds__(256) k_sac_reduce_push(SacReduceArgs A, P2pDev
       A.metrics_accum[2] += A.metrics[2];
       A.metrics_accum[4] += 1.0f;
     }
-    A.step_count[0] = A.step_count[0] + 1.0f;
   }
   p2p_push(X, epoch, i, NP, g);
 }
@@ -517,7 +673,6 @@ __global__ void __launch_bounds__(256) k_sac_reduce_exchange(SacReduceArgs A, P2
       A.metrics_accum[2] += A.metrics[2];
       A.metrics_accum[4] += 1.0f;
     }
-    A.step_count[0] = A.step_count[0] + 1.0f;
   }
   p2p_push(X, epoch, i, NP, g);
   const bool ok = p2p_wait(X, want);
@@ -536,70 +691,40 @@ __global__ void __launch_bounds__(256) k_sac_sumsq(const float *grads, int P, in
   group_sumsq(g, i, P, Q2, NP, ss_part);
 }
 
-struct SacApplyArgs {
-  float *params, *target_q, *adam_m, *adam_v, *grads, *metrics, *metrics_accum;
-  const float *step_count, *ss_part;
-  int n_parts, P, Q2;
-  float lr[3], wd[3];
-  float max_norm, tau, one_minus_tau, grad_scale;
-};
-
-__global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
+__global__ void __launch_bounds__(256) k_sac_apply(SacOptArgs A) {
   __shared__ float s_scale[3];
   __shared__ float s_corr[2];
   const int tid = threadIdx.x;
   // the element's own operands are requested first: their latency overlaps the norm reduction below
-  const int NP_ = A.P + A.Q2 + 1;
-  const int i_ = blockIdx.x * 256 + tid;
-  const bool in_ = i_ < NP_;
-  const float g_in = in_ ? A.grads[i_] : 0.f, m_in = in_ ? A.adam_m[i_] : 0.f, v_in = in_ ? A.adam_v[i_] : 0.f,
-              p_in = in_ ? A.params[i_] : 0.f;
-  const float count_in = A.step_count[0];
-  const bool crit_ = in_ && i_ >= A.P && i_ < A.P + A.Q2;
-  const float tq_in = crit_ ? A.target_q[i_ - A.P] : 0.f;
-  {
-    // wave w < 3 reduces optimizer group w's sum-of-squares partials (fixed shuffle tree -> deterministic)
-    const int w = tid >> 6, lane = tid & 63;
-    if (w < 3) {
-      float ss = 0.f;
-      for (int p = lane; p < A.n_parts; p += 64) ss += A.ss_part[p * 3 + w];
-      ss = wave_sum64(ss);
-      // [3P optax.clip_by_global_norm] g_norm = sqrt(sum g^2); g <- g if g_norm < max_norm else (g / g_norm) * max_norm
-      if (lane == 0) s_scale[w] = sqrtf(ss) * A.grad_scale;
-    } else if (lane == 0) {
-      // the Adam bias corrections are the same for every element: the fourth wave forms them (two powf, ~300 instructions)
-      // beside the three norm reductions instead of every wave after the barrier
-      s_corr[0] = 1.f - powf(0.9f, count_in);
-      s_corr[1] = 1.f - powf(0.999f, count_in);
-    }
-  }
-  __syncthreads();
   const int NP = A.P + A.Q2 + 1;
   const int i = blockIdx.x * 256 + tid;
-  if (i >= NP) return;
+  const bool in = i < NP;
+  const float g_in = in ? A.grads[i] : 0.f, m_in = in ? A.adam_m[i] : 0.f, v_in = in ? A.adam_v[i] : 0.f, p_in = in ? A.params[i] : 0.f;
+  const float count_in = A.step_count[0];
+  const bool crit = in && i >= A.P && i < A.P + A.Q2;
+  const float tq_in = crit ? A.target_q[i - A.P] : 0.f;
+  sac_group_norms(A, s_scale, tid);          // waves 0..2: fixed shuffle tree -> deterministic
+  if (tid == 192) {
+    // the Adam bias corrections are the same for every element: the fourth wave forms them (two powf, ~300 instructions)
+    // beside the three norm reductions instead of every wave after the barrier
+    s_corr[0] = 1.f - powf(0.9f, count_in);
+    s_corr[1] = 1.f - powf(0.999f, count_in);
+  }
+  __syncthreads();
+  if (!in) return;
   const int grp = (i < A.P) ? 0 : (i < A.P + A.Q2 ? 1 : 2);
   const float gnorm = s_scale[grp];
   float g = g_in * A.grad_scale;
+  // [3P optax.clip_by_global_norm] g_norm = sqrt(sum g^2); g <- g if g_norm < max_norm else (g / g_norm) * max_norm
   if (!(gnorm < A.max_norm)) g = (g / gnorm) * A.max_norm;
-  // [3P optax.adamw] scale_by_adam(b1=.9,b2=.999,eps=1e-8) -> add_decayed_weights(wd) -> scale(-lr)
-  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-  // (count_in is already incremented for this step)  optax forms (1 - decay) in Python double and only then casts: f32(0.1), f32(0.001) — not 1.f - 0.999f
-  const float mu = b1 * m_in + 0.1f * g;
-  const float nu = b2 * v_in + 0.001f * (g * g);
-  A.adam_m[i] = mu;
-  A.adam_v[i] = nu;
-  const float mu_hat = mu / s_corr[0];   // 1 - b1^count, 1 - b2^count
-  const float nu_hat = nu / s_corr[1];
-  float upd = mu_hat / (sqrtf(nu_hat) + eps);
-  const float p = p_in;
-  upd = upd + A.wd[grp] * p;
-  const float pn = p + (-A.lr[grp]) * upd;  // optax.apply_updates: p + u, u = -lr * upd
-  A.params[i] = pn;
+  const AdamOut o = sac_adam(p_in, m_in, v_in, g, s_corr[0], s_corr[1], A.lr[grp], A.wd[grp]);   // count_in is already this step's count
+  A.adam_m[i] = o.m;
+  A.adam_v[i] = o.v;
+  A.params[i] = o.p;
   if (grp == 1) {
-    const int j = i - A.P;
-    A.target_q[j] = tq_in * A.one_minus_tau + pn * A.tau;           // sac.py:260-261 ((1 - tau) formed in double on the host)
+    A.target_q[i - A.P] = tq_in * A.one_minus_tau + o.p * A.tau;           // sac.py:260-261 ((1 - tau) formed in double on the host)
   } else if (grp == 2) {
-    A.metrics[3] = expf(pn);                                      // 'alpha': exp(alpha_params) (sac.py:267)
+    A.metrics[3] = expf(o.p);                                      // 'alpha': exp(alpha_params) (sac.py:267)
     if (A.metrics_accum) A.metrics_accum[3] += A.metrics[3];
   }
 }
@@ -607,27 +732,32 @@ __global__ void __launch_bounds__(256) k_sac_apply(SacApplyArgs A) {
 // ------------------------------------------------------------------------------------------------ host side
 
 // ------------------------------------------------------------------------------------------------
-// Single-rank fast path: k_sac_reduce + k_sac_apply in ONE launch (a kernel boundary costs ~4.5 us here, the two kernels'
-// work ~2 us).  The global gradient norms need every block's partial before any block applies, so the blocks meet at a
-// device-scope arrival counter (all n_red <= ~1000 blocks of 256 threads are co-resident on 256 CUs).  The spin is bounded:
-// if the barrier is not reached the update is skipped and metrics[0] is set to NaN instead of hanging the GPU.
-struct SacFusedArgs {
-  SacReduceArgs R;
-  SacApplyArgs Ap;
-  unsigned int *sync;   // [0] arrivals at the norm barrier, [1] arrivals at the end (both return to 0)
-  float *step_count;
-};
-
-__global__ void __launch_bounds__(256) k_sac_reduce_apply(SacFusedArgs F) {
-  __shared__ float s_scale[3];
-  __shared__ int s_ok;
-  const SacReduceArgs &A = F.R;
-  const SacApplyArgs &Ap = F.Ap;
-  const int tid = threadIdx.x;
+// k_sac_reduce_apply: k_sac_reduce (+ the peer exchange when EXCHANGE) and the optimizer step in ONE launch, without a device-wide
+// meeting point: the step is applied UNCLIPPED and the previous (params, m, v, target) go to the undo log; whoever reads the
+// parameters next (k_sac_fwd_bwd's prologue, k_sac_finalize) sums the clip-norm partials this kernel leaves and, if a group's
+// norm reached max_norm, recomputes that group's step from the undo log (sac_clip_fixup).  step_count was bumped by this step's
+// fwd/bwd launch: every block reads the same final count.
+template <bool EXCHANGE>
+__global__ void __launch_bounds__(256) k_sac_reduce_apply(SacReduceArgs A, SacOptArgs O, P2pDev X) {
+  __shared__ float s_corr[2];
   const int NP = A.P + A.Q2 + 1;
+  const int tid = threadIdx.x;
   const int i = blockIdx.x * 256 + tid;
-  const int nblocks = gridDim.x;
-  const float count = F.step_count[0] + 1.0f;   // every block reads the old count before it arrives anywhere
+  const bool in = i < NP;
+  // the element's own optimizer operands are requested first: their latency overlaps the slab sums
+  const float m_in = in ? O.adam_m[i] : 0.f, v_in = in ? O.adam_v[i] : 0.f, p_in = in ? O.params[i] : 0.f;
+  const bool crit = in && i >= A.P && i < A.P + A.Q2;
+  const float tq_in = crit ? O.target_q[i - A.P] : 0.f;
+  const float count = O.step_count[0];
+  unsigned epoch = 0, want = 0;
+  if (EXCHANGE) {
+    epoch = X.epoch[0];
+    want = X.epoch[1];
+  }
+  if (tid == 0) {
+    s_corr[0] = 1.f - powf(0.9f, count);
+    s_corr[1] = 1.f - powf(0.999f, count);
+  }
   float g = 0.f;
   if (i < A.P) {
     g = slab_sum<16>(A.slab_pi, A.P, A.n_tiles, i);
@@ -635,7 +765,6 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacFusedArgs F) {
     const int j = i - A.P;
     g = slab_sum<16>(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
-    // (all loads of the three sums in flight together: this one thread is the kernel's critical path)
     const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
                 al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
     const float invB = 1.0f / (float)A.B;
@@ -649,73 +778,54 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacFusedArgs F) {
       A.metrics_accum[2] += A.metrics[2];
       A.metrics_accum[4] += 1.0f;
     }
+    O.undo_count[0] = count;
+    O.undo_count[1] = A.metrics_accum ? A.metrics_accum[3] : 0.f;
+    O.seq[0] = O.seq[0] + 1u;      // one more speculative step whose clip check is pending
   }
-  if (i < NP) A.grads[i] = g;
-  group_sumsq(g, i, A.P, A.Q2, NP, A.ss_part);   // writes this block's three partials (ends in a __syncthreads + store by tid < 3)
+  if (EXCHANGE) {
+    p2p_push(X, epoch, i, NP, g);
+    const bool ok = p2p_wait(X, want);
+    g = in ? (ok ? p2p_sum(X, epoch, i) : NAN) : 0.f;
+  }
+  if (in) A.grads[i] = g;
+  group_sumsq(g, i, A.P, A.Q2, NP, A.ss_part);   // ends in a __syncthreads: s_corr is visible below
+  if (!in) return;
+  const int grp = (i < A.P) ? 0 : (i < A.P + A.Q2 ? 1 : 2);
+  float *u_p = O.undo, *u_m = O.undo + NP, *u_v = O.undo + 2 * NP, *u_tq = O.undo + 3 * NP;
+  u_p[i] = p_in;
+  u_m[i] = m_in;
+  u_v[i] = v_in;
+  const AdamOut o = sac_adam(p_in, m_in, v_in, g * O.grad_scale, s_corr[0], s_corr[1], O.lr[grp], O.wd[grp]);
+  O.params[i] = o.p;
+  O.adam_m[i] = o.m;
+  O.adam_v[i] = o.v;
+  if (grp == 1) {
+    u_tq[i - A.P] = tq_in;
+    O.target_q[i - A.P] = tq_in * O.one_minus_tau + o.p * O.tau;       // sac.py:260-261
+  } else if (grp == 2) {
+    O.undo_count[2] = s_corr[0];
+    O.undo_count[3] = s_corr[1];
+    const float al = expf(o.p);                                        // 'alpha' (sac.py:267); repaired by the fix-up if the group clips
+    O.metrics[3] = al;
+    if (O.metrics_accum) O.metrics_accum[3] = O.undo_count[1] + al;    // same thread wrote undo_count[1] above
+  }
+}
+
+// Resolves the clip check of the last speculative step when no further fwd/bwd launch will (end of training_step's sgd scan,
+// a single sgd_step of the eager API): one workgroup.  Idempotent.
+__global__ void __launch_bounds__(1024) k_sac_finalize(SacOptArgs O) {
+  __shared__ float s_gn[4];
+  const int tid = threadIdx.x;
+  if (O.seq[0] == O.seq[1]) return;
+  sac_group_norms(O, s_gn, tid);
   __syncthreads();
-  // ---- device-wide meeting point ----
-  if (tid == 0) {
-    __threadfence();                                                               // partials visible device-wide
-    __hip_atomic_fetch_add(&F.sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    int ok = 0;
-    for (int spin = 0; spin < (1 << 22); ++spin) {
-      if (__hip_atomic_load(&F.sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)nblocks) {
-        ok = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
+  const bool clip = !(s_gn[0] < O.max_norm) || !(s_gn[1] < O.max_norm) || !(s_gn[2] < O.max_norm);
+  if (clip) {
+    sac_clip_fixup(O, s_gn, tid, 1024);
     __threadfence();
-    s_ok = ok;
   }
   __syncthreads();
-  const bool ok = s_ok != 0;
-  {
-    const int w = tid >> 6, lane = tid & 63;
-    if (w < 3) {
-      float ss = 0.f;
-      for (int p = lane; p < nblocks; p += 64) ss += __hip_atomic_load(&A.ss_part[p * 3 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ss = wave_sum64(ss);
-      if (lane == 0) s_scale[w] = sqrtf(ss) * Ap.grad_scale;
-    }
-  }
-  __syncthreads();
-  if (ok && i < NP) {
-    const int grp = (i < A.P) ? 0 : (i < A.P + A.Q2 ? 1 : 2);
-    const float gnorm = s_scale[grp];
-    g = g * Ap.grad_scale;
-    if (!(gnorm < Ap.max_norm)) g = (g / gnorm) * Ap.max_norm;
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-    const float mu = b1 * Ap.adam_m[i] + 0.1f * g;
-    const float nu = b2 * Ap.adam_v[i] + 0.001f * (g * g);
-    Ap.adam_m[i] = mu;
-    Ap.adam_v[i] = nu;
-    const float mu_hat = mu / (1.f - powf(b1, count));
-    const float nu_hat = nu / (1.f - powf(b2, count));
-    float upd = mu_hat / (sqrtf(nu_hat) + eps);
-    const float p = Ap.params[i];
-    upd = upd + Ap.wd[grp] * p;
-    const float pn = p + (-Ap.lr[grp]) * upd;
-    Ap.params[i] = pn;
-    if (grp == 1) {
-      const int j = i - A.P;
-      Ap.target_q[j] = Ap.target_q[j] * Ap.one_minus_tau + pn * Ap.tau;
-    } else if (grp == 2) {
-      Ap.metrics[3] = expf(pn);
-      if (Ap.metrics_accum) Ap.metrics_accum[3] += Ap.metrics[3];
-    }
-  }
-  // ---- last block out advances the optimizer count and re-arms the counters ----
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(&F.sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == (unsigned)nblocks - 1u) {
-      if (ok) F.step_count[0] = count;
-      else A.metrics[0] = NAN;
-      __hip_atomic_store(&F.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&F.sync[1], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  if (tid == 0) O.seq[1] = O.seq[0];
 }
 
 struct SacPlan {
@@ -724,7 +834,7 @@ struct SacPlan {
   size_t lds;
   int ld_x, ld_xu, ld_h, ld_y;
   // workspace offsets (floats)
-  long long off_slab_pi, off_slab_q, off_slab_ex, off_ss, off_sync, total;
+  long long off_slab_pi, off_slab_q, off_slab_ex, off_ss, off_seq, off_undo, total;
 };
 
 static int same_hidden(const int *dims, int n_layers) {
@@ -784,14 +894,15 @@ static int sac_plan(const mbpo_sac_desc *d, SacPlan *pl, bool need_ptrs) {
   pl->ld_y = up4(2 * d->u_dim) + 4;
   const int U = d->u_dim;
   size_t f = 16ull * up4(d->row_len) + 2ull * 16 * pl->ld_x + 2ull * 16 * pl->ld_xu + 4ull * 16 * pl->ld_h +
-             (size_t)pl->LH * 4 * 16 * pl->ld_h + 5ull * 16 * pl->ld_y + 2ull * 16 * pl->ld_xu + 6ull * up4(16 * U) + 64;
+             (size_t)pl->LH * 4 * 16 * pl->ld_h + 5ull * 16 * pl->ld_y + 2ull * 16 * pl->ld_xu + 6ull * up4(16 * U) + 64 + 4;
   pl->lds = f * sizeof(float);
   pl->off_slab_pi = 0;
   pl->off_slab_q = pl->off_slab_pi + (long long)pl->n_tiles * pl->P;
   pl->off_slab_ex = pl->off_slab_q + (long long)pl->n_tiles * 2 * pl->Q;
   pl->off_ss = pl->off_slab_ex + (long long)pl->n_tiles * 4;
-  pl->off_sync = (pl->off_ss + (long long)pl->n_red * 3 + 3) & ~3LL;   // 2 x uint32 grid-barrier counters (zero between launches)
-  pl->total = pl->off_sync + 4;
+  pl->off_seq = (pl->off_ss + (long long)pl->n_red * 3 + 3) & ~3LL;   // 3 x uint32 sequence numbers + the undo count (zero at start)
+  pl->off_undo = pl->off_seq + 8;                                      // undo log of the speculative optimizer step
+  pl->total = pl->off_undo + 3LL * pl->NP + 2LL * pl->Q;
   if (need_ptrs) {
     MBPO_REQUIRE(d->params && d->target_q && d->adam_m && d->adam_v && d->step_count && d->grads && d->workspace && d->metrics,
                  MBPO_ERR_ARG, "sac: null state pointer");
@@ -868,8 +979,21 @@ static void sac_chain_table(const SacPlan &pl, int D, SacArgs *A) {
       }
 }
 
+static void sac_fill_opt(const mbpo_sac_desc *d, const SacPlan &pl, SacOptArgs *A) {
+  A->params = d->params; A->target_q = d->target_q; A->adam_m = d->adam_m; A->adam_v = d->adam_v; A->grads = d->grads;
+  A->metrics = d->metrics; A->metrics_accum = d->metrics_accum; A->step_count = d->step_count; A->ss_part = d->workspace + pl.off_ss;
+  A->undo = d->workspace + pl.off_undo;
+  A->seq = reinterpret_cast<unsigned int *>(d->workspace + pl.off_seq);
+  A->undo_count = d->workspace + pl.off_seq + 2;
+  A->n_parts = pl.n_red; A->P = pl.P; A->Q2 = 2 * pl.Q;
+  A->lr[0] = d->lr_policy; A->lr[1] = d->lr_q; A->lr[2] = d->lr_alpha;
+  A->wd[0] = d->wd_policy; A->wd[1] = d->wd_q; A->wd[2] = d->wd_alpha;
+  A->max_norm = d->max_grad_norm; A->tau = d->tau; A->one_minus_tau = (float)(1.0 - (double)d->tau); A->grad_scale = d->grad_scale;
+}
+
+// phase_mask: bit0 = k_sac_fwd_bwd, bit1 = the slab reduction.  apply_in_reduce: the reduction launch is k_sac_reduce_apply.
 static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, const mbpo_p2p_desc *xd = nullptr,
-                          bool exchange_in_reduce = false) {
+                          bool exchange_in_reduce = false, bool apply_in_reduce = false) {
   SacPlan pl;
   int rc = sac_plan(d, &pl, true);
   if (rc != MBPO_OK) return rc;
@@ -885,8 +1009,11 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
   A.log_alpha = d->params + pl.NP - 1;
   A.noise_alpha = d->noise_alpha; A.noise_critic = d->noise_critic; A.noise_actor = d->noise_actor;
   A.seed = d->seed; A.offset = d->offset; A.rng_dev = (const unsigned long long *)d->rng_dev;
+  sac_fill_opt(d, pl, &A.opt);
+  A.step_count_rw = d->step_count;
   A.stamps = g_sac_stamps;
   P2pDev X;
+  memset(&X, 0, sizeof(X));
   A.p2p_epoch = nullptr;
   A.p2p_blocks = (unsigned)pl.n_red;
   if (xd) {
@@ -928,7 +1055,10 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
   R.slab_pi = A.slab_pi; R.slab_q = A.slab_q; R.slab_ex = A.slab_ex;
   R.n_tiles = pl.n_tiles; R.P = pl.P; R.Q2 = 2 * pl.Q; R.B = d->batch_size;
   R.grads = d->grads; R.metrics = d->metrics; R.metrics_accum = d->metrics_accum; R.ss_part = d->workspace + pl.off_ss; R.step_count = d->step_count;
-  if (xd && exchange_in_reduce) hipLaunchKernelGGL(k_sac_reduce_exchange, dim3(pl.n_red), dim3(256), 0, st, R, X);
+  if (apply_in_reduce) {
+    if (xd) hipLaunchKernelGGL(k_sac_reduce_apply<true>, dim3(pl.n_red), dim3(256), 0, st, R, A.opt, X);
+    else hipLaunchKernelGGL(k_sac_reduce_apply<false>, dim3(pl.n_red), dim3(256), 0, st, R, A.opt, X);
+  } else if (xd && exchange_in_reduce) hipLaunchKernelGGL(k_sac_reduce_exchange, dim3(pl.n_red), dim3(256), 0, st, R, X);
   else if (xd) hipLaunchKernelGGL(k_sac_reduce_push, dim3(pl.n_red), dim3(256), 0, st, R, X);
   else hipLaunchKernelGGL(k_sac_reduce, dim3(pl.n_red), dim3(256), 0, st, R);
   MBPO_CHECK_LAUNCH("sac_grads");
@@ -985,38 +1115,35 @@ extern "C" int mbpo_sac_apply(const mbpo_sac_desc *d, void *stream) {
   SacPlan pl;
   int rc = sac_plan(d, &pl, true);
   if (rc != MBPO_OK) return rc;
-  SacApplyArgs A;
-  A.params = d->params; A.target_q = d->target_q; A.adam_m = d->adam_m; A.adam_v = d->adam_v; A.grads = d->grads;
-  A.metrics = d->metrics; A.metrics_accum = d->metrics_accum; A.step_count = d->step_count; A.ss_part = d->workspace + pl.off_ss;
-  A.n_parts = pl.n_red; A.P = pl.P; A.Q2 = 2 * pl.Q;
-  A.lr[0] = d->lr_policy; A.lr[1] = d->lr_q; A.lr[2] = d->lr_alpha;
-  A.wd[0] = d->wd_policy; A.wd[1] = d->wd_q; A.wd[2] = d->wd_alpha;
-  A.max_norm = d->max_grad_norm; A.tau = d->tau; A.one_minus_tau = (float)(1.0 - (double)d->tau); A.grad_scale = d->grad_scale;
+  SacOptArgs A;
+  sac_fill_opt(d, pl, &A);
   hipLaunchKernelGGL(k_sac_apply, dim3(pl.n_red), dim3(256), 0, (hipStream_t)stream, A);
   MBPO_CHECK_LAUNCH("sac_apply");
   return MBPO_OK;
 }
 
-extern "C" int mbpo_sac_reduce_apply(const mbpo_sac_desc *d, void *stream) {
+// One sgd_step in TWO launches: k_sac_fwd_bwd, then k_sac_reduce_apply (slab reduction + [peer exchange +] unclipped optimizer
+// step + undo log).  The clip check is resolved by the next mbpo_sac_step / mbpo_sac_grads launch or by mbpo_sac_finalize.
+extern "C" int mbpo_sac_step(const mbpo_sac_desc *d, void *stream) { return sac_grads_impl(d, 3, stream, nullptr, false, true); }
+
+extern "C" int mbpo_sac_step_p2p(const mbpo_sac_desc *d, const mbpo_p2p_desc *x, void *stream) {
+  MBPO_REQUIRE(x, MBPO_ERR_ARG, "sac_step_p2p: null exchange descriptor");
   SacPlan pl;
   int rc = sac_plan(d, &pl, true);
   if (rc != MBPO_OK) return rc;
-  SacFusedArgs F;
-  F.R.slab_pi = d->workspace + pl.off_slab_pi; F.R.slab_q = d->workspace + pl.off_slab_q; F.R.slab_ex = d->workspace + pl.off_slab_ex;
-  F.R.n_tiles = pl.n_tiles; F.R.P = pl.P; F.R.Q2 = 2 * pl.Q; F.R.B = d->batch_size;
-  F.R.grads = d->grads; F.R.metrics = d->metrics; F.R.metrics_accum = d->metrics_accum; F.R.ss_part = d->workspace + pl.off_ss;
-  F.R.step_count = d->step_count;
-  SacApplyArgs &A = F.Ap;
-  A.params = d->params; A.target_q = d->target_q; A.adam_m = d->adam_m; A.adam_v = d->adam_v; A.grads = d->grads;
-  A.metrics = d->metrics; A.metrics_accum = d->metrics_accum; A.step_count = d->step_count; A.ss_part = d->workspace + pl.off_ss;
-  A.n_parts = pl.n_red; A.P = pl.P; A.Q2 = 2 * pl.Q;
-  A.lr[0] = d->lr_policy; A.lr[1] = d->lr_q; A.lr[2] = d->lr_alpha;
-  A.wd[0] = d->wd_policy; A.wd[1] = d->wd_q; A.wd[2] = d->wd_alpha;
-  A.max_norm = d->max_grad_norm; A.tau = d->tau; A.one_minus_tau = (float)(1.0 - (double)d->tau); A.grad_scale = d->grad_scale;
-  F.sync = reinterpret_cast<unsigned int *>(d->workspace + pl.off_sync);
-  F.step_count = d->step_count;
-  MBPO_REQUIRE(pl.n_red <= 2048, MBPO_ERR_UNSUPPORTED, "sac_reduce_apply: %d blocks cannot be assumed co-resident; use grads + apply", pl.n_red);
-  hipLaunchKernelGGL(k_sac_reduce_apply, dim3(pl.n_red), dim3(256), 0, (hipStream_t)stream, F);
-  MBPO_CHECK_LAUNCH("sac_reduce_apply");
+  // every workgroup of the reduction waits inside the kernel for the peers' same kernel: they must all be resident at once
+  MBPO_REQUIRE(pl.n_red <= 1024, MBPO_ERR_UNSUPPORTED, "sac_step_p2p: %d workgroups cannot be assumed co-resident; use "
+               "mbpo_sac_grads_p2p + mbpo_sac_gather_p2p + mbpo_sac_apply", pl.n_red);
+  return sac_grads_impl(d, 3, stream, x, true, true);
+}
+
+extern "C" int mbpo_sac_finalize(const mbpo_sac_desc *d, void *stream) {
+  SacPlan pl;
+  int rc = sac_plan(d, &pl, true);
+  if (rc != MBPO_OK) return rc;
+  SacOptArgs A;
+  sac_fill_opt(d, pl, &A);
+  hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
+  MBPO_CHECK_LAUNCH("sac_finalize");
   return MBPO_OK;
 }

@@ -211,7 +211,7 @@ def _bind_optional(lib: C.CDLL) -> None:
         if fn is not None:
             fn.restype = C.c_int
             fn.argtypes = argtypes
-    for name in ("mbpo_sac_grads", "mbpo_sac_grad_norms", "mbpo_sac_apply", "mbpo_sac_reduce_apply"):
+    for name in ("mbpo_sac_grads", "mbpo_sac_grad_norms", "mbpo_sac_apply", "mbpo_sac_step", "mbpo_sac_finalize"):
         fn = getattr(lib, name, None)
         if fn is not None:
             fn.restype = C.c_int
@@ -253,7 +253,8 @@ def _bind_optional(lib: C.CDLL) -> None:
                            ("mbpo_p2p_status", [C.POINTER(P2pDesc), C.POINTER(C.c_int32)]),
                            ("mbpo_sac_grads_p2p", [C.POINTER(SacDesc), C.POINTER(P2pDesc), vp]),
                            ("mbpo_sac_gather_p2p", [C.POINTER(SacDesc), C.POINTER(P2pDesc), vp]),
-                           ("mbpo_sac_grads_exchange_p2p", [C.POINTER(SacDesc), C.POINTER(P2pDesc), vp])):
+                           ("mbpo_sac_grads_exchange_p2p", [C.POINTER(SacDesc), C.POINTER(P2pDesc), vp]),
+                           ("mbpo_sac_step_p2p", [C.POINTER(SacDesc), C.POINTER(P2pDesc), vp])):
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = argtypes

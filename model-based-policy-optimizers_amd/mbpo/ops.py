@@ -450,15 +450,17 @@ class SacUpdater:
                  reward_scaling: float = 1.0, target_entropy: Optional[float] = None, tau: float = 0.005,
                  lr_policy: float = 1e-4, lr_q: float = 1e-4, lr_alpha: float = 1e-4, wd_policy: float = 0.0,
                  wd_q: float = 0.0, wd_alpha: float = 0.0, max_grad_norm: float = 1e5, seed: int = 0,
-                 all_reduce=None, world_size: int = 1, fused_apply: bool = False, p2p=None,
+                 all_reduce=None, world_size: int = 1, two_launch: Optional[bool] = None, p2p=None,
                  non_equidistant_time: bool = False, continuous_discounting: float = 0.0, min_time_between_switches: float = 0.0,
                  max_time_between_switches: float = 0.0, env_dt: float = 0.0):
         self.lib = load()
         self.x_dim, self.u_dim, self.batch_size = x_dim, u_dim, batch_size
-        # single rank: slab reduction + optimizer in ONE launch (mbpo_sac_reduce_apply).  Off by default: measured on MI355X the
-        # in-kernel device-wide meeting point (cross-XCD atomics + L2 write-back) costs more than the kernel boundary it removes
-        # (48 vs 40 us per sgd_step).
-        self.fused_apply = fused_apply
+        # two_launch (default on; MBPO_SAC_TWO_LAUNCH=0 or two_launch=False selects grads + apply): fwd/bwd, then ONE launch for slab
+        # reduction [+ peer exchange] + optimizer step; the clip check is resolved by the next step's prologue or by finalize().
+        # A library collective (`all_reduce` without p2p) sits BETWEEN reduction and optimizer step: that path keeps its launches.
+        if two_launch is None:
+            two_launch = os.environ.get("MBPO_SAC_TWO_LAUNCH", "1") != "0"
+        self.two_launch = bool(two_launch)
         self.policy_spec = MlpSpec(list(policy_dims), policy_activation, 1)
         self.q_spec = MlpSpec(list(q_dims), q_activation, 2)
         self.P, self.Q = self.policy_spec.n_params, self.q_spec.n_params
@@ -511,6 +513,7 @@ class SacUpdater:
         return self.params[self.NP - 1:]
 
     def load_state(self, params, target_q=None, adam_m=None, adam_v=None, count: float = 0.0):
+        self.finalize()          # a pending clip check belongs to the state that is being replaced
         self.params.copy_(params)
         self.target_q.copy_(self.params[self.P:self.P + 2 * self.Q] if target_q is None else target_q)
         self.adam_m.zero_() if adam_m is None else self.adam_m.copy_(adam_m)
@@ -518,10 +521,13 @@ class SacUpdater:
         self.step_count.fill_(count)
 
     def sgd_step(self, batch: torch.Tensor, norm_mean=None, norm_std=None, noise_alpha=None, noise_critic=None,
-                 noise_actor=None, offset: int = 0, seed: Optional[int] = None, rng_dev: Optional[torch.Tensor] = None) -> None:
+                 noise_actor=None, offset: int = 0, seed: Optional[int] = None, rng_dev: Optional[torch.Tensor] = None,
+                 defer_clip_check: bool = False) -> None:
         """One SAC.sgd_step (sac/sac.py:227-281) on `batch` [B, 2x+u+3]; metrics land in self.metrics (device).
         Noise that is not given explicitly is Philox(seed, offset [+ rng_dev]): vary `offset` (or advance the device counter)
-        between steps — the optimizer step count plays no part in the streams."""
+        between steps — the optimizer step count plays no part in the streams.
+        defer_clip_check (two-launch path): leave the clip check of this step to the next sgd_step's first launch; the caller
+        ends a run of steps with finalize() before reading params / target_q / moments / metrics[3]."""
         _req(batch, "batch")
         if batch.shape != (self.batch_size, self.desc.row_len):
             raise ValueError(f"batch must be [{self.batch_size},{self.desc.row_len}], got {tuple(batch.shape)}")
@@ -539,12 +545,12 @@ class SacUpdater:
             d.seed = seed
         d.rng_dev = rng_ptr(rng_dev)
         st = current_stream_ptr()
-        if self.all_reduce is None and self.fused_apply:
-            # single rank: fwd/bwd, then ONE launch for slab reduction + norms + clip + AdamW + Polyak
-            check(self.lib.mbpo_sac_grads_phase(C.byref(d), 1, st), "mbpo_sac_grads_phase")
-            check(self.lib.mbpo_sac_reduce_apply(C.byref(d), st), "mbpo_sac_reduce_apply")
-            return
         if self.p2p is not None:
+            if self.two_launch and self.p2p_fused:
+                check(self.lib.mbpo_sac_step_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_step_p2p")
+                if not defer_clip_check:
+                    self.finalize()
+                return
             if self.p2p_fused:      # the slab reduction also exchanges: one launch less per sgd_step
                 check(self.lib.mbpo_sac_grads_exchange_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_grads_exchange_p2p")
             else:
@@ -552,11 +558,20 @@ class SacUpdater:
                 check(self.lib.mbpo_sac_gather_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_gather_p2p")
             check(self.lib.mbpo_sac_apply(C.byref(d), st), "mbpo_sac_apply")
             return
+        if self.all_reduce is None and self.two_launch:
+            check(self.lib.mbpo_sac_step(C.byref(d), st), "mbpo_sac_step")
+            if not defer_clip_check:
+                self.finalize()
+            return
         check(self.lib.mbpo_sac_grads(C.byref(d), st), "mbpo_sac_grads")
         if self.all_reduce is not None:
             self.all_reduce(self.grads)
             check(self.lib.mbpo_sac_grad_norms(C.byref(d), st), "mbpo_sac_grad_norms")
         check(self.lib.mbpo_sac_apply(C.byref(d), st), "mbpo_sac_apply")
+
+    def finalize(self) -> None:
+        """Resolve the pending clip check of the last two-launch step (mbpo_sac_finalize; a no-op when nothing is pending)."""
+        check(self.lib.mbpo_sac_finalize(C.byref(self.desc), current_stream_ptr()), "mbpo_sac_finalize")
 
 
 # ------------------------------------------------------------------------------------------------ PPO minibatch update (P1-P3)

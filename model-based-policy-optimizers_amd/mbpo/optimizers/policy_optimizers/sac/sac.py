@@ -292,13 +292,14 @@ class SAC:
         return normalizer_params, env_state, buffer_state
 
     def sgd_step(self, transitions_rows: torch.Tensor, normalizer_params: RunningStatisticsState, key: Optional[int] = None,
-                 g: int = 0) -> None:
+                 g: int = 0, defer_clip_check: bool = False) -> None:
         """sac.py:227-281 on one minibatch [B, D] (alpha, critic, actor updates at the old params + Polyak); `g` is the
         position inside training_step's scan (:324) — the reference hands every sgd_step its own split of the key."""
         if key is not None:
             self.rekey(key)
         nm, ns = self._norm(normalizer_params)
-        self.updater.sgd_step(transitions_rows, nm, ns, seed=0, offset=(SITE_SGD + g) << 32, rng_dev=self._rng)
+        self.updater.sgd_step(transitions_rows, nm, ns, seed=0, offset=(SITE_SGD + g) << 32, rng_dev=self._rng,
+                              defer_clip_check=defer_clip_check)
 
     def training_step(self, training_state: TrainingState, env_state: State, buffer_state: ReplayBufferState,
                       key: Optional[int] = None):
@@ -314,7 +315,9 @@ class SAC:
                                                             offset=SITE_SAMPLE << 32, rng_dev=self._rng)   # :318
         B = self.batch_size
         for g in range(self.grad_updates_per_step):                                                # scan :324
-            self.sgd_step(rows[g * B:(g + 1) * B], normalizer_params, g=g)
+            # each step's clip check is resolved by the next step's first launch; the last one by finalize (ops.SacUpdater)
+            self.sgd_step(rows[g * B:(g + 1) * B], normalizer_params, g=g, defer_clip_check=True)
+        self.updater.finalize()
         ops.rng_advance(self._rng)
         return training_state, env_state, buffer_state
 

@@ -5,15 +5,17 @@ rollout kernel (ops.model_rollout), which contains BraxWrapper.step + Episode.st
 """
 from __future__ import annotations
 
-from typing import Sequence
+from typing import TYPE_CHECKING, Sequence
 
 import torch
 
 from mbpo import ops
-from mbpo.optimizers.policy_optimizers.brax_utils.base import State
 from mbpo.replay import ReplayBufferState, UniformSamplingQueue
 from mbpo.systems.base_systems import System, SystemParams
 from mbpo.utils import keys as K
+
+if TYPE_CHECKING:      # a module-level import would be circular when mbpo.systems is imported before mbpo.optimizers
+    from mbpo.optimizers.policy_optimizers.brax_utils.base import State
 
 
 class BraxWrapper:
@@ -27,6 +29,7 @@ class BraxWrapper:
     def reset(self, rng: Sequence[int]) -> State:
         """One state per key, each drawn uniformly from the TRUE buffer (brax_wrapper.py:25-38).  The reference vmaps a
         batch-size-1 sample over the keys; here one launch draws all N rows (Philox index = env id)."""
+        from mbpo.optimizers.policy_optimizers.brax_utils.base import State
         keys = list(rng) if isinstance(rng, (list, tuple)) else [rng]
         n = len(keys)
         bs = self.sample_buffer_state

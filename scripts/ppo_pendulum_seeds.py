@@ -23,4 +23,5 @@ for key in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
         u, st = opt.act(x, st, evaluate=True)
         nxt = system.step(x, u, st.system_params)
         x, r = nxt.x_next, float(nxt.reward)
-    print(key, round(dt, 1), 's  last eval', round(out.summary[-1]['eval/episode_reward'], 1), ' final-step reward', round(r, 4), flush=True)
+    print(f"hip ppo key {key}: {dt:.1f}s  final eval {out.summary[-1]['eval/episode_reward']:.1f}  |r_200| {abs(r):.3f}  curve "
+          f"{[round(m['eval/episode_reward']) for m in out.summary]}", flush=True)

@@ -6,7 +6,7 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 PKG = ROOT / "model-based-policy-optimizers_amd"
-for p in (str(ROOT), str(PKG)):
+for p in (str(ROOT), str(PKG), str(ROOT / "tests")):     # tests/: test modules share helper systems
     if p not in sys.path:
         sys.path.insert(0, p)
 

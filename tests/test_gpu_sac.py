@@ -158,33 +158,41 @@ def test_sac_bad_args(dev):
         ops.SacUpdater(x_dim=3, u_dim=1, policy_dims=[3, 256, 256, 2], q_dims=[4, 256, 256, 1], batch_size=32, device=dev)
 
 
-def test_fused_reduce_apply_matches_two_launch_path(dev):
-    """mbpo_sac_reduce_apply (one launch, in-kernel device-wide meeting point for the clip norms) vs mbpo_sac_grads +
-    mbpo_sac_apply on the same state and batches: 6 chained steps, bit-identical state (same arithmetic, same order), with a
-    clip threshold low enough to be active."""
+@pytest.mark.parametrize("max_norm,mode", [(0.05, "finalize_each"), (0.05, "deferred"), (1e5, "deferred"), (0.4, "deferred")])
+def test_two_launch_step_matches_three_launch_path(dev, max_norm, mode):
+    """mbpo_sac_step (fwd/bwd + ONE launch: slab reduction + unclipped optimizer step + undo log; the clip check resolved by the
+    next step's prologue or by mbpo_sac_finalize) vs mbpo_sac_grads + mbpo_sac_apply on the same state and batches: 6 chained
+    steps, BIT-identical state.  max_norm 0.05: every group clips every step (the fix-up path runs each time, in the next
+    launch's prologue when deferred, in k_sac_finalize otherwise); 0.4: only some groups / steps clip; 1e5: never."""
     from mbpo import ops
     X, U, B = 4, 1, 256
     g = torch.Generator().manual_seed(3)
-    init = (torch.randn(ops.SacUpdater(x_dim=X, u_dim=U, policy_dims=[X, 64, 64, 64, 2 * U], q_dims=[X + U, 64, 64, 64, 1],
-                                        batch_size=B, device=dev).NP, generator=g) * 0.1)
-    ups = []
-    for fused in (True, False):
-        up = ops.SacUpdater(x_dim=X, u_dim=U, policy_dims=[X, 64, 64, 64, 2 * U], q_dims=[X + U, 64, 64, 64, 1], batch_size=B,
-                            device=dev, seed=5, max_grad_norm=0.05, lr_policy=1e-3, lr_q=1e-3, lr_alpha=1e-3, fused_apply=fused)
+    mk = lambda two: ops.SacUpdater(x_dim=X, u_dim=U, policy_dims=[X, 64, 64, 64, 2 * U], q_dims=[X + U, 64, 64, 64, 1], batch_size=B,
+                                    device=dev, seed=5, max_grad_norm=max_norm, lr_policy=1e-3, lr_q=1e-3, lr_alpha=1e-3, wd_q=1e-3,
+                                    two_launch=two)
+    ups = [mk(True), mk(False)]
+    init = torch.randn(ups[0].NP, generator=g) * 0.1
+    for up in ups:
         up.load_state(init.to(dev))
-        ups.append(up)
     D = 2 * X + U + 3
+    clipped = 0
     for it in range(6):
         batch = torch.randn(B, D, generator=g).to(dev)
         batch[:, -1] = (torch.rand(B, generator=g) < 0.1).float().to(dev)
-        for up in ups:
-            up.sgd_step(batch)
+        ups[0].sgd_step(batch, offset=it, defer_clip_check=(mode == "deferred"))
+        ups[1].sgd_step(batch, offset=it)
+        gn = float(ups[1].grads[:ups[1].P].norm())
+        clipped += gn >= max_norm
+    ups[0].finalize()
+    ups[0].finalize()          # idempotent
     torch.cuda.synchronize()
     a, b = ups
     assert float(a.step_count) == float(b.step_count) == 6
     for name in ("params", "target_q", "adam_m", "adam_v", "grads", "metrics"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
-    assert int(a.workspace[-4:].view(torch.int32).abs().sum()) == 0      # counters re-armed
+    assert clipped == (6 if max_norm == 0.05 else 0 if max_norm == 1e5 else clipped)
+    print('policy-group clips:', clipped, 'of 6 at max_norm', max_norm)
+    torch.testing.assert_close(a.metrics_accum, b.metrics_accum, atol=0, rtol=0)
 
 
 def test_sac_non_equidistant_time_target(dev):
