@@ -234,3 +234,117 @@ def test_bptt_data_parallel_two_ranks(tmp_path):
     port = 37500 + (os.getpid() % 2000)
     mp.spawn(_bptt_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"bptt_ok{r}").exists() for r in range(world))
+
+
+# ------------------------------------------------------------------------------------------------ trainer under a process group
+def _trainer_setup(dev, pg, use_graph=True, n_steps=4):
+    from mbpo.optimizers.policy_optimizers.sac.sac import SAC
+    from mbpo.replay import UniformSamplingQueue
+    from mbpo.systems import PendulumSystem
+    from mbpo.systems.brax_wrapper import BraxWrapper
+    from mbpo.types import Transition
+    X, U, N, S = 3, 1, 64, 5
+    system = PendulumSystem()
+    dummy = Transition(observation=torch.zeros(X), action=torch.zeros(U), reward=torch.zeros(1), discount=torch.zeros(1),
+                       next_observation=torch.zeros(X))
+    tb = UniformSamplingQueue(128, dummy, 1, device=dev)
+    g = torch.Generator().manual_seed(0)
+    data = torch.randn(128, 2 * X + U + 2, generator=g)
+    th = (torch.rand(128, generator=g) * 2 - 1) * 3.14159
+    data[:, 0], data[:, 1] = torch.cos(th), torch.sin(th)
+    tbs = tb.insert_rows(tb.init(0), data.to(dev))
+    env = BraxWrapper(system, system.init_params(0), tbs, tb)
+    tr = SAC(environment=env, num_timesteps=64 + N * S * n_steps, episode_length=5, num_env_steps_between_updates=S, num_envs=N,
+             batch_size=64, grad_updates_per_step=3, normalize_observations=True, max_replay_size=1000, min_replay_size=64,
+             use_graph=use_graph, process_group=pg)
+    return tr, env
+
+
+def _run_epoch(tr, env):
+    rk = tr.dp.rank_key
+    ts = tr.init_training_state(7)
+    es = tr.reset_envs(env, rk(11), tr.num_envs)
+    bs = tr.replay_buffer.init(rk(13))
+    ts, es, bs, _ = tr.prefill_replay_buffer(ts, es, bs, rk(17))
+    ts, es, bs, m = tr.training_epoch(ts, es, bs, rk(19))
+    torch.cuda.synchronize()
+    return ts, es, bs, m
+
+
+def _nccl_capture_worker(rank, world, port, tmpdir):
+    """1-rank RCCL group: the training step holds torch.distributed (RCCL) all-reduces and IS captured into a hipGraph
+    (RCCL collectives are stream-ordered kernels).  Result == the group-less trainer, bit for bit (a 1-rank SUM is the identity)."""
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        tr, env = _trainer_setup(dev, dist.group.WORLD)
+        assert tr.p2p is None and tr._capturable()
+        _run_epoch(tr, env)
+        assert tr._graph is not None                              # captured WITH the collectives inside
+        ref, env2 = _trainer_setup(dev, None)
+        _run_epoch(ref, env2)
+        for name in ("params", "target_q", "adam_m", "adam_v"):
+            assert torch.equal(getattr(tr.updater, name), getattr(ref.updater, name)), name
+        assert torch.equal(tr._stats_vec, ref._stats_vec)
+        (Path(tmpdir) / "nccl_capture_ok").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sac_epoch_captured_with_rccl_collectives(tmp_path):
+    """keep the hipGraph when the backend is nccl (RCCL).  In a child process: a capture that a collective
+    invalidates cannot be recovered from in-process (round 1: hipErrorStreamCaptureInvalidated, then SIGSEGV) — here it must
+    simply work."""
+    port = 39500 + (os.getpid() % 2000)
+    mp.spawn(_nccl_capture_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "nccl_capture_ok").exists()
+
+
+def _trainer_dp_worker(rank, world, port, tmpdir, fail_rank):
+    """Two ranks on the one GPU (gloo moves the tensors): per-rank DATA keys (rollout rows differ between ranks), identical
+    parameters after the epoch, and — gloo being a host-side collective — the step is issued eagerly, never captured (the
+    guarded path: round 1's abort was a gloo collective inside a capture).  fail_rank >= 0: that rank reports a failed peer-memory
+    self-check; create() must decline on BOTH ranks without deadlock and training proceeds over the library collective."""
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if fail_rank >= 0:
+        os.environ["MBPO_P2P_TEST_FAIL_RANK"] = str(fail_rank)
+    else:
+        os.environ["MBPO_P2P_ALLREDUCE"] = "0"                    # library collective: the eager, uncaptured path
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tr, env = _trainer_setup(dev, dist.group.WORLD)
+        assert tr.p2p is None                                      # declined (forced failure) or switched off — on every rank
+        assert not tr._capturable()
+        ts, es, bs, m = _run_epoch(tr, env)
+        assert tr._graph is None                                   # never captured with a host-side collective inside
+        rows = [torch.zeros_like(tr._rollout_rows) for _ in range(world)]
+        dist.all_gather(rows, tr._rollout_rows)
+        assert not torch.equal(rows[0], rows[1])                   # ranks roll out DIFFERENT envs with different noise
+        for t in (tr.updater.params, tr.updater.target_q, tr._stats_vec):
+            ts_ = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(ts_, t)
+            assert torch.equal(ts_[0], ts_[1]) and bool(torch.isfinite(t).all())       # replicas stay bit-identical
+        assert float(tr._stats_vec[0]) == world * (1 + 4) * 64 * 5                     # normaliser counts BOTH ranks' observations
+        tr.close()
+        (Path(tmpdir) / f"dp_ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_sac_trainer_two_ranks_rank_keys_and_guarded_capture(tmp_path, fail_rank):
+    world = 2
+    port = 41500 + (os.getpid() % 2000) + (11 if fail_rank >= 0 else 0)
+    mp.spawn(_trainer_dp_worker, args=(world, port, str(tmp_path), fail_rank), nprocs=world, join=True)
+    assert all((tmp_path / f"dp_ok{r}").exists() for r in range(world))
