@@ -68,10 +68,16 @@ extern "C" int mbpo_replay_insert(float *data, int64_t max_size, int32_t row_len
 }
 
 // SAMPLE: false -> idx given (gather); true -> idx from Philox
+// A workgroup takes 256 rows at a time: every thread resolves ONE row's physical position (one Philox block per row — the first
+// version drew it again for every one of the row's D floats), then the 256 rows are copied cooperatively, 16 bytes per lane
+// when D is a multiple of 4 (rows of 2x+u+3 floats with x=4,u=1 are 48 bytes: three lanes per row, consecutive lanes write
+// consecutive 16-byte pieces of `out`).  The gather side reads whole rows, i.e. every 64-byte sector it touches is used at 75 %
+// or more; the scatter into random rows of a table much larger than L2 is what bounds this kernel below the streaming rate.
 template <bool SAMPLE>
 __global__ void __launch_bounds__(256) k_replay_gather(const float *data, long long max_size, int D, const int *state,
                                                         const int *idx, unsigned long long seed, unsigned long long offset,
                                                         const unsigned long long *rng_dev, long long n, int *idx_out, float *out) {
+  __shared__ long long s_phys[256];
   if (SAMPLE) {
     const RngKey rk = rng_resolve(seed, offset, rng_dev);
     seed = rk.seed;
@@ -79,23 +85,43 @@ __global__ void __launch_bounds__(256) k_replay_gather(const float *data, long l
   }
   const int head = state[2];
   const int lo = state[1], hi = state[0];
-  const long long total = n * D;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    long long j = i / D;
-    int c = (int)(i - j * D);
-    long long li;
-    if (SAMPLE) {
-      // jax.random.randint(sample_key, (n,), minval=sample_position, maxval=insert_position) — stream restated with Philox
-      li = philox_randint(seed, offset, MBPO_STREAM_REPLAY, (unsigned long long)j, lo, hi);
-      if (idx_out && c == 0) idx_out[j] = (int)li;
-    } else {
-      li = idx[j];
+  const int tid = threadIdx.x;
+  const bool vec = (D & 3) == 0 && ((((unsigned long long)data) | ((unsigned long long)out)) & 15ull) == 0;
+  for (long long row0 = (long long)blockIdx.x * 256; row0 < n; row0 += (long long)gridDim.x * 256) {
+    const long long j = row0 + tid;
+    if (j < n) {
+      long long li;
+      if (SAMPLE) {
+        // jax.random.randint(sample_key, (n,), minval=sample_position, maxval=insert_position) — stream restated with Philox
+        li = philox_randint(seed, offset, MBPO_STREAM_REPLAY, (unsigned long long)j, lo, hi);
+        if (idx_out) idx_out[j] = (int)li;
+      } else {
+        li = idx[j];
+      }
+      // jnp.take(mode='wrap'): python-style modulo
+      long long w = li % max_size;
+      if (w < 0) w += max_size;
+      s_phys[tid] = (w + head) % max_size;
     }
-    // jnp.take(mode='wrap'): python-style modulo
-    long long w = li % max_size;
-    if (w < 0) w += max_size;
-    long long phys = (w + head) % max_size;
-    out[i] = data[phys * D + c];
+    __syncthreads();
+    const int rows_here = (int)((n - row0) < 256 ? (n - row0) : 256);
+    if (vec) {
+      const int D4 = D >> 2, total = rows_here * D4;
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(data);
+      f32x4 *dst = reinterpret_cast<f32x4 *>(out) + row0 * D4;
+      for (int e = tid; e < total; e += 256) {
+        const int r = e / D4, c = e - r * D4;
+        dst[e] = src[s_phys[r] * D4 + c];
+      }
+    } else {
+      const int total = rows_here * D;
+      float *dst = out + row0 * D;
+      for (int e = tid; e < total; e += 256) {
+        const int r = e / D, c = e - r * D;
+        dst[e] = data[s_phys[r] * D + c];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -105,8 +131,7 @@ extern "C" int mbpo_replay_gather(const float *data, int64_t max_size, int32_t r
   MBPO_REQUIRE(max_size > 0 && row_len > 0 && n >= 0, MBPO_ERR_ARG, "replay_gather: bad sizes");
   if (n == 0) return MBPO_OK;
   MBPO_REQUIRE(idx && out, MBPO_ERR_ARG, "replay_gather: null idx/out");
-  long long total = n * row_len;
-  int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(k_replay_gather<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, (long long)max_size, row_len,
                      state, idx, 0ull, 0ull, (const unsigned long long *)nullptr, (long long)n, (int *)nullptr, out);
   MBPO_CHECK_LAUNCH("replay_gather");
@@ -120,8 +145,7 @@ extern "C" int mbpo_replay_sample(const float *data, int64_t max_size, int32_t r
   MBPO_REQUIRE(max_size > 0 && row_len > 0 && n >= 0, MBPO_ERR_ARG, "replay_sample: bad sizes");
   if (n == 0) return MBPO_OK;
   MBPO_REQUIRE(out, MBPO_ERR_ARG, "replay_sample: null out");
-  long long total = n * row_len;
-  int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(k_replay_gather<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, (long long)max_size, row_len,
                      state, (const int *)nullptr, (unsigned long long)seed, (unsigned long long)offset, (const unsigned long long *)rng_dev, (long long)n, idx_out, out);
   MBPO_CHECK_LAUNCH("replay_sample");

@@ -896,6 +896,9 @@ static int sac_plan(const mbpo_sac_desc *d, SacPlan *pl, bool need_ptrs) {
   size_t f = 16ull * up4(d->row_len) + 2ull * 16 * pl->ld_x + 2ull * 16 * pl->ld_xu + 4ull * 16 * pl->ld_h +
              (size_t)pl->LH * 4 * 16 * pl->ld_h + 5ull * 16 * pl->ld_y + 2ull * 16 * pl->ld_xu + 6ull * up4(16 * U) + 64 + 4;
   pl->lds = f * sizeof(float);
+  MBPO_REQUIRE(pl->lds <= 160 * 1024, MBPO_ERR_UNSUPPORTED,
+               "sac: a 16-sample tile of these networks needs %zu B of LDS (> 160 KiB): %d hidden layers of width %d do not fit; "
+               "use fewer / narrower hidden layers (INTEGRATION.md, 'Network shapes')", pl->lds, pl->LH, Hp);
   pl->off_slab_pi = 0;
   pl->off_slab_q = pl->off_slab_pi + (long long)pl->n_tiles * pl->P;
   pl->off_slab_ex = pl->off_slab_q + (long long)pl->n_tiles * 2 * pl->Q;

@@ -133,6 +133,96 @@ __global__ void __launch_bounds__(256) k_scan_batch_major(ScanArgs A) {
   }
 }
 
+// batch-major, T a multiple of 4 (and T <= 256): every lane owns FOUR consecutive time steps of a row (one 16-byte load per input
+// array instead of four 4-byte ones), TL = T/4 lanes make a row and floor(64/TL) rows share a wave — at T = 40 that is 6 rows on 60
+// lanes where the one-step-per-lane kernel above puts 1 row on 40.  In-lane the four affine maps are composed sequentially, across
+// the lanes of a row with a segmented Hillis-Steele suffix scan (ceil(log2 TL) shuffle rounds), then the lane walks its four steps.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_scan_batch_major_v4(ScanArgs A, int TL, int RPW) {
+  const int lane = threadIdx.x & 63;
+  const int seg = lane / TL, tl = lane - seg * TL;
+  const long long wave_global = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long n_groups = (A.B + RPW - 1) / RPW;
+  const int T = A.T;
+  for (long long grp = wave_global; grp < n_groups; grp += n_waves) {
+    const long long b = grp * RPW + seg;
+    const bool ok = seg < RPW && b < A.B;
+    const long long i = ok ? b * T + 4 * tl : 0;
+    f32x4 r4 = {0.f, 0.f, 0.f, 0.f}, v4 = r4, m4 = r4, g4 = r4;
+    float c[4] = {1.f, 1.f, 1.f, 1.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+    float carry = 0.f, boot = 0.f;
+    if (ok) {
+      r4 = *reinterpret_cast<const f32x4 *>(A.rew + i);
+      v4 = *reinterpret_cast<const f32x4 *>(A.val + i);
+      if (MODE == MODE_GAE) {
+        const f32x4 tr = *reinterpret_cast<const f32x4 *>(A.trunc + i), te = *reinterpret_cast<const f32x4 *>(A.term + i);
+        f32x4 ds = {A.gamma, A.gamma, A.gamma, A.gamma};
+        if (A.disc) ds = *reinterpret_cast<const f32x4 *>(A.disc + i);
+        boot = A.boot[b];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          m4[k] = 1.f - tr[k];
+          g4[k] = ds[k] * (1.f - te[k]);
+        }
+      } else {
+        carry = A.val[b * T + (T - 1)];
+      }
+    }
+    // the value one step past this lane's four: the next lane's first, or the bootstrap at the end of the row
+    float v_after = __shfl_down(v4[0], 1, 64);
+    if (tl == TL - 1) v_after = boot;
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (MODE == MODE_GAE) {
+          const float v_next = k < 3 ? v4[k + 1] : v_after;
+          d[k] = (r4[k] + g4[k] * v_next - v4[k]) * m4[k];        // losses.py:157-158
+          c[k] = g4[k] * m4[k] * A.lam;                            // :166
+        } else {
+          d[k] = r4[k] + A.gamma * v4[k] * (1.f - A.lam);          // optimizer_utils.py:128
+          c[k] = A.gamma * A.lam;
+        }
+      }
+    }
+    // the lane's four steps as one map  a_first = D + C * a_after
+    float C = c[0] * c[1] * c[2] * c[3];
+    float D = d[0] + c[0] * (d[1] + c[1] * (d[2] + c[2] * d[3]));
+    for (int off = 1; off < TL; off <<= 1) {      // inclusive suffix scan over the lanes of one row
+      const float C2 = __shfl_down(C, off, 64), D2 = __shfl_down(D, off, 64);
+      if (tl + off < TL) {
+        D = D + C * D2;
+        C = C * C2;
+      }
+    }
+    // what enters this lane from the right: the next lane's inclusive result applied to the row's carry
+    const float Cn = __shfl_down(C, 1, 64), Dn = __shfl_down(D, 1, 64);
+    float a_in = (tl == TL - 1) ? carry : Dn + Cn * carry;
+    float a[4];
+#pragma unroll
+    for (int k = 3; k >= 0; --k) {
+      a[k] = d[k] + c[k] * a_in;
+      a_in = a[k];
+    }
+    if (MODE == MODE_GAE) {
+      f32x4 vs, adv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) vs[k] = a[k] + v4[k];                     // :176
+      float vs_after = __shfl_down(vs[0], 1, 64);
+      if (tl == TL - 1) vs_after = boot;                                    // :179-180
+#pragma unroll
+      for (int k = 0; k < 4; ++k) adv[k] = (r4[k] + g4[k] * (k < 3 ? vs[k + 1] : vs_after) - v4[k]) * m4[k];   // :181-182
+      if (ok) {
+        *reinterpret_cast<f32x4 *>(A.out0 + i) = vs;
+        *reinterpret_cast<f32x4 *>(A.out1 + i) = adv;
+      }
+    } else if (ok) {
+      f32x4 o = {a[0], a[1], a[2], a[3]};
+      *reinterpret_cast<f32x4 *>(A.out0 + i) = o;
+    }
+  }
+}
+
 template <int MODE>
 static int launch_scan(const ScanArgs &A, int time_major, hipStream_t st, const char *what) {
   if (A.B == 0 || A.T == 0) return MBPO_OK;
@@ -141,6 +231,22 @@ static int launch_scan(const ScanArgs &A, int time_major, hipStream_t st, const 
     int grid = (int)(blocks < 2048 ? blocks : 2048);
     hipLaunchKernelGGL(k_scan_time_major<MODE>, dim3(grid), dim3(256), 0, st, A);
   } else {
+    // 16-byte form: T a multiple of 4 (rows then start on 16-byte boundaries whenever the arrays do), at most 64 lanes per row
+    const unsigned long long al = (unsigned long long)A.rew | (unsigned long long)A.val | (unsigned long long)A.out0 |
+                                  (unsigned long long)A.trunc | (unsigned long long)A.term | (unsigned long long)A.out1 | (unsigned long long)A.disc;
+    if ((A.T & 3) == 0 && A.T >= 8 && A.T <= 256 && (al & 15ull) == 0) {
+      const int TL = A.T / 4, RPW = 64 / TL;
+      const long long groups = (A.B + RPW - 1) / RPW;
+      const long long blocks = (groups + 3) / 4;
+      const int grid = (int)(blocks < 4096 ? blocks : 4096);
+      hipLaunchKernelGGL(k_scan_batch_major_v4<MODE>, dim3(grid), dim3(256), 0, st, A, TL, RPW);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) {
+        mbpo_set_error("%s: %s", what, hipGetErrorString(e));
+        return MBPO_ERR_LAUNCH;
+      }
+      return MBPO_OK;
+    }
     int tp = 1;
     while (tp < A.T && tp < 64) tp <<= 1;
     long long groups = (A.B + (64 / tp) - 1) / (64 / tp);

@@ -57,6 +57,67 @@ def ensemble_mlp_forward(params: torch.Tensor, spec: MlpSpec, x: torch.Tensor, s
     return y
 
 
+# ------------------------------------------------------------------------------------------------ hidden-width padding
+# The MFMA kernels are built for hidden layers of ONE width per launch (64 or 128; the rollout also 256).  The reference accepts
+# any sizes (experiments/train_inverted_pendulum/exp_ppo.py: policy (32,)*4 beside critic (256,)*5).  Narrower or unequal hidden
+# layers are therefore ZERO-PADDED to a common supported width: a padded unit has zero incoming weights and bias, so its
+# pre-activation is 0 and swish/relu/tanh(0) = 0 — it contributes nothing forward; its outgoing weights are zero, so its delta and
+# every gradient that touches a padded weight is 0, and AdamW leaves an all-zero (p, g, m, v) exactly where it is (update
+# 0 / (0 + eps) + wd * 0).  The padding is a fixed point of training: the padded network IS the logical one, bit for bit in
+# exact arithmetic (the k-ordered fp32 sums gain only +0.0 terms).
+KERNEL_WIDTHS = (64, 128)
+
+
+def common_width(*hidden_size_lists, supported=KERNEL_WIDTHS, what: str = "networks") -> int:
+    """Smallest supported width >= every hidden size given (each argument is a sequence of hidden sizes, possibly empty)."""
+    m = max([int(h) for hs in hidden_size_lists for h in hs], default=supported[0])
+    for w in supported:
+        if m <= w:
+            return w
+    raise _hip.MbpoHipError(f"{what}: hidden width {m} exceeds what the MI355X kernels are built for (max {supported[-1]}; see "
+                            "INTEGRATION.md, 'Network shapes')")
+
+
+def padded_dims(dims: Sequence[int], width: int) -> list:
+    d = [int(v) for v in dims]
+    return [d[0]] + [width] * (len(d) - 2) + [d[-1]]
+
+
+def embed_mlp_params(flat: torch.Tensor, dims: Sequence[int], width: int, n_nets: int = 1) -> torch.Tensor:
+    """Flat params of `n_nets` MLPs with `dims` -> the same networks with every hidden layer zero-padded to `width`."""
+    d, dp = [int(v) for v in dims], padded_dims(dims, width)
+    if d == dp:
+        return flat
+    n, npad = sum(d[i] * d[i + 1] + d[i + 1] for i in range(len(d) - 1)), sum(dp[i] * dp[i + 1] + dp[i + 1] for i in range(len(d) - 1))
+    out = torch.zeros(n_nets * npad, dtype=flat.dtype, device=flat.device)
+    for e in range(n_nets):
+        o, op = e * n, e * npad
+        for i in range(len(d) - 1):
+            w = flat[o:o + d[i] * d[i + 1]].reshape(d[i], d[i + 1])
+            out[op:op + dp[i] * dp[i + 1]].reshape(dp[i], dp[i + 1])[:d[i], :d[i + 1]] = w
+            o += d[i] * d[i + 1]; op += dp[i] * dp[i + 1]
+            out[op:op + d[i + 1]] = flat[o:o + d[i + 1]]
+            o += d[i + 1]; op += dp[i + 1]
+    return out
+
+
+def extract_mlp_params(flat_padded: torch.Tensor, dims: Sequence[int], width: int, n_nets: int = 1) -> torch.Tensor:
+    """Inverse of embed_mlp_params: the logical networks' flat params out of the padded ones."""
+    d, dp = [int(v) for v in dims], padded_dims(dims, width)
+    if d == dp:
+        return flat_padded
+    n, npad = sum(d[i] * d[i + 1] + d[i + 1] for i in range(len(d) - 1)), sum(dp[i] * dp[i + 1] + dp[i + 1] for i in range(len(d) - 1))
+    out = torch.zeros(n_nets * n, dtype=flat_padded.dtype, device=flat_padded.device)
+    for e in range(n_nets):
+        o, op = e * n, e * npad
+        for i in range(len(d) - 1):
+            out[o:o + d[i] * d[i + 1]] = flat_padded[op:op + dp[i] * dp[i + 1]].reshape(dp[i], dp[i + 1])[:d[i], :d[i + 1]].reshape(-1)
+            o += d[i] * d[i + 1]; op += dp[i] * dp[i + 1]
+            out[o:o + d[i + 1]] = flat_padded[op:op + d[i + 1]]
+            o += d[i + 1]; op += dp[i + 1]
+    return out
+
+
 def make_rng(device, seed: int = 0, counter: int = 0) -> torch.Tensor:
     """Device RNG control words (include/mbpo_hip.h "randomness"): int64[2] holding the uint64 pair {seed word, step counter}."""
     t = torch.zeros(2, dtype=torch.int64, device=device)

@@ -194,8 +194,13 @@ class BPTTOptimizer(BaseOptimizer):
         self.obs_dim, self.action_dim = int(obs_dim), int(action_dim)
         self.state_normalizer = Normalizer((self.obs_dim,))
         self.reward_normalizer = Normalizer((1,))
-        self.actor_dims = [self.obs_dim, *[int(f) for f in actor_features], 2 * self.action_dim]
-        self.critic_dims = [self.obs_dim, *[int(f) for f in critic_features], 1]
+        # logical shapes and kernel shapes: the BPTT kernels are built for 64-wide hidden layers; narrower ones are zero-padded
+        # (ops.py "hidden-width padding"), wider ones are refused (INTEGRATION.md "Network shapes")
+        self.actor_dims_logical = [self.obs_dim, *[int(f) for f in actor_features], 2 * self.action_dim]
+        self.critic_dims_logical = [self.obs_dim, *[int(f) for f in critic_features], 1]
+        self.kernel_width = ops.common_width(actor_features, critic_features, supported=(64,), what="BPTT")
+        self.actor_dims = ops.padded_dims(self.actor_dims_logical, self.kernel_width)
+        self.critic_dims = ops.padded_dims(self.critic_dims_logical, self.kernel_width)
         self.policy_activation, self.critic_activation = policy_activation, critic_activation
         self.actor_spec = ops.MlpSpec(self.actor_dims, policy_activation, 1)
         self.critic_spec = ops.MlpSpec(self.critic_dims, critic_activation, 2)
@@ -266,9 +271,11 @@ class BPTTOptimizer(BaseOptimizer):
         critic_key, actor_key, system_key, key = K.split(key, 4)
         dev = self.device
         gen = torch.Generator().manual_seed(int(critic_key) % (2 ** 63))
-        critic_params = torch.cat([lecun_normal_flat(self.critic_dims, gen), lecun_normal_flat(self.critic_dims, gen)]).to(dev)
+        emb = lambda flat, dims: ops.embed_mlp_params(flat, dims, self.kernel_width)
+        critic_params = torch.cat([emb(lecun_normal_flat(self.critic_dims_logical, gen), self.critic_dims_logical),
+                                   emb(lecun_normal_flat(self.critic_dims_logical, gen), self.critic_dims_logical)]).to(dev)
         gen = torch.Generator().manual_seed(int(actor_key) % (2 ** 63))
-        actor_params = lecun_normal_flat(self.actor_dims, gen).to(dev)
+        actor_params = emb(lecun_normal_flat(self.actor_dims_logical, gen), self.actor_dims_logical).to(dev)
         self.dp.broadcast(actor_params)
         self.dp.broadcast(critic_params)
         z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)

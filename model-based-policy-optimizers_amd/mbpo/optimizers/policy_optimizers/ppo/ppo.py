@@ -111,8 +111,15 @@ class PPO:
         self.env = environment
         self.x_dim, self.u_dim = self.env.observation_size, self.env.action_size
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.policy_dims = [self.x_dim, *policy_hidden_layer_sizes, 2 * self.u_dim]
-        self.value_dims = [self.x_dim, *critic_hidden_layer_sizes, 1]
+        self.policy_dims_logical = [self.x_dim, *policy_hidden_layer_sizes, 2 * self.u_dim]
+        self.value_dims_logical = [self.x_dim, *critic_hidden_layer_sizes, 1]
+        dyn_hidden = list(getattr(getattr(self.env.system, "dynamics", None), "dims", [])[1:-1]) if self.env.system.fused else []
+        self.kernel_width = ops.common_width(policy_hidden_layer_sizes, critic_hidden_layer_sizes, dyn_hidden, what="PPO")
+        if dyn_hidden and any(h != self.kernel_width for h in dyn_hidden):
+            raise _hip.MbpoHipError(f"PPO: the learned ensemble's hidden width {dyn_hidden} must equal the policy/value kernel width "
+                                    f"{self.kernel_width} inside the fused rollout (build the EnsembleDynamics with that width)")
+        self.policy_dims = ops.padded_dims(self.policy_dims_logical, self.kernel_width)     # hidden layers zero-padded (ops.py)
+        self.value_dims = ops.padded_dims(self.value_dims_logical, self.kernel_width)
         self.policy_spec = ops.MlpSpec(self.policy_dims, policy_activation, 1)
         self.dp = DataParallel(process_group)
         self._all_reduce = self.dp.all_reduce_fn()
@@ -168,8 +175,10 @@ class PPO:
     def init_training_state(self, key: int) -> TrainingState:
         """ppo.py:265-277."""
         k0, k1 = K.split(key)
-        pol = lecun_uniform_flat(self.policy_dims, torch.Generator().manual_seed(k0 % (2 ** 63)))
-        val = lecun_uniform_flat(self.value_dims, torch.Generator().manual_seed(k1 % (2 ** 63)))
+        pol = ops.embed_mlp_params(lecun_uniform_flat(self.policy_dims_logical, torch.Generator().manual_seed(k0 % (2 ** 63))),
+                                   self.policy_dims_logical, self.kernel_width)
+        val = ops.embed_mlp_params(lecun_uniform_flat(self.value_dims_logical, torch.Generator().manual_seed(k1 % (2 ** 63))),
+                                   self.value_dims_logical, self.kernel_width)
         params = torch.cat([pol, val]).to(self.device)
         self.dp.broadcast(params, src=0)
         self.updater.load_state(params)

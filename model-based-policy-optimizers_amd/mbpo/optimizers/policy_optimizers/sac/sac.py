@@ -173,8 +173,17 @@ class SAC:
         self.x_dim = self.env.observation_size
         self.u_dim = self.env.action_size
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.policy_dims = [self.x_dim, *policy_hidden_layer_sizes, 2 * self.u_dim]
-        self.q_dims = [self.x_dim + self.u_dim, *critic_hidden_layer_sizes, 1]
+        # logical shapes (what the user asked for) and kernel shapes (hidden layers zero-padded to one supported width: ops.py
+        # "hidden-width padding"; a learned ensemble inside the fused rollout must share that width)
+        self.policy_dims_logical = [self.x_dim, *policy_hidden_layer_sizes, 2 * self.u_dim]
+        self.q_dims_logical = [self.x_dim + self.u_dim, *critic_hidden_layer_sizes, 1]
+        dyn_hidden = list(getattr(getattr(self.env.system, "dynamics", None), "dims", [])[1:-1]) if self.env.system.fused else []
+        self.kernel_width = ops.common_width(policy_hidden_layer_sizes, critic_hidden_layer_sizes, dyn_hidden, what="SAC")
+        if dyn_hidden and any(h != self.kernel_width for h in dyn_hidden):
+            raise _hip.MbpoHipError(f"SAC: the learned ensemble's hidden width {dyn_hidden} must equal the policy/critic kernel width "
+                                    f"{self.kernel_width} inside the fused rollout (build the EnsembleDynamics with that width)")
+        self.policy_dims = ops.padded_dims(self.policy_dims_logical, self.kernel_width)
+        self.q_dims = ops.padded_dims(self.q_dims_logical, self.kernel_width)
         self.policy_spec = ops.MlpSpec(self.policy_dims, policy_activation, 1)
         # data-parallel ranks (the live form of _PMAP_AXIS_NAME, sac.py:188-189): one process per GPU
         self.process_group = process_group
@@ -246,8 +255,10 @@ class SAC:
         key_policy, key_q = K.split(key)
         gp = torch.Generator().manual_seed(key_policy % (2 ** 63))
         gq = torch.Generator().manual_seed(key_q % (2 ** 63))
-        pol = lecun_uniform_flat(self.policy_dims, gp)
-        q = torch.cat([lecun_uniform_flat(self.q_dims, gq) for _ in range(2)])
+        # lecun-uniform at the LOGICAL fan-ins, then embedded into the (possibly wider) kernel shape
+        pol = ops.embed_mlp_params(lecun_uniform_flat(self.policy_dims_logical, gp), self.policy_dims_logical, self.kernel_width)
+        q = torch.cat([ops.embed_mlp_params(lecun_uniform_flat(self.q_dims_logical, gq), self.q_dims_logical, self.kernel_width)
+                       for _ in range(2)])
         params = torch.cat([pol, q, torch.tensor([self.init_log_alpha], dtype=torch.float32)]).to(self.device)
         self.dp.broadcast(params, src=0)     # identical replicas: rank 0's initialisation everywhere
         self.updater.load_state(params)

@@ -237,3 +237,95 @@ def test_sac_step_against_committed_golden(dev):
     d = (up.params.cpu().double() - torch.from_numpy(gold["new_params"])).abs()
     assert float(d.max()) <= 4.1e-3 and float((d > 1e-5).float().mean()) < 0.01      # at most a few sign flips of size 2*lr
     torch.testing.assert_close(up.target_q.cpu().double(), torch.from_numpy(gold["new_target_q"]), atol=5e-5, rtol=0)
+
+
+# ------------------------------------------------------------------------------------------------ hidden-width padding
+def test_embed_extract_roundtrip_cpu_side():
+    from mbpo import ops
+    g = torch.Generator().manual_seed(0)
+    dims = [5, 32, 48, 32, 3]
+    flat = torch.randn(2 * sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(4)), generator=g)
+    pad = ops.embed_mlp_params(flat, dims, 64, n_nets=2)
+    assert pad.numel() == 2 * ops.MlpSpec(ops.padded_dims(dims, 64)).n_params
+    assert torch.equal(ops.extract_mlp_params(pad, dims, 64, n_nets=2), flat)
+    assert ops.common_width((32, 32), (64,)) == 64 and ops.common_width((100,), ()) == 128
+    with pytest.raises(Exception):
+        ops.common_width((256,))
+
+
+@pytest.mark.parametrize("ph,qh", [((32, 32, 32, 32), (64, 64, 64)), ((48, 48), (100, 100, 100)), ((64, 64, 64), (32, 32))])
+def test_sac_padded_widths_match_the_logical_networks(dev, ph, qh):
+    """the reference accepts any hidden sizes (exp_ppo.py: policy (32,)*4 beside critic (256,)*5).  Unequal / narrow
+    hidden layers are zero-padded to one kernel width; the padded networks ARE the logical ones: 5 chained sgd_steps on the
+    padded HIP state vs the oracle on the LOGICAL shapes (rel L2 like test_sac_chained_steps), and every padded entry of params,
+    moments and target stays exactly zero."""
+    from mbpo import ops
+    X, U, B = 4, 1, 64
+    pd, qd = [X, *ph, 2 * U], [X + U, *qh, 1]
+    W = ops.common_width(ph, qh)
+    cfg = osac.SacConfig(X, U, pd, qd, lr_policy=1e-3, lr_q=1e-3, lr_alpha=1e-3, wd_q=1e-3)
+    g = torch.Generator().manual_seed(1)
+    st = osac.init_state(cfg, g)
+    P, Q = cfg.P, cfg.Q
+    emb = lambda flat, dims: ops.embed_mlp_params(flat, dims, W)
+    padded = torch.cat([emb(st.params[:P], pd), emb(st.params[P:P + Q], qd), emb(st.params[P + Q:P + 2 * Q], qd), st.params[-1:]])
+    pdp, qdp = ops.padded_dims(pd, W), ops.padded_dims(qd, W)
+    up = ops.SacUpdater(x_dim=X, u_dim=U, policy_dims=pdp, q_dims=qdp, batch_size=B, device=dev, lr_policy=1e-3, lr_q=1e-3,
+                        lr_alpha=1e-3, wd_q=1e-3)
+    up.load_state(padded.to(dev))
+    D = 2 * X + U + 3
+    for it in range(5):
+        batch = torch.randn(B, D, generator=g)
+        batch[:, X + U + 1] = 1.0
+        batch[:, D - 1] = (torch.rand(B, generator=g) < 0.1).float()
+        noise = [torch.randn(B, U, generator=g) for _ in range(3)]
+        st, _, _ = osac.sgd_step(cfg, st, batch, *noise)
+        up.sgd_step(batch.to(dev), None, None, *[n.to(dev) for n in noise])
+    Pp, Qp = up.P, up.Q
+    ext = lambda flat, dims: ops.extract_mlp_params(flat, dims, W)
+    for name, ref in (("params", st.params), ("adam_m", st.adam_m), ("adam_v", st.adam_v)):
+        t = getattr(up, name).cpu()
+        logical = torch.cat([ext(t[:Pp], pd), ext(t[Pp:Pp + Qp], qd), ext(t[Pp + Qp:Pp + 2 * Qp], qd), t[-1:]])
+        rel = float((logical - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert rel < (2e-3 if name == "adam_v" else 1e-3), (name, rel)
+        # what is NOT a logical entry is exactly zero
+        back = torch.cat([emb(logical[:P], pd), emb(logical[P:P + Q], qd), emb(logical[P + Q:P + 2 * Q], qd), logical[-1:]])
+        assert torch.equal(back, t), name
+    tq = up.target_q.cpu()
+    assert torch.equal(torch.cat([emb(ext(tq[:Qp], qd), qd), emb(ext(tq[Qp:], qd), qd)]), tq)
+
+
+def test_sac_trainer_accepts_reference_experiment_shapes(dev):
+    """exp.py / exp_ppo.py-like shapes through the trainers: policy (32,)*4 with critic (128,)*3 trains; a 256-wide critic is
+    refused with a message that names the cap (INTEGRATION.md "Network shapes")."""
+    from mbpo import _hip
+    from mbpo.optimizers.policy_optimizers.ppo.ppo import PPO
+    from mbpo.optimizers.policy_optimizers.sac.sac import SAC
+    from mbpo.replay import UniformSamplingQueue
+    from mbpo.systems import PendulumSystem
+    from mbpo.systems.brax_wrapper import BraxWrapper
+    from mbpo.types import Transition
+    X, U = 3, 1
+    system = PendulumSystem()
+    dummy = Transition(observation=torch.zeros(X), action=torch.zeros(U), reward=torch.zeros(1), discount=torch.zeros(1),
+                       next_observation=torch.zeros(X))
+    tb = UniformSamplingQueue(16, dummy, 1, device=dev)
+    tbs = tb.insert_rows(tb.init(0), torch.randn(16, 2 * X + U + 2, generator=torch.Generator().manual_seed(0)).to(dev))
+    env = BraxWrapper(system, system.init_params(0), tbs, tb)
+    tr = SAC(environment=env, num_timesteps=32 + 32 * 2 * 3, episode_length=10, num_env_steps_between_updates=2, num_envs=32, batch_size=32,
+             grad_updates_per_step=2, min_replay_size=32, policy_hidden_layer_sizes=(32,) * 4, critic_hidden_layer_sizes=(48,) * 3)
+    assert tr.kernel_width == 64 and tr.policy_dims == [3, 64, 64, 64, 64, 2] and tr.policy_dims_logical == [3, 32, 32, 32, 32, 2]
+    params, metrics = tr.run_training(key=1)
+    assert bool(torch.isfinite(params[1]).all()) and "eval/episode_reward" in metrics[-1]
+    pp = PPO(environment=env, num_timesteps=2000, episode_length=10, num_envs=32, unroll_length=5, batch_size=16, num_minibatches=2,
+             policy_hidden_layer_sizes=(32,) * 4, critic_hidden_layer_sizes=(48,) * 5)
+    assert pp.kernel_width == 64
+    params, metrics = pp.run_training(key=2)
+    assert bool(torch.isfinite(params[1]).all())
+    with pytest.raises(_hip.MbpoHipError, match="exceeds"):
+        SAC(environment=env, num_timesteps=1000, episode_length=10, critic_hidden_layer_sizes=(256,) * 5)
+    # four 128-wide hidden layers: the stored activations of a tile exceed the 160 KiB of LDS — refused at construction, by name
+    with pytest.raises(_hip.MbpoHipError, match="LDS"):
+        SAC(environment=env, num_timesteps=1000, episode_length=10, policy_hidden_layer_sizes=(32,) * 4, critic_hidden_layer_sizes=(128,) * 3)
+    ok = SAC(environment=env, num_timesteps=1000, episode_length=10, policy_hidden_layer_sizes=(100, 100, 100), critic_hidden_layer_sizes=(128,) * 3)
+    assert ok.kernel_width == 128
