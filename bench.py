@@ -286,16 +286,24 @@ def main():
         t_roll = time_rollout_alone(trainer, ts, env_state, buffer_state)
         achieved = BATCH * flop_per_sample / t_kernel / 1e12
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be collected from inside this process (separate
-        # rocprofv3 --pmc passes, MI355X_MICROARCH.md); the committed measurement of this same command is reported
+        # rocprofv3 --pmc passes, MI355X_MICROARCH.md); the committed measurement of this same command is reported — but only
+        # while the kernel sources still hash to what it was collected on (scripts/make_pmc_traffic.py): a stale file is refused
         traffic, traffic_note = None, "no PMC measurement committed"
         try:
-            pmc = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
-            k = pmc["k_sac_fwd_bwd<64,4,false>"]
-            traffic = int((k["fetch_kb"] + k["write_kb"]) * 1024)
-            traffic_note = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r01_pmc_traffic.json (rocprofv3 --pmc, separate passes); "
-                            "1.64 MB of it are the per-tile gradient slabs (deterministic reduction), reads are L2-absorbed weights")
-        except Exception:      # noqa: BLE001
-            pass
+            sys.path.insert(0, str(ROOT / "scripts"))
+            from make_pmc_traffic import source_sha16
+            pmc = json.loads((ROOT / "profiles" / "r02_pmc_traffic.json").read_text())
+            k = pmc["kernels"]["k_sac_fwd_bwd<64, 4, false>"]
+            if pmc.get("source_sha16") != source_sha16():
+                traffic_note = ("profiles/r02_pmc_traffic.json was collected on other kernel sources (hash mismatch): refused; "
+                                "re-run scripts/collect_pmc.sh + scripts/make_pmc_traffic.py")
+            else:
+                traffic = int((k["fetch_kb"] + k["write_kb"]) * 1024)
+                traffic_note = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r02_pmc_traffic.json (rocprofv3 --pmc, separate passes; "
+                                "source hash checked); 1.64 MB of it are the 16 per-tile gradient slabs the deterministic cross-tile "
+                                "reduction needs, reads are the weights once per XCD")
+        except Exception as e:      # noqa: BLE001
+            traffic_note = f"no usable PMC measurement ({type(e).__name__})"
         out = {
             "metric": "model-rollout transitions/sec + SAC updates/sec, Pendulum 5-ens h=5",
             "value": world * N_ENVS * S_STEPS * args.steps / dt,

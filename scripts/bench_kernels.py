@@ -1,6 +1,6 @@
 """Per-kernel rooflines for every row of SURVEY §8a (the secondary measurements of SURVEY §8d).
 
-    python scripts/bench_kernels.py [--out profiles/r01_kernel_rooflines.json]
+    python scripts/bench_kernels.py [--out profiles/r02_kernel_rooflines.json]
 
 Each entry: the C-ABI entry point, the configuration, average launch time from HIP events on the launch stream, the
 ALGORITHMIC work per unit (SURVEY §8d's figures, restated next to each case), achieved GB/s or TFLOP/s and the fraction of the
@@ -234,9 +234,12 @@ def main():
         batch[:, X + U + 1] = 1.0
         batch[:, -1] = 0.0
         batch = batch.to(dev)
-        t, te = both(lambda: up.sgd_step(batch), reps)
+        # as the trainer issues it: each step's clip check is resolved by the next step's first launch (a scan of sgd_steps ends
+        # in ONE mbpo_sac_finalize, not timed here)
+        t, te = both(lambda: up.sgd_step(batch, defer_clip_check=True), reps)
+        up.finalize()
         flop = B * 2 * (5 * mlp_macs(pd) + 12 * mlp_macs(qd))
-        out.append(mfma_entry("k_sac_fwd_bwd + k_sac_reduce + k_sac_apply", "mbpo_sac_grads + mbpo_sac_apply",
+        out.append(mfma_entry("k_sac_fwd_bwd + k_sac_reduce_apply", "mbpo_sac_step",
                               {"x": X, "u": U, "hidden": list(hidden), "B": B}, t, flop, "2*(5P + 12Q) FLOP per sample",
                               {"updates_per_s": 1.0 / t}))
         log(f"sac sgd_step x={X} {hidden} B={B}: {t * 1e6:.1f} us")
