@@ -46,7 +46,11 @@ struct SacOptArgs {
   float *params, *target_q, *adam_m, *adam_v, *grads, *metrics, *metrics_accum;
   float *undo;                  // [3*NP + Q2]: params | adam_m | adam_v | target_q BEFORE the last speculative step
   const float *step_count, *ss_part;
-  unsigned int *seq;            // [0] speculative steps issued, [1] ... resolved by k_sac_finalize
+  unsigned int *seq;            // [0] speculative steps issued, [1] ... resolved by k_sac_finalize; then, in the same 8 dwords (ONE scalar
+                                // load in k_sac_fwd_bwd): [2..4] and [5..7] two slots of per-group sums of squares formed with float
+                                // atomics by k_sac_reduce_apply (order not fixed: a QUICK, conservative clip test only), step k adds
+                                // to slot k & 1
+  unsigned int *slot_word;      // the slot k & 1 of the step in flight, published by its fwd/bwd launch for its reduce launch
   float *undo_count;            // [0] optax count of the last speculative step (step_count itself is bumped again by the next fwd/bwd
                                 //     launch), [1] metrics_accum[3] before that step added its 'alpha', [2..3] its Adam bias corrections
   int n_parts, P, Q2;
@@ -89,34 +93,6 @@ __device__ __forceinline__ void sac_group_norms(const SacOptArgs &O, float *s_gn
     if (lane == 0) s_gn[w] = sqrtf(ss) * O.grad_scale;
   }
 }
-// The same three sums by ONE wave, in two halves, for k_sac_fwd_bwd: requested at the top of the kernel, added up later by a wave
-// that is idle anyway — the waves of the critical policy chain never wait for them.  Lane l holds terms l and l + 64 of every
-// group (all of them for n_parts <= 128: the 64x3 networks have 103), the rest is read in the second half.
-struct NormReq {
-  float a[3], b[3];
-};
-__device__ __forceinline__ NormReq sac_group_norms_request(const SacOptArgs &O, int lane) {
-  NormReq r;
-#pragma unroll
-  for (int w = 0; w < 3; ++w) {
-    r.a[w] = lane < O.n_parts ? O.ss_part[lane * 3 + w] : 0.f;
-    r.b[w] = lane + 64 < O.n_parts ? O.ss_part[(lane + 64) * 3 + w] : 0.f;
-  }
-  return r;
-}
-// sac_group_norms' order per group: ss = 0 + term(l) + term(l + 64) + ..., then the shuffle tree.
-__device__ __forceinline__ void sac_group_norms_finish(const SacOptArgs &O, const NormReq &r, float *s_gn, int lane) {
-#pragma unroll
-  for (int w = 0; w < 3; ++w) {
-    float ss = 0.f;
-    if (lane < O.n_parts) ss += r.a[w];
-    if (lane + 64 < O.n_parts) ss += r.b[w];
-    for (int p = lane + 128; p < O.n_parts; p += 64) ss += O.ss_part[p * 3 + w];
-    ss = wave_sum64(ss);
-    if (lane == 0) s_gn[w] = sqrtf(ss) * O.grad_scale;
-  }
-}
-
 // The clip fix-up: recompute, from the undo log, the optimizer step of every element whose group's norm reached max_norm
 // ([3P optax.clip_by_global_norm] g <- g if g_norm < max_norm else (g / g_norm) * max_norm).  Every workgroup that runs this writes
 // the SAME values to the same addresses (inputs: grads, undo, step_count, ss_part — all final since the previous launch), so
@@ -272,21 +248,17 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
   }
   // Clip check of the previous speculative optimizer step (k_sac_reduce_apply): the partial sums are requested now, next to the
   // tile and log_alpha loads, and looked at after the section's barrier.
-  // Nothing here may WAIT for a load: a branch on the sequence words at this point would put a whole cold-miss latency in front of
-  // the tile loads and the first-layer weight request (measured: +2 us per launch).  The partials are requested unconditionally
-  // (the buffer always exists) and the sequence words are looked at after the section's barrier.
-  // (This kernel is short of scalar registers — ~130 are spilled — and every value kept across the phase loop costs the lone
-  // waves spill/reload instructions in every phase: the sequence words and the counters block 0 bumps are read here and used up
-  // right after the first barrier.)
-  const unsigned int seq_issued = A.opt.seq[0], seq_resolved = A.opt.seq[1];
+  // Clip check of the previous speculative optimizer step.  Nothing here may WAIT for a load (a branch on these words at this
+  // point put a whole cold-miss latency in front of the tile loads: +2 us per launch), nothing may add work to a wave the other
+  // waves wait for, and nothing may live in registers across the phase loop (this kernel is short of scalar registers; every
+  // such value costs the lone waves spill code in every phase — measured 0.2-0.4 us each).  So: ONE scalar load of eight words
+  // here; after the first barrier they are folded into one flag — "a group's QUICK norm (float atomics of the reduce launch, any
+  // order) is within 1e-4 of max_norm or beyond": practically never.  Only then, behind the phases, are the canonical norms formed
+  // (fixed order: the clip decision and the clipped step are bit-identical to mbpo_sac_apply's).
+  const uint4 qw0 = *reinterpret_cast<const uint4 *>(A.opt.seq), qw1 = *reinterpret_cast<const uint4 *>(A.opt.seq + 4);
   const float count_in = A.step_count_rw[0];
   const unsigned int ep0_in = A.p2p_epoch ? A.p2p_epoch[0] : 0u, ep1_in = A.p2p_epoch ? A.p2p_epoch[1] : 0u;
-  bool spec_pending = false;
-  // The LAST wave of the workgroup forms the norms: it is idle during phase 0 in both roles (critic role: chain 3, actor role:
-  // chains 1-3), so it adds them up there and the decision is taken at the end of phase 0 — in the rare case of a clip the
-  // phase-0 work is thrown away with everything else.
-  NormReq nreq;
-  if (wave == 4 * SP - 1) nreq = sac_group_norms_request(A.opt, tid_ & 63);
+  bool maybe_clip = false;
   // requested now, consumed after the first layer phase: the two scalar loads overlap the tile load instead of preceding it
   const float log_alpha_top = A.log_alpha[0];   // requested now, consumed after the first layer phase
   const RngKey rk_ = rng_resolve(A.seed, A.offset, A.rng_dev);
@@ -326,7 +298,6 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
 #pragma nounroll
   for (int ph = -1; ph < nph; ++ph) {
     const int tid = opaque(tid_), lane = tid & 63;   // keeps per-lane addresses of all phases from being hoisted and spilled
-    if (ph == 0 && wave == 4 * SP - 1) sac_group_norms_finish(A.opt, nreq, s_gn, lane);   // this wave is idle in phase 0 (see above)
     if (ph >= 0) {
       const int len = (role == 0) ? (ph == 0 ? Lmax : QL) : ((ph == 0 || ph == 3) ? PL : QL);
       const NetShape sh = netid == 0 ? A.sh_pi : A.sh_q;
@@ -522,8 +493,19 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
     __syncthreads();
     if (ph == -1) {
       // the words requested at the top have arrived with the tile: use them up (idempotent: a second pass repeats the same stores)
-      spec_pending = seq_issued != seq_resolved;
+      {
+        const unsigned int seq_issued = qw0.x, seq_resolved = qw0.y;
+        const bool odd = (seq_issued & 1u) == 0u;        // the step being checked is number seq_issued - 1: its slot is the OTHER one
+        const float q0 = __uint_as_float(odd ? qw1.y : qw0.z), q1 = __uint_as_float(odd ? qw1.z : qw0.w), q2 = __uint_as_float(odd ? qw1.w : qw1.x);
+        const float lim = (A.opt.max_norm / A.opt.grad_scale) * (A.opt.max_norm / A.opt.grad_scale) * 0.9998f;
+        maybe_clip = seq_issued != seq_resolved && !(q0 < lim && q1 < lim && q2 < lim);
+      }
       if (blockIdx.x == 0 && tid == 0) {
+        // this step's slot: published for the reduce launch, emptied for its atomics
+        const unsigned int slot = qw0.x & 1u;
+        A.opt.slot_word[0] = slot;
+        float *q = reinterpret_cast<float *>(A.opt.seq) + 2 + 3 * slot;
+        q[0] = 0.f; q[1] = 0.f; q[2] = 0.f;
         // optax's count: one per sgd_step.  Nothing in this kernel uses it; the reduce / apply launches of this step read the final
         // value (kernel boundary), the clip fix-up of the NEXT launch reads the copy k_sac_reduce_apply keeps.  (A load -> add ->
         // store chain at the very top made block 0 wait a cold-miss latency before its first tile load.)
@@ -539,9 +521,11 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
   }
   };
   run_phases(log_alpha_top);
-  // s_gn was written during phase 0 and every phase ends in a barrier: valid here.  Common case: every group's norm is below
-  // max_norm and this launch is done.
-  if (!spec_pending) return;
+  if (!maybe_clip) return;        // the common case: this launch is done
+  // RARE from here on.  Canonical norms (fixed order), the exact decision, and if a group really clips: fix its step up from the undo
+  // log and run ALL phases again — what the first pass wrote (slabs, loss partials) is overwritten.
+  sac_group_norms(A.opt, s_gn, tid_);
+  __syncthreads();
   if (s_gn[0] < A.opt.max_norm && s_gn[1] < A.opt.max_norm && s_gn[2] < A.opt.max_norm) return;
   sac_clip_fixup(A.opt, s_gn, opaque(tid_), nthreads);
   __threadfence();
@@ -557,7 +541,7 @@ struct SacReduceArgs {
 };
 
 // sum-of-squares partials per workgroup and optimizer group (0 policy, 1 critics, 2 alpha), fixed order
-__device__ __forceinline__ void group_sumsq(float g, int i, int P, int Q2, int NP, float *ss_part) {
+__device__ __forceinline__ void group_sumsq(float g, int i, int P, int Q2, int NP, float *ss_part, float *quick = nullptr) {
   __shared__ float s_ss[3][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float gg = (i < NP) ? g * g : 0.f;
@@ -569,7 +553,11 @@ __device__ __forceinline__ void group_sumsq(float g, int i, int P, int Q2, int N
     s_ss[2][wave] = v2;
   }
   __syncthreads();
-  if (tid < 3) ss_part[blockIdx.x * 3 + tid] = s_ss[tid][0] + s_ss[tid][1] + s_ss[tid][2] + s_ss[tid][3];
+  if (tid < 3) {
+    const float part = s_ss[tid][0] + s_ss[tid][1] + s_ss[tid][2] + s_ss[tid][3];
+    ss_part[blockIdx.x * 3 + tid] = part;       // the canonical partials: summed in a FIXED order by whoever needs the norm
+    if (quick) atomicAdd(quick + tid, part);     // the quick sums: any order, for the conservative test only
+  }
 }
 
 __global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
@@ -788,7 +776,8 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacReduceArgs A, SacOp
     g = in ? (ok ? p2p_sum(X, epoch, i) : NAN) : 0.f;
   }
   if (in) A.grads[i] = g;
-  group_sumsq(g, i, A.P, A.Q2, NP, A.ss_part);   // ends in a __syncthreads: s_corr is visible below
+  // (slot_word was published by this step's fwd/bwd launch: stable during this launch)
+  group_sumsq(g, i, A.P, A.Q2, NP, A.ss_part, reinterpret_cast<float *>(O.seq) + 2 + 3 * (O.slot_word[0] & 1u));   // ends in a __syncthreads
   if (!in) return;
   const int grp = (i < A.P) ? 0 : (i < A.P + A.Q2 ? 1 : 2);
   float *u_p = O.undo, *u_m = O.undo + NP, *u_v = O.undo + 2 * NP, *u_tq = O.undo + 3 * NP;
@@ -903,8 +892,9 @@ static int sac_plan(const mbpo_sac_desc *d, SacPlan *pl, bool need_ptrs) {
   pl->off_slab_q = pl->off_slab_pi + (long long)pl->n_tiles * pl->P;
   pl->off_slab_ex = pl->off_slab_q + (long long)pl->n_tiles * 2 * pl->Q;
   pl->off_ss = pl->off_slab_ex + (long long)pl->n_tiles * 4;
-  pl->off_seq = (pl->off_ss + (long long)pl->n_red * 3 + 3) & ~3LL;   // 3 x uint32 sequence numbers + the undo count (zero at start)
-  pl->off_undo = pl->off_seq + 8;                                      // undo log of the speculative optimizer step
+  pl->off_seq = (pl->off_ss + (long long)pl->n_red * 3 + 3) & ~3LL;   // 8 words {seq issued, seq resolved, 2 x 3 quick sums} (16-byte aligned),
+                                                                       // then slot word + undo count, accum, 2 bias corrections (zero at start)
+  pl->off_undo = pl->off_seq + 16;                                     // undo log of the speculative optimizer step
   pl->total = pl->off_undo + 3LL * pl->NP + 2LL * pl->Q;
   if (need_ptrs) {
     MBPO_REQUIRE(d->params && d->target_q && d->adam_m && d->adam_v && d->step_count && d->grads && d->workspace && d->metrics,
@@ -987,7 +977,8 @@ static void sac_fill_opt(const mbpo_sac_desc *d, const SacPlan &pl, SacOptArgs *
   A->metrics = d->metrics; A->metrics_accum = d->metrics_accum; A->step_count = d->step_count; A->ss_part = d->workspace + pl.off_ss;
   A->undo = d->workspace + pl.off_undo;
   A->seq = reinterpret_cast<unsigned int *>(d->workspace + pl.off_seq);
-  A->undo_count = d->workspace + pl.off_seq + 2;
+  A->slot_word = reinterpret_cast<unsigned int *>(d->workspace + pl.off_seq + 8);
+  A->undo_count = d->workspace + pl.off_seq + 9;
   A->n_parts = pl.n_red; A->P = pl.P; A->Q2 = 2 * pl.Q;
   A->lr[0] = d->lr_policy; A->lr[1] = d->lr_q; A->lr[2] = d->lr_alpha;
   A->wd[0] = d->wd_policy; A->wd[1] = d->wd_q; A->wd[2] = d->wd_alpha;
