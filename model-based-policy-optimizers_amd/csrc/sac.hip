@@ -261,7 +261,6 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
   bool maybe_clip = false;
   // requested now, consumed after the first layer phase: the two scalar loads overlap the tile load instead of preceding it
   const float log_alpha_top = A.log_alpha[0];   // requested now, consumed after the first layer phase
-  const RngKey rk_ = rng_resolve(A.seed, A.offset, A.rng_dev);
   const float invB = 1.0f / (float)B;
   const float *pi_p = A.pi.params, *q1_p = A.q.params, *q2_p = A.q.params + A.q.net_stride;
   const float *t1_p = A.qt.params, *t2_p = A.qt.params + A.qt.net_stride;
@@ -361,9 +360,32 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
           s_qin[r * ld_xu + X + d] = (row0 + r < B) ? A.batch[(long long)(row0 + r) * D + X + d] : 0.f;  // transitions.action
         }
       }
+      // The noise of the sampling sections depends on (seed, offset, element) only: it is drawn HERE, by waves that have no tile
+      // element to load, while the tile is in flight — Philox + Box-Muller (logf, sqrtf, cosf: ~250 instructions) used to sit in
+      // the sampling sections, on the lone wave every other wave waits for.  critic role: next-action noise -> s_eps;
+      // actor role: actor-loss noise -> s_eps, alpha-loss noise -> s_lpa (replaced by the log-prob when it is used).
+      {
+        const int half = nthreads / 2;
+        const RngKey rkq = rng_resolve(A.seed, A.offset, A.rng_dev);
+        if (tid >= half) {
+          const bool second = tid >= half + half / 2;
+          if (!second || role == 1) {
+            for (int i2 = tid - half - (second ? half / 2 : 0); i2 < 16 * U; i2 += half / 2) {
+              const int r = i2 & 15, d = i2 >> 4, idx = r * U + d;
+              const long long nidx = (long long)(row0 + r) * U + d;
+              float e = 0.f;
+              if (row0 + r < B) {
+                const float *given = second ? A.noise_alpha : (role == 0 ? A.noise_critic : A.noise_actor);
+                const unsigned int stream = second ? MBPO_STREAM_SAC_ALPHA : (role == 0 ? MBPO_STREAM_SAC_CRITIC : MBPO_STREAM_SAC_ACTOR);
+                e = given ? given[nidx] : philox_normal(rkq.seed, rkq.offset, stream, (unsigned long long)nidx);
+              }
+              (second ? s_lpa : s_eps)[idx] = e;
+            }
+          }
+        }
+      }
     }
     const float alpha = expf(log_alpha_v);
-    const unsigned long long rng_off = rk_.offset, rng_seed = rk_.seed;
     if (ph == -1) {
     } else if (role == 0) {
       // ============================== CRITIC (sac/losses.py:74-110) ==============================
@@ -371,10 +393,7 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
         // next_action ~ policy(next_observation); next_log_prob (:80-87)
         for (int i2 = tid; i2 < 16 * U; i2 += nthreads) {
           const int r = i2 & 15, d = i2 >> 4, idx = r * U + d;
-          long long nidx = (long long)(row0 + r) * U + d;
-          float eps = 0.f;
-          if (row0 + r < B)
-            eps = A.noise_critic ? A.noise_critic[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_SAC_CRITIC, (unsigned long long)nidx);
+          const float eps = s_eps[idx];      // drawn in the tile section
           ActSample sm = normal_tanh_sample(y_pi[r * ld_y + d], y_pi[r * ld_y + U + d], eps);
           s_qin2[r * ld_xu + X + d] = sm.a;  // postprocess(next_action)
           s_lp[idx] = sm.lp;
@@ -422,17 +441,13 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
         const bool second = tid >= half;
         for (int i2 = second ? tid - half : tid; i2 < 16 * U; i2 += half) {
           const int r = i2 & 15, d = i2 >> 4, idx = r * U + d;
-          long long nidx = (long long)(row0 + r) * U + d;
-          const bool ok = row0 + r < B;
           const float loc = y_pi[r * ld_y + d], raw = y_pi[r * ld_y + U + d];
           if (second) {
-            float e_al = 0.f;
-            if (ok) e_al = A.noise_alpha ? A.noise_alpha[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_SAC_ALPHA, (unsigned long long)nidx);
+            const float e_al = s_lpa[idx];     // drawn in the tile section
             ActSample sal = normal_tanh_sample(loc, raw, e_al);   // alpha loss sample (:66-68)
             s_lpa[idx] = sal.lp;
           } else {
-            float e_ac = 0.f;
-            if (ok) e_ac = A.noise_actor ? A.noise_actor[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_SAC_ACTOR, (unsigned long long)nidx);
+            const float e_ac = s_eps[idx];     // drawn in the tile section
             ActSample sac = normal_tanh_sample(loc, raw, e_ac);   // actor loss sample (:117-119)
             s_lp[idx] = sac.lp;
             s_eps[idx] = e_ac;
