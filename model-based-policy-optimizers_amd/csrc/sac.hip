@@ -22,6 +22,7 @@
 #include "chain_run.hpp"
 #include "p2p.hpp"
 #include <string.h>
+#include <stdlib.h>
 int mbpo_p2p_make_dev(const mbpo_p2p_desc *d, P2pDev *P);
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
@@ -126,7 +127,7 @@ __device__ __forceinline__ void sac_clip_fixup(const SacOptArgs &O, const float 
 struct SacArgs {
   MlpDev pi, q, qt;
   NetShape sh_pi, sh_q;
-  SacChainDesc tab[2][5][4];   // [role][phase (index nph = idle)][chain]
+  SacChainDesc tab[3][5][4];   // [table role][phase (index nph = idle)][chain]; table role 2 exists only with `split`
   int X, U, B, D;
   const float *batch, *norm_mean, *norm_std, *log_alpha;
   const float *noise_alpha, *noise_critic, *noise_actor;
@@ -142,6 +143,7 @@ struct SacArgs {
   unsigned long long *stamps;   // measurement hook (mbpo_debug_set_stamps): [2 roles][16] s_memtime values of tile 0, or NULL
   SacOptArgs opt;               // clip check of the previous speculative step
   float *step_count_rw;         // optimizer count: bumped by block 0 of every fwd/bwd launch
+  int split;                    // 1: THREE workgroups per tile — critic 0, actor(+alpha), critic 1 (see k_sac_fwd_bwd)
 };
 
 // Timeline stamps for DESIGN.md's phase breakdown: one s_memtime per phase boundary, written by thread 0 of tile 0.
@@ -206,15 +208,32 @@ __device__ __forceinline__ ActSample normal_tanh_sample(float loc, float raw, fl
 //   P3  per layer: c0/c1: Q1/Q2 dgrad               P3  per layer: c0/c1: Q1/Q2 input-gradient
 //                  c2/c3: Q1/Q2 wgrad               -- dL/dlogits
 //                                                   P4  per layer: c0: pi dgrad   c1: pi wgrad
-template <int H, int SP, bool WIDE>   // SP = waves per chain: 4 chains x SP waves; WIDE: chain_run.hpp fast_shape
-__global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
+// SP = waves per chain, NCH = chain slots: NCH x SP waves; WIDE: chain_run.hpp fast_shape.  NCH = 2 is for the `split` launch, where
+// no role carries more than two chains at a time: at hidden width 128 that makes room for 4 waves per chain (8 waves, 2 per SIMD,
+// 256 VGPRs each) and with them for the register-image weight prefetch (a lane's share of a 128-wide layer is 64 weights + 2
+// biases per image, two images) that 16 waves x 128 VGPRs cannot hold.
+template <int H, int SP, bool WIDE, int NCH = 4>
+__global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
-  const int tid_ = threadIdx.x, nthreads = 256 * SP;
+  const int tid_ = threadIdx.x, nthreads = 64 * SP * NCH;
   const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   const int chain = wave / SP, sub = wave % SP;
-  const int role = blockIdx.x & 1;  // 0 = critic, 1 = actor(+alpha)
-  const int tile = blockIdx.x >> 1;
+  // Two workgroups per tile (critic role, actor role), or — `split`, used at hidden width 128 where a phase is bound by the
+  // fp32-MFMA rate of its CU — three: the critic role once per critic.  Each critic workgroup runs pi(s') and BOTH target critics
+  // (the target needs their minimum) but the forward, dgrad and wgrad of ITS critic only: no phase carries more than two chains, the
+  // critic backward 2 x 256 MFMAs per layer on a CU instead of 4 x 256.  kq = the critic this workgroup owns (-1: both).
+  int role, tile, trole, kq = -1;
+  if (A.split) {
+    trole = blockIdx.x % 3;
+    tile = blockIdx.x / 3;
+    role = trole == 1 ? 1 : 0;
+    kq = trole == 1 ? -1 : (trole >> 1);
+  } else {
+    role = blockIdx.x & 1;   // 0 = critic, 1 = actor(+alpha)
+    tile = blockIdx.x >> 1;
+    trole = role;
+  }
   const int X = A.X, U = A.U, D = A.D, B = A.B;
   const int row0 = tile * 16;
   const int ld_x = A.ld_x, ld_xu = A.ld_xu, ld_h = A.ld_h, ld_y = A.ld_y, LH = A.LH;
@@ -315,7 +334,7 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
     // ---- the chain this wave walks in the NEXT phase; its first layer's weights are requested now ----
     {
       const int nx = ph + 1;
-      const SacChainDesc &cd = A.tab[role][nx][chain];
+      const SacChainDesc &cd = A.tab[trole][nx][chain];
       mode = cd.mode;
       netid = cd.netid;
       cparams = (cd.base_sel ? A.qt.params : A.pi.params) + cd.param_off;
@@ -400,7 +419,7 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
         }
         if (tid < 32) {  // keep q_old_action (:78-79) out of the way of the target critics' outputs
           const int k = tid >> 4, r = tid & 15;
-          s_scal[32 + tid] = (k == 0 ? y_q1 : y_q2)[r * ld_y];
+          if (kq < 0 || k == kq) s_scal[32 + tid] = (k == 0 ? y_q1 : y_q2)[r * ld_y];
         }
       } else if (ph == 1) {
         if (tid < 32) {
@@ -420,7 +439,7 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
           }
           const float target = rew * A.reward_scaling + disc * gamma * next_v;                     // :101-103
           const float trunc = s_row[r * D4 + D - 1];
-          const float err = ok ? (s_scal[32 + tid] - target) * (1.f - trunc) : 0.f;               // q_error :104-108
+          const float err = (ok && (kq < 0 || k == kq)) ? (s_scal[32 + tid] - target) * (1.f - trunc) : 0.f;   // q_error :104-108 (own critic)
           s_scal[tid] = err * err;
           // loss = 0.5*mean(err^2) over [B,2]  ->  dL/dq = err*(1-trunc)/(2B)
           s_dy[(k * 16 + r) * ld_y] = err * (1.f - trunc) * (0.5f * invB);
@@ -429,7 +448,7 @@ __global__ void __launch_bounds__(256 * SP) k_sac_fwd_bwd(SacArgs A) {
         if (tid == 0) {
           float acc = 0.f;
           for (int i = 0; i < 32; ++i) acc += s_scal[i];
-          A.slab_ex[tile * 4 + 0] = acc;
+          A.slab_ex[tile * 4 + (kq == 1 ? 3 : 0)] = acc;     // (split: the two critics' partials in slots 0 and 3, added by the reduce)
         }
       }
     } else {
@@ -586,7 +605,7 @@ __global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
     g = slab_sum<16>(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
     // (all loads of the three sums in flight together: this one thread is the kernel's critical path)
-    const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
+    const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0) + slab_sum<16>(A.slab_ex, 4, A.n_tiles, 3), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
                 al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
     const float invB = 1.0f / (float)A.B;
     g = al * invB;                          // d alpha_loss / d log_alpha
@@ -617,7 +636,7 @@ __global__ void __launch_bounds__(256) k_sac_reduce_push(SacReduceArgs A, P2pDev
     g = slab_sum<16>(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
     // (all loads of the three sums in flight together: this one thread is the kernel's critical path)
-    const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
+    const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0) + slab_sum<16>(A.slab_ex, 4, A.n_tiles, 3), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
                 al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
     const float invB = 1.0f / (float)A.B;
     g = al * invB;
@@ -663,7 +682,7 @@ __global__ void __launch_bounds__(256) k_sac_reduce_exchange(SacReduceArgs A, P2
     const int j = i - A.P;
     g = slab_sum<16>(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
-    const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
+    const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0) + slab_sum<16>(A.slab_ex, 4, A.n_tiles, 3), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
                 al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
     const float invB = 1.0f / (float)A.B;
     g = al * invB;
@@ -768,7 +787,7 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacReduceArgs A, SacOp
     const int j = i - A.P;
     g = slab_sum<16>(A.slab_q, A.Q2, A.n_tiles, j);
   } else if (i == NP - 1) {
-    const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
+    const float ce = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 0) + slab_sum<16>(A.slab_ex, 4, A.n_tiles, 3), ac = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 1),
                 al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
     const float invB = 1.0f / (float)A.B;
     g = al * invB;
@@ -928,7 +947,7 @@ extern "C" int64_t mbpo_sac_workspace_floats(const mbpo_sac_desc *d) {
 constexpr int SP64 = 4;   // waves per chain at hidden width 64
 
 // LDS offsets (floats) of the tiles the chains use; must mirror the carve at the top of k_sac_fwd_bwd
-static void sac_chain_table(const SacPlan &pl, int D, SacArgs *A) {
+static void sac_chain_table(const SacPlan &pl, int D, SacArgs *A, bool split) {
   const int ld_x = pl.ld_x, ld_xu = pl.ld_xu, ld_h = pl.ld_h, ld_y = pl.ld_y, LH = pl.LH;
   const int T = 16 * ld_h;
   const int o_row = 0;
@@ -936,7 +955,7 @@ static void sac_chain_table(const SacPlan &pl, int D, SacArgs *A) {
   const int o_pp = o_qin2 + 16 * ld_xu, o_st0 = o_pp + 4 * T, o_y = o_st0 + 4 * LH * T, o_dy = o_y + 3 * 16 * ld_y, o_dx = o_dy + 2 * 16 * ld_y;
   const int o_st1 = o_st0 + LH * T, o_st2 = o_st0 + 2 * LH * T, o_st3 = o_st0 + 3 * LH * T;
   const int P = pl.P, Q = pl.Q;   // params = [policy | critic0 | critic1 | log_alpha]; target_q = [critic0 | critic1]
-  for (int role = 0; role < 2; ++role)
+  for (int role = 0; role < 3; ++role)
     for (int ph = 0; ph < 5; ++ph)
       for (int c = 0; c < 4; ++c) {
         SacChainDesc d;
@@ -945,7 +964,30 @@ static void sac_chain_table(const SacPlan &pl, int D, SacArgs *A) {
         d.x = d.pp0 = d.pp1 = d.zb = d.hb = d.y = d.dx = -1;
         d.ldx = ld_x;
         const int net = c & 1;
-        if (role == 0) {                       // critic role
+        if (split && role != 1) {              // critic role of ONE critic kq: never more than two chains
+          const int kq = role >> 1;
+          if (ph == 0 && c < 2) {              // pi(s') || Qk(s,a)
+            d.mode = CH_FWD;
+            if (c == 0) {
+              d.netid = 0; d.param_off = 0; d.x = o_sn2; d.ldx = ld_x; d.pp0 = o_pp; d.pp1 = o_pp + T; d.y = o_y;
+            } else {
+              d.netid = 1; d.param_off = P + kq * Q; d.x = o_qin; d.ldx = ld_xu;
+              d.zb = kq == 0 ? o_st0 : o_st2; d.hb = kq == 0 ? o_st1 : o_st3; d.y = o_y + (kq + 1) * 16 * ld_y;
+            }
+          } else if (ph == 1 && c < 2) {       // BOTH target critics on (s', a')
+            d.mode = CH_FWD;
+            d.netid = 1; d.base_sel = 1; d.param_off = c * Q; d.x = o_qin2; d.ldx = ld_xu;
+            d.pp0 = o_pp + 2 * c * T; d.pp1 = d.pp0 + T; d.y = o_y + (c + 1) * 16 * ld_y;
+          } else if (ph == 2 && c < 2) {       // critic kq backward: dgrad beside wgrad
+            d.mode = c == 0 ? CH_DGRAD : CH_WGRAD;
+            d.netid = 1; d.param_off = P + kq * Q; d.x = o_qin; d.ldx = ld_xu;
+            d.pp0 = o_pp + 2 * kq * T; d.pp1 = d.pp0 + T; d.zb = kq ? o_st2 : o_st0; d.hb = kq ? o_st3 : o_st1;
+            d.y = o_dy + kq * 16 * ld_y;
+            d.slab_sel = 2; d.slab_off = kq * Q;
+          }
+        } else if (role == 2) {
+          // (table role 2 is not used without `split`)
+        } else if (role == 0) {                // critic role
           if (ph == 0 && c < 3) {              // pi(s') || Q1(s,a) || Q2(s,a)
             d.mode = CH_FWD;
             if (c == 0) {
@@ -1012,7 +1054,12 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
   A.pi = pl.pi; A.q = pl.q; A.qt = pl.qt;
   A.sh_pi = NetShape{pl.pi.dims[0], pl.pi.n_layers, pl.pi.dims[pl.pi.n_layers], pl.pi.act};
   A.sh_q = NetShape{pl.q.dims[0], pl.q.n_layers, pl.q.dims[pl.q.n_layers], pl.q.act};
-  sac_chain_table(pl, d->row_len, &A);
+  // three workgroups per tile where a phase is MFMA-bound on its CU (hidden width 128); MBPO_SAC_SPLIT=0/1 overrides (measurement)
+  static const int split_env = getenv("MBPO_SAC_SPLIT") ? atoi(getenv("MBPO_SAC_SPLIT")) : -1;
+  const bool split = split_env >= 0 ? split_env != 0 : pl.H >= 128;
+  A.split = split ? 1 : 0;
+  const int wg_per_tile = split ? 3 : 2;
+  sac_chain_table(pl, d->row_len, &A, split);
   A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.D = d->row_len;
   A.batch = d->batch; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std;
   A.log_alpha = d->params + pl.NP - 1;
@@ -1044,16 +1091,20 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
       if (net_is_wide(A.sh_pi) || net_is_wide(A.sh_q)) {
         rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64, true>>(pl.lds, "sac_grads");
         if (rc != MBPO_OK) return rc;
-        hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64, true>), dim3(2 * pl.n_tiles), dim3(256 * SP64), pl.lds, st, A);
+        hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64, true>), dim3(wg_per_tile * pl.n_tiles), dim3(256 * SP64), pl.lds, st, A);
       } else {
         rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64, false>>(pl.lds, "sac_grads");
         if (rc != MBPO_OK) return rc;
-        hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64, false>), dim3(2 * pl.n_tiles), dim3(256 * SP64), pl.lds, st, A);
+        hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64, false>), dim3(wg_per_tile * pl.n_tiles), dim3(256 * SP64), pl.lds, st, A);
       }
+    } else if (split && !(net_is_wide(A.sh_pi) || net_is_wide(A.sh_q))) {
+      rc = mbpo_ensure_lds<k_sac_fwd_bwd<128, 4, false, 2>>(pl.lds, "sac_grads");
+      if (rc != MBPO_OK) return rc;
+      hipLaunchKernelGGL((k_sac_fwd_bwd<128, 4, false, 2>), dim3(wg_per_tile * pl.n_tiles), dim3(512), pl.lds, st, A);
     } else {
       rc = mbpo_ensure_lds<k_sac_fwd_bwd<128, 2, false>>(pl.lds, "sac_grads");
       if (rc != MBPO_OK) return rc;
-      hipLaunchKernelGGL((k_sac_fwd_bwd<128, 2, false>), dim3(2 * pl.n_tiles), dim3(512), pl.lds, st, A);
+      hipLaunchKernelGGL((k_sac_fwd_bwd<128, 2, false>), dim3(wg_per_tile * pl.n_tiles), dim3(512), pl.lds, st, A);
     }
   }
   if (!(phase_mask & 2)) {
