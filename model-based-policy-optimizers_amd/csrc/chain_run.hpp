@@ -177,14 +177,25 @@ __device__ __forceinline__ void wset_load_dg_in(WSet<HT, SP> &S, const float *W,
 
 // ---- computes on a register image ----------------------------------------------------------------------------
 // hidden slice from a full (K == H) or input (K <= 32) image
-template <int HT, int SP, bool IN>
+// JVP (forward-mode tangent riding along, SAC actor loss): a SECOND 16-row tile goes through the same weights in the same wave —
+// the tangent d(.)/d(input k_tan) of every row.  th_in/th_out: tangent of the previous / this layer's activations (same tile
+// layout); the lane that holds z[row][col] also holds the tangent pre-activation of that (row, col), so
+// h' = act'(z) * z' is formed in registers, with no exchange between waves.  Layer 0 (IN): the tangent input is the one-hot e_{k_tan}
+// for every row.  th_out == nullptr: no tangent (the only form the other kernels instantiate).
+template <int HT, int SP, bool IN, bool JVP = false>
 __device__ __forceinline__ void wset_fwd_hidden(const WSet<HT, SP> &S, const float *x, int ldx, int K, float *h_out, float *z_out,
-                                                int ldo, int act, int lane) {
+                                                int ldo, int act, int lane, const float *th_in = nullptr, float *th_out = nullptr,
+                                                int k_tan = 0) {
   constexpr int KS = 4 * HT, CT = HT / SP;
   const int r = lane & 15, g = lane >> 4;
   f32x4 acc[CT];
+  f32x4 tacc[JVP ? CT : 1];
 #pragma unroll
   for (int t = 0; t < CT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (JVP) {
+#pragma unroll
+    for (int t = 0; t < CT; ++t) tacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   if constexpr (!IN) {
     const float *xr = x + r * ldx + g * KS;
 #pragma unroll
@@ -195,6 +206,20 @@ __device__ __forceinline__ void wset_fwd_hidden(const WSet<HT, SP> &S, const flo
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], S.w[(4 * q + u) * CT + t], acc[t], 0, 0, 0);
+    }
+    if constexpr (JVP) {
+      if (th_out) {
+        const float *tr = th_in + r * ldx + g * KS;
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+          float av[4];
+          load_vec_lds<4>(tr + 4 * q, av);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < CT; ++t) tacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], S.w[(4 * q + u) * CT + t], tacc[t], 0, 0, 0);
+        }
+      }
     }
   } else {
     const int kc = (K + 3) >> 2;
@@ -210,6 +235,17 @@ __device__ __forceinline__ void wset_fwd_hidden(const WSet<HT, SP> &S, const flo
     for (int s = 0; s < 8; ++s)
 #pragma unroll
       for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], S.w[s * CT + t], acc[t], 0, 0, 0);
+    if constexpr (JVP) {
+      if (th_out) {
+        // tangent input e_{k_tan} in every row: z'_0[row][n] = W0[k_tan][n]
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const float one = ((s < kc) && (g * kc + s == k_tan)) ? 1.f : 0.f;
+#pragma unroll
+          for (int t = 0; t < CT; ++t) tacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(one, S.w[s * CT + t], tacc[t], 0, 0, 0);
+        }
+      }
+    }
   }
   // epilogue: the (uniform) activation / z-store decisions are taken once, not per row, and the 4*CT values of a lane go
   // through the activation together (independent transcendental ops pipeline instead of serialising per row)
@@ -223,13 +259,26 @@ __device__ __forceinline__ void wset_fwd_hidden(const WSet<HT, SP> &S, const flo
 #pragma unroll
     for (int i = 0; i < 4; ++i) store_vec_lds<CT>(z_out + o0 + i * ldo, *reinterpret_cast<float(*)[CT]>(&zv[i * CT]));
   }
+  if constexpr (JVP) {
+    if (th_out) {
+      float tv[4 * CT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) tv[i * CT + t] = tacc[t][i];
+      act_grad_mul_vec<4 * CT>(tv, zv, act);      // h' = act'(z) * z'
+#pragma unroll
+      for (int i = 0; i < 4; ++i) store_vec_lds<CT>(th_out + o0 + i * ldo, *reinterpret_cast<float(*)[CT]>(&tv[i * CT]));
+    }
+  }
   act_apply_vec<4 * CT>(zv, act);
 #pragma unroll
   for (int i = 0; i < 4; ++i) store_vec_lds<CT>(h_out + o0 + i * ldo, *reinterpret_cast<float(*)[CT]>(&zv[i * CT]));
 }
 
-template <int HT, int SP, int NTL>
-__device__ __forceinline__ void wset_fwd_out(const WSet<HT, SP> &S, const float *x, int ldx, int N, float *y, int ldy, int lane) {
+template <int HT, int SP, int NTL, bool JVP = false>
+__device__ __forceinline__ void wset_fwd_out(const WSet<HT, SP> &S, const float *x, int ldx, int N, float *y, int ldy, int lane,
+                                             const float *th_in = nullptr, float *ty = nullptr, int ldty = 0) {
   constexpr int KS = 4 * HT;
   const int r = lane & 15, g = lane >> 4;
   f32x4 acc[NTL];
@@ -251,6 +300,31 @@ __device__ __forceinline__ void wset_fwd_out(const WSet<HT, SP> &S, const float 
     if (n < N) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[(4 * g + i) * ldy + n] = acc[t][i] + S.b[t];
+    }
+  }
+  if constexpr (JVP) {
+    if (ty) {      // tangent of the output: y' = h' W (no bias)
+      f32x4 tacc[NTL];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) tacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float *tr = th_in + r * ldx + g * KS;
+#pragma unroll
+      for (int q = 0; q < KS / 4; ++q) {
+        float av[4];
+        load_vec_lds<4>(tr + 4 * q, av);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < NTL; ++t) tacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], S.w[(4 * q + u) * NTL + t], tacc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        const int n = NTL * r + t;
+        if (n < N) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ty[(4 * g + i) * ldty + n] = tacc[t][i];
+        }
+      }
     }
   }
 }
@@ -410,10 +484,13 @@ __device__ __forceinline__ void dgrad_request(WSet<HT, SP> &S, const float *para
 // x: network input tile [16][ldx].  Hidden outputs go to hbuf + l*T (when hbuf) or ping-pong pp0/pp1; pre-activations to
 // zbuf + l*T (when zbuf); the output layer to y [16][ldy].  A must hold layer 0's request (chain_fwd_prefetch).
 // Executes exactly n_steps workgroup barriers.
-template <int HT, int SP, bool WIDE = false>
+// JVP: tp0 / tp1 (ping-pong hidden tiles for the tangent), ty [16][ldty] (tangent of the output) and k_tan (the input the tangent is
+// taken with respect to); tp0 == nullptr: no tangent.  Register-image path with a one-tile output only.
+template <int HT, int SP, bool WIDE = false, bool JVP = false>
 __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__restrict__ params, const float *x, int ldx, float *pp0,
                                               float *pp1, float *zbuf, float *hbuf, float *y, int ldy, int ldh, int n_steps, int sub,
-                                              int lane_, WSet<HT, SP> &A, unsigned long long *dbg = nullptr) {
+                                              int lane_, WSet<HT, SP> &A, unsigned long long *dbg = nullptr, float *tp0 = nullptr,
+                                              float *tp1 = nullptr, float *ty = nullptr, int ldty = 0, int k_tan = 0) {
   constexpr int H = 16 * HT, CT = HT / SP;
   const int T = 16 * ldh, c0 = sub * 16 * CT;
   const int L = sh.L;
@@ -428,6 +505,8 @@ __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__
 #define hout(l) ((hbuf ? hbuf + (l) * T : (((l) & 1) ? pp1 : pp0)) + c0)
 #define zout(l) (zbuf ? zbuf + (l) * T + c0 : nullptr)
 #define hin(l) ((const float *)(hbuf ? hbuf + ((l) - 1) * T : ((((l) - 1) & 1) ? pp1 : pp0)))   /* l >= 1 */
+#define tout(l) (tp0 ? (((l) & 1) ? tp1 : tp0) + c0 : nullptr)
+#define tin(l) ((const float *)((((l) - 1) & 1) ? tp1 : tp0))                                     /* l >= 1 */
   if (fast_shape<HT, SP, WIDE>(sh)) {
     if constexpr (4 * HT * (HT / SP) <= 64) {
       WSet<HT, SP> B;
@@ -438,7 +517,7 @@ __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__
         const int lane = opaque(lane_);
         wset_wait(A);
         request(B, 1, lane);
-        wset_fwd_hidden<HT, SP, true>(A, x, ldx, sh.K_in, hout(0), zout(0), ldh, sh.act, lane);
+        wset_fwd_hidden<HT, SP, true, JVP>(A, x, ldx, sh.K_in, hout(0), zout(0), ldh, sh.act, lane, nullptr, tout(0), k_tan);
         __syncthreads();
       }
       // ---- hidden layers 1 .. L-2, two per trip: B then A ----
@@ -450,14 +529,14 @@ __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__
         wset_wait(B);
         request(A, l + 1, lane);
         DBG_STAMP(1);
-        wset_fwd_hidden<HT, SP, false>(B, hin(l), ldh, H, hout(l), zout(l), ldh, sh.act, lane);
+        wset_fwd_hidden<HT, SP, false, JVP>(B, hin(l), ldh, H, hout(l), zout(l), ldh, sh.act, lane, tin(l), tout(l));
         DBG_STAMP(2);
         __syncthreads();
         DBG_STAMP(3);
         wset_wait(A);
         request(B, l + 2, lane);
         DBG_STAMP(4);
-        wset_fwd_hidden<HT, SP, false>(A, hin(l + 1), ldh, H, hout(l + 1), zout(l + 1), ldh, sh.act, lane);
+        wset_fwd_hidden<HT, SP, false, JVP>(A, hin(l + 1), ldh, H, hout(l + 1), zout(l + 1), ldh, sh.act, lane, tin(l + 1), tout(l + 1));
         DBG_STAMP(5);
         __syncthreads();
         DBG_STAMP(6);
@@ -467,7 +546,7 @@ __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__
         const int lane = opaque(lane_);
         wset_wait(B);
         request(A, l + 1, lane);
-        wset_fwd_hidden<HT, SP, false>(B, hin(l), ldh, H, hout(l), zout(l), ldh, sh.act, lane);
+        wset_fwd_hidden<HT, SP, false, JVP>(B, hin(l), ldh, H, hout(l), zout(l), ldh, sh.act, lane, tin(l), tout(l));
         __syncthreads();
         ++l;
         in_a = true;
@@ -477,8 +556,8 @@ __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__
         if (sub == 0) {
           const int lane = opaque(lane_);
           if (sh.N_out <= 16) {
-            if (in_a) wset_fwd_out<HT, SP, 1>(A, hin(L - 1), ldh, sh.N_out, y, ldy, lane);
-            else wset_fwd_out<HT, SP, 1>(B, hin(L - 1), ldh, sh.N_out, y, ldy, lane);
+            if (in_a) wset_fwd_out<HT, SP, 1, JVP>(A, hin(L - 1), ldh, sh.N_out, y, ldy, lane, tp0 ? tin(L - 1) : nullptr, ty, ldty);
+            else wset_fwd_out<HT, SP, 1, JVP>(B, hin(L - 1), ldh, sh.N_out, y, ldy, lane, tp0 ? tin(L - 1) : nullptr, ty, ldty);
           } else {
             if constexpr (!WIDE && CT >= 2) gen_dense_fwd(hin(L - 1), ldh, H, W1 + (L - 2) * (H * H + H), sh.N_out,
                                                           W1 + (L - 2) * (H * H + H) + H * sh.N_out, 0, sh.N_out, y, nullptr, ldy, -1, lane);
@@ -524,6 +603,8 @@ __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__
 #undef hout
 #undef zout
 #undef hin
+#undef tout
+#undef tin
 #undef request
 #undef DBG_STAMP
 }

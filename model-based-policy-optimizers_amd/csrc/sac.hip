@@ -39,7 +39,7 @@ struct SacChainDesc {
   int pp0, pp1, zb, hb, y, dx;
   int slab_sel;    // 0 none, 1 = policy slab, 2 = critic slab
   int slab_off;    // floats inside the tile's slab
-  int pad0, pad1;
+  int tp0, tp1;    // CH_FWD with a tangent (jvp): the tangent's ping-pong hidden tiles (its output goes to `dx`), -1 = none
 };
 
 // Flat optimizer state + what the clip check needs (shared by k_sac_apply, k_sac_reduce_apply, the fix-up and k_sac_finalize).
@@ -144,6 +144,9 @@ struct SacArgs {
   SacOptArgs opt;               // clip check of the previous speculative step
   float *step_count_rw;         // optimizer count: bumped by block 0 of every fwd/bwd launch
   int split;                    // 1: THREE workgroups per tile — critic 0, actor(+alpha), critic 1 (see k_sac_fwd_bwd)
+  int jvp;                      // 1 (u_dim == 1): the actor role gets dQ/da in FORWARD mode — the tangent rides along the critics' forward
+                                // pass (chain_run.hpp JVP) and the critics' input-gradient phase does not exist: 12 dependent layer
+                                // steps instead of 16 on the role that bounds the kernel
 };
 
 // Timeline stamps for DESIGN.md's phase breakdown: one s_memtime per phase boundary, written by thread 0 of tile 0.
@@ -301,9 +304,9 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
   int mode = CH_IDLE, netid = 0;
   const float *cparams = pi_p;
   float *cslab = nullptr;
-  int cx = -1, cldx = ld_x, cpp0 = -1, cpp1 = -1, czb = -1, chb = -1, cy = -1, cdx = -1;
+  int cx = -1, cldx = ld_x, cpp0 = -1, cpp1 = -1, czb = -1, chb = -1, cy = -1, cdx = -1, ctp0 = -1, ctp1 = -1;
 #define P(off) ((off) < 0 ? (float *)nullptr : smem + (off))
-  const int nph = role == 0 ? 3 : 4;
+  const int nph = (role == 0 || A.jvp) ? 3 : 4;
   // At most two passes over the phases: the second one only after a clip fix-up of the previous optimizer step (rare), whose code
   // sits behind the phase loop so that it costs the loop neither registers nor instruction-cache lines.
   // The clip decision must not touch the phase loop's control flow: a `break` on it, or a loop bound that depends on it, made hipcc
@@ -317,11 +320,12 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
   for (int ph = -1; ph < nph; ++ph) {
     const int tid = opaque(tid_), lane = tid & 63;   // keeps per-lane addresses of all phases from being hoisted and spilled
     if (ph >= 0) {
-      const int len = (role == 0) ? (ph == 0 ? Lmax : QL) : ((ph == 0 || ph == 3) ? PL : QL);
+      const int len = (role == 0) ? (ph == 0 ? Lmax : QL) : ((ph == 0 || ph == nph - 1) ? PL : QL);
       const NetShape sh = netid == 0 ? A.sh_pi : A.sh_q;
       if (mode == CH_FWD)
-        chain_fwd_run<HT, SP, WIDE>(sh, cparams, P(cx), cldx, P(cpp0), P(cpp1), P(czb), P(chb), P(cy), ld_y, ld_h, len, sub, lane, R,
-                              (A.stamps && tile == 0 && role == 1 && ph == 0 && wave == 0) ? A.stamps + 40 : nullptr);
+        chain_fwd_run<HT, SP, WIDE, !WIDE>(sh, cparams, P(cx), cldx, P(cpp0), P(cpp1), P(czb), P(chb), P(cy), ld_y, ld_h, len, sub, lane, R,
+                                           (A.stamps && tile == 0 && role == 1 && ph == 0 && wave == 0) ? A.stamps + 40 : nullptr,
+                                           P(ctp0), P(ctp1), ctp0 >= 0 ? P(cdx) : nullptr, ld_xu, X);
       else if (mode == CH_DGRAD)
         chain_dgrad_run<HT, SP, WIDE>(sh, cparams, P(cy), ld_y, P(czb), P(cpp0), P(cpp1), P(cdx), ld_xu, ld_h, len, sub, lane, R);
       else if (mode == CH_WGRAD)
@@ -339,6 +343,7 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
       netid = cd.netid;
       cparams = (cd.base_sel ? A.qt.params : A.pi.params) + cd.param_off;
       cx = cd.x; cldx = cd.ldx; cpp0 = cd.pp0; cpp1 = cd.pp1; czb = cd.zb; chb = cd.hb; cy = cd.y; cdx = cd.dx;
+      ctp0 = cd.tp0; ctp1 = cd.tp1;
       cslab = cd.slab_sel == 1 ? A.slab_pi + (long long)tile * A.pi.n_params + cd.slab_off
                                : (cd.slab_sel == 2 ? A.slab_q + (long long)tile * (2 * A.q.n_params) + cd.slab_off : nullptr);
       const NetShape shn = netid == 0 ? A.sh_pi : A.sh_q;
@@ -497,10 +502,21 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
             else if (q1 < q0) g1 = -invB;
             else g0 = g1 = -0.5f * invB;
           }
-          s_dy[r * ld_y] = g0;
-          s_dy[(16 + r) * ld_y] = g1;
+          if (A.jvp) {
+            // forward mode (u_dim == 1): the critics' forward pass carried d q_k / d a along (s_dx[k][r][0]); the actor loss's
+            // gradient with respect to the action and, from it, the logits' gradients follow here — no critic backward phase
+            const float dLda = g0 * s_dx[r * ld_xu] + g1 * s_dx[(16 + r) * ld_xu];
+            const float a = s_a[r], sg = s_sig[r], eps = s_eps[r], raw = s_raw[r];
+            const float gz = dLda * (1.f - a * a) + alpha * invB * 2.f * a;
+            const float gsig = gz * eps - alpha * invB / sg;
+            s_dy[r * ld_y] = ok ? gz : 0.f;                              // d/dloc
+            s_dy[r * ld_y + 1] = ok ? gsig * fast_sigmoid(raw) : 0.f;    // d/draw = d/dsigma * softplus'(raw)
+          } else {
+            s_dy[r * ld_y] = g0;
+            s_dy[(16 + r) * ld_y] = g1;
+          }
         }
-      } else if (ph == 2) {
+      } else if (ph == 2 && !A.jvp) {
         for (int i2 = tid; i2 < 16 * U; i2 += nthreads) {
           const int r = i2 & 15, d = i2 >> 4, idx = r * U + d;
           const bool ok = row0 + r < B;
@@ -947,7 +963,7 @@ extern "C" int64_t mbpo_sac_workspace_floats(const mbpo_sac_desc *d) {
 constexpr int SP64 = 4;   // waves per chain at hidden width 64
 
 // LDS offsets (floats) of the tiles the chains use; must mirror the carve at the top of k_sac_fwd_bwd
-static void sac_chain_table(const SacPlan &pl, int D, SacArgs *A, bool split) {
+static void sac_chain_table(const SacPlan &pl, int D, SacArgs *A, bool split, bool jvp) {
   const int ld_x = pl.ld_x, ld_xu = pl.ld_xu, ld_h = pl.ld_h, ld_y = pl.ld_y, LH = pl.LH;
   const int T = 16 * ld_h;
   const int o_row = 0;
@@ -961,7 +977,7 @@ static void sac_chain_table(const SacPlan &pl, int D, SacArgs *A, bool split) {
         SacChainDesc d;
         memset(&d, 0, sizeof(d));
         d.mode = CH_IDLE;
-        d.x = d.pp0 = d.pp1 = d.zb = d.hb = d.y = d.dx = -1;
+        d.x = d.pp0 = d.pp1 = d.zb = d.hb = d.y = d.dx = d.tp0 = d.tp1 = -1;
         d.ldx = ld_x;
         const int net = c & 1;
         if (split && role != 1) {              // critic role of ONE critic kq: never more than two chains
@@ -1015,6 +1031,16 @@ static void sac_chain_table(const SacPlan &pl, int D, SacArgs *A, bool split) {
             d.mode = CH_FWD;
             d.netid = 1; d.param_off = P + c * Q; d.x = o_qin; d.ldx = ld_xu;
             d.pp0 = o_pp + 2 * c * T; d.pp1 = d.pp0 + T; d.zb = c == 0 ? o_st2 : o_st3; d.y = o_y + (c + 1) * 16 * ld_y;
+            if (jvp) {     // no z store (no backward through the critics): its tiles carry the tangent, whose output goes to s_dx[c]
+              d.zb = -1;
+              d.tp0 = c == 0 ? o_st2 : o_st3; d.tp1 = d.tp0 + T; d.dx = o_dx + c * 16 * ld_xu;
+            }
+          } else if (jvp && ph == 2 && c < 2) {      // the policy's backward pass follows at once
+            d.mode = c == 0 ? CH_DGRAD : CH_WGRAD;
+            d.netid = 0; d.param_off = 0; d.x = o_sn; d.ldx = ld_x; d.pp0 = o_pp; d.pp1 = o_pp + T; d.zb = o_st0; d.hb = o_st1;
+            d.y = o_dy; d.slab_sel = 1; d.slab_off = 0;
+          } else if (jvp) {
+            // (idle)
           } else if (ph == 2 && c < 2) {
             d.mode = CH_DGRAD;
             d.netid = 1; d.param_off = P + net * Q; d.pp0 = o_pp + 2 * net * T; d.pp1 = d.pp0 + T; d.zb = net ? o_st3 : o_st2;
@@ -1054,12 +1080,20 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
   A.pi = pl.pi; A.q = pl.q; A.qt = pl.qt;
   A.sh_pi = NetShape{pl.pi.dims[0], pl.pi.n_layers, pl.pi.dims[pl.pi.n_layers], pl.pi.act};
   A.sh_q = NetShape{pl.q.dims[0], pl.q.n_layers, pl.q.dims[pl.q.n_layers], pl.q.act};
-  // three workgroups per tile where a phase is MFMA-bound on its CU (hidden width 128); MBPO_SAC_SPLIT=0/1 overrides (measurement)
+  // three workgroups per tile (one critic each): at hidden width 128 a phase is MFMA-bound on its CU, at 64 the two critic
+  // workgroups finish before the actor role does and 8-wave workgroups have cheaper barriers (26.9 -> 24.0 us with the forward-mode
+  // actor role).  The WIDE kernels keep two workgroups per tile.  MBPO_SAC_SPLIT=0/1 overrides (measurement).
   static const int split_env = getenv("MBPO_SAC_SPLIT") ? atoi(getenv("MBPO_SAC_SPLIT")) : -1;
-  const bool split = split_env >= 0 ? split_env != 0 : pl.H >= 128;
+  const bool wide_any = net_is_wide(A.sh_pi) || net_is_wide(A.sh_q);
+  const bool split = split_env >= 0 ? split_env != 0 : !wide_any;
   A.split = split ? 1 : 0;
   const int wg_per_tile = split ? 3 : 2;
-  sac_chain_table(pl, d->row_len, &A, split);
+  // forward-mode dQ/da in the actor role: one action dimension (one tangent), register-image kernels with one-tile network ends
+  static const int jvp_env = getenv("MBPO_SAC_JVP") ? atoi(getenv("MBPO_SAC_JVP")) : -1;
+  const bool reg_path = (pl.H == 64 || split) && !(net_is_wide(A.sh_pi) || net_is_wide(A.sh_q)) && pl.LH >= 2;
+  const bool jvp = d->u_dim == 1 && reg_path && (jvp_env < 0 || jvp_env != 0);
+  A.jvp = jvp ? 1 : 0;
+  sac_chain_table(pl, d->row_len, &A, split, jvp);
   A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.D = d->row_len;
   A.batch = d->batch; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std;
   A.log_alpha = d->params + pl.NP - 1;
@@ -1092,6 +1126,10 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
         rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64, true>>(pl.lds, "sac_grads");
         if (rc != MBPO_OK) return rc;
         hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64, true>), dim3(wg_per_tile * pl.n_tiles), dim3(256 * SP64), pl.lds, st, A);
+      } else if (split) {
+        rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64, false, 2>>(pl.lds, "sac_grads");
+        if (rc != MBPO_OK) return rc;
+        hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64, false, 2>), dim3(wg_per_tile * pl.n_tiles), dim3(128 * SP64), pl.lds, st, A);
       } else {
         rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64, false>>(pl.lds, "sac_grads");
         if (rc != MBPO_OK) return rc;
