@@ -266,9 +266,24 @@ __device__ __forceinline__ void wset_fwd_hidden(const WSet<HT, SP> &S, const flo
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int t = 0; t < CT; ++t) tv[i * CT + t] = tacc[t][i];
-      act_grad_mul_vec<4 * CT>(tv, zv, act);      // h' = act'(z) * z'
+      if (act == MBPO_ACT_SWISH) {
+        // one sigmoid per element serves both: h = z * sg, h' = sg * (1 + z * (1 - sg)) * z'  (the same expressions as
+        // act_apply / act_grad, evaluated once)
+#pragma unroll
+        for (int i = 0; i < 4 * CT; ++i) {
+          const float sg = fast_sigmoid(zv[i]);
+          tv[i] *= sg * (1.0f + zv[i] * (1.0f - sg));
+          zv[i] = zv[i] * sg;
+        }
+      } else {
+        act_grad_mul_vec<4 * CT>(tv, zv, act);      // h' = act'(z) * z'
+        act_apply_vec<4 * CT>(zv, act);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) store_vec_lds<CT>(th_out + o0 + i * ldo, *reinterpret_cast<float(*)[CT]>(&tv[i * CT]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) store_vec_lds<CT>(h_out + o0 + i * ldo, *reinterpret_cast<float(*)[CT]>(&zv[i * CT]));
+      return;
     }
   }
   act_apply_vec<4 * CT>(zv, act);
