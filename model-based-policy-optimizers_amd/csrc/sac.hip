@@ -277,6 +277,18 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
   // here; after the first barrier they are folded into one flag — "a group's QUICK norm (float atomics of the reduce launch, any
   // order) is within 1e-4 of max_norm or beyond": practically never.  Only then, behind the phases, are the canonical norms formed
   // (fixed order: the clip decision and the clipped step are bit-identical to mbpo_sac_apply's).
+  // Warm the scalar cache with the whole kernel-argument block.  The phase loop fetches its operands lazily — the 64-byte chain
+  // descriptor of each phase, network shapes, slab pointers — and every first touch of a kernarg line was a miss to memory
+  // (the block is fresh for every launch): ~2 k cycles of "chain set-up" per phase, on every wave.  The LAST wave, which has no
+  // tile element to load, reads one dword of every 64-byte line here (scalar loads: they fill the scalar cache the whole CU
+  // shares) and pays the one cold-miss latency while the other waves wait for the tile anyway.
+  if (wave == NCH * SP - 1) {
+    const int *ka = reinterpret_cast<const int *>(&A.pi);
+    int acc = 0;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(SacArgs) / 64); ++i) acc += ka[i * 16];
+    asm volatile("" ::"s"(acc));
+  }
   const uint4 qw0 = *reinterpret_cast<const uint4 *>(A.opt.seq), qw1 = *reinterpret_cast<const uint4 *>(A.opt.seq + 4);
   const float count_in = A.step_count_rw[0];
   const unsigned int ep0_in = A.p2p_epoch ? A.p2p_epoch[0] : 0u, ep1_in = A.p2p_epoch ? A.p2p_epoch[1] : 0u;

@@ -15,6 +15,11 @@ stamps = torch.zeros(64, dtype=torch.int64, device=dev)
 names = {0: ["start", "setup", "E load tile", "F0 pi(s')||Q1||Q2 fwd", "E sample a'", "F1 Qtgt fwd", "E targets", "B2 Q dgrad||wgrad", "E partials"],
          1: ["start", "setup", "E load tile", "F0 pi(s) fwd", "E sample a", "F1 Q1||Q2 fwd", "E dL/dq", "B2 Q input-grad", "E dL/dlogits",
              "B3 pi dgrad||wgrad", "E partials"]}
+import os
+if X and U == 1 and os.environ.get("MBPO_SAC_JVP", "1") != "0" and hid[0] in (64, 128):
+    # forward-mode actor role (the default at u = 1): no critic input-gradient phase
+    names[1] = ["start", "setup", "E load tile", "F0 pi(s) fwd", "E sample a", "F1 Q1||Q2 fwd + tangent", "E dL/dq, dL/dlogits",
+                "B2 pi dgrad||wgrad", "E partials"]
 for mode in ("warm (same params re-read)", "cold (params rewritten by apply)"):
     acc = None
     for it in range(20):
