@@ -258,9 +258,26 @@ def main():
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
+        if os.environ.get("MBPO_BENCH_CHUNKS") and graph is not None:
+            # diagnostic (stderr only, after the timed region): is the step time stable within one process?
+            per = []
+            for _ in range(int(os.environ["MBPO_BENCH_CHUNKS"])):
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                for _ in range(20):
+                    graph.replay()
+                torch.cuda.synchronize()
+                per.append((time.perf_counter() - c0) / 20 * 1e3)
+            log("chunks of 20 steps, ms/step: " + " ".join(f"{v:.3f}" for v in per))
 
         return trainer, ts, env_state, buffer_state, graph, dt
 
+    for _ in range(int(os.environ.get("MBPO_BENCH_REMEASURE", "0"))):
+        # diagnostic: does the step time depend on where THIS trainer instance's buffers landed?  (stderr only)
+        tr_, *_rest, g_, dt_ = measure()
+        log(f"extra trainer instance: {dt_ / args.steps * 1e3:.3f} ms/step  params@{tr_.updater.params.data_ptr():#x} "
+            f"workspace@{tr_.updater.workspace.data_ptr():#x}")
+        del tr_, _rest, g_
     trainer, ts, env_state, buffer_state, graph, dt = measure()
     if pg is not None and getattr(trainer, "p2p", None) is not None:
         # a peer exchange that timed out poisons the gradients with NaN (csrc/p2p.hpp); such a run is not a measurement:

@@ -178,6 +178,13 @@ def main():
         pd, dd = [X, *hid_pi, 2 * U], [X + U, *hid_dyn, 2 * X]
         pp = lecun_flat(pd, g).to(dev)
         dp = lecun_flat(dd, g, E).to(dev)
+        pd_k, dd_k = pd, dd
+        if max(hid_pi) != max(hid_dyn):
+            # the fused kernel walks policy and members at ONE hidden width: the host zero-pads the narrower net (as the trainers
+            # do, INTEGRATION.md "Network shapes"); FLOP are counted on the logical shapes
+            w = max(max(hid_pi), max(hid_dyn))
+            pp, dp = ops.embed_mlp_params(pp, pd, w), ops.embed_mlp_params(dp, dd, w, E)
+            pd_k, dd_k = ops.padded_dims(pd, w), ops.padded_dims(dd, w)
         obs = torch.randn(N, X, generator=g).to(dev)
         first = obs.clone()
         steps, done = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
@@ -185,9 +192,9 @@ def main():
         rows = torch.empty(S * N, 2 * X + U + 3, device=dev)
 
         def run():
-            ops.model_rollout(policy_params=pp, policy_spec=ops.MlpSpec(pd), x_dim=X, u_dim=U, obs=obs, first_obs=first, steps=steps,
+            ops.model_rollout(policy_params=pp, policy_spec=ops.MlpSpec(pd_k), x_dim=X, u_dim=U, obs=obs, first_obs=first, steps=steps,
                               done=done, n_steps=S, episode_length=S, system_kind=_hip.SYS_ENSEMBLE, dyn_params=dp,
-                              dyn_spec=ops.MlpSpec(dd, "swish", E), reward_kind=_hip.REWARD_QUADRATIC, reward_params=rp, seed=1,
+                              dyn_spec=ops.MlpSpec(dd_k, "swish", E), reward_kind=_hip.REWARD_QUADRATIC, reward_params=rp, seed=1,
                               offset=0, out=rows)
         t, te = both(run, reps)
         flop = N * S * (2 * E * mlp_macs(dd) + 2 * mlp_macs(pd))
