@@ -310,15 +310,15 @@ def main():
             sys.path.insert(0, str(ROOT / "scripts"))
             from make_pmc_traffic import source_sha16
             pmc = json.loads((ROOT / "profiles" / "r02_pmc_traffic.json").read_text())
-            k = pmc["kernels"]["k_sac_fwd_bwd<64, 4, false>"]
+            k = pmc["kernels"]["k_sac_fwd_bwd<64, 4, false, 2>"]     # the variant this workload launches (three workgroups per tile)
             if pmc.get("source_sha16") != source_sha16():
                 traffic_note = ("profiles/r02_pmc_traffic.json was collected on other kernel sources (hash mismatch): refused; "
                                 "re-run scripts/collect_pmc.sh + scripts/make_pmc_traffic.py")
             else:
                 traffic = int((k["fetch_kb"] + k["write_kb"]) * 1024)
                 traffic_note = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r02_pmc_traffic.json (rocprofv3 --pmc, separate passes; "
-                                "source hash checked); 1.64 MB of it are the 16 per-tile gradient slabs the deterministic cross-tile "
-                                "reduction needs, reads are the weights once per XCD")
+                                "source hash checked); 1.65 MB written = the 16 per-tile gradient slabs the fixed-order cross-tile "
+                                "reduction reads back, 1.1 MB read = weights once per workgroup (48 workgroups, 8 L2s) + the tile rows")
         except Exception as e:      # noqa: BLE001
             traffic_note = f"no usable PMC measurement ({type(e).__name__})"
         out = {
@@ -346,7 +346,7 @@ def main():
             "sac_updates_per_s": GRAD_UPDATES * args.steps / dt,
             "sac_update_samples_per_s": world * BATCH * GRAD_UPDATES * args.steps / dt,
             "params_finite": finite,
-            "roofline": {"bound": "mfma", "kernel": "k_sac_fwd_bwd<64,4,false>", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "k_sac_fwd_bwd<64,4,false,2>", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_us": t_kernel * 1e6, "algorithmic_flop_per_launch": BATCH * flop_per_sample,
                          "launches_per_step": GRAD_UPDATES},
