@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
         chain_dgrad_run<HT, SP, WIDE>(sh, cparams, P(cy), ld_y, P(czb), P(cpp0), P(cpp1), P(cdx), ld_xu, ld_h, len, sub, lane, R);
       else if (mode == CH_WGRAD)
         chain_wgrad_run<HT, SP, WIDE>(sh, P(cx), cldx, P(chb), P(cy), ld_y, P(cpp0), P(cpp1), cslab, false, ld_h, len, sub, lane,
-                                (A.stamps && tile == 0 && role == 0 && sub == 0 && chain == 2) ? A.stamps + 48 : nullptr);
+                                (A.stamps && tile == 0 && role == 0 && sub == 0 && chain == (A.split ? 1 : 2)) ? A.stamps + 48 : nullptr);
       else
         chain_idle_run(len);
     }
