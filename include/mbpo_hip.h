@@ -286,6 +286,13 @@ typedef struct mbpo_sac_desc {
 } mbpo_sac_desc;
 
 int64_t mbpo_sac_workspace_floats(const mbpo_sac_desc *d);
+/* Offset (in floats) inside `workspace` of the 16-word control block the optimizer launches keep (uint32 words unless noted):
+ * [0] two-launch steps issued, [1] two-launch steps whose clip check is resolved, [13] clip events = optimizer steps in which
+ * clip_by_global_norm actually scaled some group (sac.py:218-225 'optax.clip_by_global_norm'), counted by every path
+ * (mbpo_sac_apply, the next mbpo_sac_step, mbpo_sac_finalize).  The other words are private.  A host reads [13] between epochs
+ * to choose between the two- and the three-launch step: a step that clips costs the two-launch path a second pass (see
+ * INTEGRATION.md, "Gradient clipping").  Negative: error code. */
+int64_t mbpo_sac_control_offset(const mbpo_sac_desc *d);
 int mbpo_sac_grads(const mbpo_sac_desc *d, void *stream);
 /* measurement hook: run only part of mbpo_sac_grads — phase_mask bit0 = forward/backward kernel (k_sac_fwd_bwd),
  * bit1 = slab reduce (k_sac_reduce).  mbpo_sac_grads == phase_mask 3.  Used by bench.py to time the dominant kernel. */

@@ -59,6 +59,10 @@ struct SacOptArgs {
   float max_norm, tau, one_minus_tau, grad_scale;
 };
 
+// Control block (16 words in the workspace, mbpo_sac_control_offset): [0] speculative steps issued, [1] resolved, [2..7] quick sums,
+// [8] slot word, [9..12] undo_count, [13] clip events = optimizer steps in which some group's gradient was clipped (every path).
+#define SAC_CTL_CLIP_EVENTS 13
+
 struct AdamOut {
   float p, m, v;
 };
@@ -589,6 +593,7 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
   sac_group_norms(A.opt, s_gn, tid_);
   __syncthreads();
   if (s_gn[0] < A.opt.max_norm && s_gn[1] < A.opt.max_norm && s_gn[2] < A.opt.max_norm) return;
+  if (blockIdx.x == 0 && tid_ == 0) A.opt.seq[SAC_CTL_CLIP_EVENTS] += 1u;     // (one writer per launch; read by the host between epochs)
   sac_clip_fixup(A.opt, s_gn, opaque(tid_), nthreads);
   __threadfence();
   __syncthreads();
@@ -776,6 +781,8 @@ __global__ void __launch_bounds__(256) k_sac_apply(SacOptArgs A) {
   } else if (grp == 2) {
     A.metrics[3] = expf(o.p);                                      // 'alpha': exp(alpha_params) (sac.py:267)
     if (A.metrics_accum) A.metrics_accum[3] += A.metrics[3];
+    // (this is the one thread of the launch that owns log_alpha) a step in which any group was clipped counts as a clip event
+    if (!(s_scale[0] < A.max_norm) || !(s_scale[1] < A.max_norm) || !(s_scale[2] < A.max_norm)) A.seq[SAC_CTL_CLIP_EVENTS] += 1u;
   }
 }
 
@@ -873,6 +880,7 @@ __global__ void __launch_bounds__(1024) k_sac_finalize(SacOptArgs O) {
   const bool clip = !(s_gn[0] < O.max_norm) || !(s_gn[1] < O.max_norm) || !(s_gn[2] < O.max_norm);
   if (clip) {
     sac_clip_fixup(O, s_gn, tid, 1024);
+    if (tid == 0) O.seq[SAC_CTL_CLIP_EVENTS] += 1u;
     __threadfence();
   }
   __syncthreads();
@@ -970,6 +978,13 @@ extern "C" int64_t mbpo_sac_workspace_floats(const mbpo_sac_desc *d) {
   int rc = sac_plan(d, &pl, false);
   if (rc != MBPO_OK) return rc;
   return pl.total;
+}
+
+extern "C" int64_t mbpo_sac_control_offset(const mbpo_sac_desc *d) {
+  SacPlan pl;
+  int rc = sac_plan(d, &pl, false);
+  if (rc != MBPO_OK) return rc;
+  return pl.off_seq;
 }
 
 constexpr int SP64 = 4;   // waves per chain at hidden width 64

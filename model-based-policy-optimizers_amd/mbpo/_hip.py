@@ -274,6 +274,10 @@ def _bind_optional(lib: C.CDLL) -> None:
     if fn is not None:
         fn.restype = C.c_int64
         fn.argtypes = [C.POINTER(SacDesc)]
+    fn = getattr(lib, "mbpo_sac_control_offset", None)
+    if fn is not None:
+        fn.restype = C.c_int64
+        fn.argtypes = [C.POINTER(SacDesc)]
 
 
 def check(rc: int, what: str) -> None:

@@ -519,6 +519,8 @@ class SacUpdater:
         # two_launch (default on; MBPO_SAC_TWO_LAUNCH=0 or two_launch=False selects grads + apply): fwd/bwd, then ONE launch for slab
         # reduction [+ peer exchange] + optimizer step; the clip check is resolved by the next step's prologue or by finalize().
         # A library collective (`all_reduce` without p2p) sits BETWEEN reduction and optimizer step: that path keeps its launches.
+        # (chosen explicitly — argument or environment — it stays; otherwise a trainer may switch between epochs on the clip rate)
+        self.two_launch_explicit = two_launch is not None or "MBPO_SAC_TWO_LAUNCH" in os.environ
         if two_launch is None:
             two_launch = os.environ.get("MBPO_SAC_TWO_LAUNCH", "1") != "0"
         self.two_launch = bool(two_launch)
@@ -559,6 +561,21 @@ class SacUpdater:
         d.step_count, d.grads, d.workspace, d.metrics = (t.data_ptr() for t in (self.step_count, self.grads, self.workspace, self.metrics))
         d.metrics_accum = self.metrics_accum.data_ptr()
         self.desc = d
+        off = int(self.lib.mbpo_sac_control_offset(C.byref(d)))
+        if off < 0:
+            check(off, "mbpo_sac_control_offset")
+        self._control = self.workspace[off:off + 16].view(torch.int32)      # include/mbpo_hip.h: mbpo_sac_control_offset
+
+    def clip_events(self) -> int:
+        """Optimizer steps so far in which clip_by_global_norm scaled some group (device counter; this call synchronises)."""
+        self.finalize()
+        return int(self._control[13])
+
+    def set_two_launch(self, flag: bool) -> None:
+        """Choose the two-launch (speculative apply, clip resolved by the next launch) or the three-launch step.  Results are
+        bit-identical; a step that clips costs the two-launch path a fix-up and a second pass (~95 vs ~36 us at B=256)."""
+        self.finalize()
+        self.two_launch = bool(flag)
 
     # views into the flat state
     @property

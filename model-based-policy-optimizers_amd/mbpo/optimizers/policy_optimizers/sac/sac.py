@@ -227,6 +227,7 @@ class SAC:
         self.use_graph = use_graph
         self._graph = None
         self._graph_key = None
+        self._clip_events_seen = 0                 # _adapt_step_mode
         self._graph_refs = None
         self._rng = ops.make_rng(self.device)      # device uint64[2]: {key of the running epoch / prefill, step index}
         self._eval_calls = 0
@@ -376,6 +377,7 @@ class SAC:
             training_state, env_state, buffer_state = self.training_step(training_state, env_state, buffer_state)
             done_steps += 1
         acc = self.updater.metrics_accum.cpu()
+        self._adapt_step_mode(n * self.grad_updates_per_step)
         if self.p2p is not None and self.p2p.status() != 0:
             # a rank never arrived within the bounded wait (csrc/p2p.hpp): its gradients were poisoned with NaN, not skipped
             raise _hip.MbpoHipError("SAC: the peer-memory gradient exchange timed out on this rank; "
@@ -384,6 +386,24 @@ class SAC:
         metrics = {'critic_loss': float(acc[0]) / cnt, 'actor_loss': float(acc[1]) / cnt, 'alpha_loss': float(acc[2]) / cnt,
                    'alpha': float(acc[3]) / cnt, 'buffer_current_size': float(self.replay_buffer.size(buffer_state))}
         return training_state, env_state, buffer_state, metrics
+
+    def _adapt_step_mode(self, steps: int) -> None:
+        """Between epochs: pick the sgd_step flavour from how often clip_by_global_norm (sac.py:218-225) actually scaled a
+        gradient.  The two-launch step applies the optimizer step unclipped and lets the next launch repair it — free when
+        nothing clips (the reference default max_grad_norm = 1e5), a fix-up and a second pass over the phases when
+        something does (~95 vs ~36 us per update at B = 256).  Both flavours give bit-identical parameters
+        (tests/test_gpu_sac.py), every rank sees the same all-reduced gradient and so takes the same decision, and the
+        hipGraph is keyed on the flavour.  An explicit choice (SacUpdater(two_launch=...), MBPO_SAC_TWO_LAUNCH) is left alone."""
+        up = self.updater
+        if up.two_launch_explicit or (up.all_reduce is not None and up.p2p is None):
+            return
+        events = up.clip_events()
+        rate = (events - self._clip_events_seen) / max(int(steps), 1)
+        self._clip_events_seen = events
+        if up.two_launch and rate > 0.05:
+            up.set_two_launch(False)
+        elif not up.two_launch and rate < 0.01:
+            up.set_two_launch(True)
 
     def _capturable(self) -> bool:
         """A training_step can be captured when it holds plain kernels only: single rank, the peer-memory exchange, or an
@@ -402,7 +422,7 @@ class SAC:
         tensors = [env_state.obs, env_state.info['first_obs'], env_state.info['steps'], env_state.done, buffer_state.data,
                    buffer_state.state, self._rollout_rows, self._batch_rows, self._stats_vec, self._rng]
         tensors += [v for v in spec.values() if isinstance(v, torch.Tensor)]
-        return tuple(t.data_ptr() for t in tensors), tensors
+        return tuple(t.data_ptr() for t in tensors) + (bool(self.updater.two_launch),), tensors
 
     def close(self) -> None:
         """Release the graph and the peer-memory regions (one P2PExchange per trainer: BraxOptimizer.train builds a trainer

@@ -7,7 +7,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     dev = torch.device('cuda:0')
     X, U, B, G = 4, 1, 256, 64
     hid = (64, 64, 64)
-    up = ops.SacUpdater(x_dim=X, u_dim=U, policy_dims=[X, *hid, 2 * U], q_dims=[X + U, *hid, 1], batch_size=B, device=dev, seed=1)
+    up = ops.SacUpdater(x_dim=X, u_dim=U, policy_dims=[X, *hid, 2 * U], q_dims=[X + U, *hid, 1], batch_size=B, device=dev, seed=1,
+                        max_grad_norm=float(os.environ.get("MBPO_AB_MAXNORM", "1e5")))
     g = torch.Generator().manual_seed(0)
     up.load_state((torch.randn(up.params.numel(), generator=g) * 0.1).to(dev))
     batches = torch.randn(G, B, 2 * X + U + 3, generator=g).to(dev)

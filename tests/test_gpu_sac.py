@@ -192,6 +192,11 @@ def test_two_launch_step_matches_three_launch_path(dev, max_norm, mode):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert clipped == (6 if max_norm == 0.05 else 0 if max_norm == 1e5 else clipped)
     print('policy-group clips:', clipped, 'of 6 at max_norm', max_norm)
+    # the device counter of clip events (mbpo_sac_control_offset word 13): both flavours count the same steps — those in which
+    # SOME group clipped (>= the policy-group count formed above)
+    ev = [up.clip_events() for up in ups]
+    assert ev[0] == ev[1], ev
+    assert ev[0] == (6 if max_norm == 0.05 else 0 if max_norm == 1e5 else ev[0]) and ev[0] >= clipped
     torch.testing.assert_close(a.metrics_accum, b.metrics_accum, atol=0, rtol=0)
 
 

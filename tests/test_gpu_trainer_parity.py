@@ -167,6 +167,44 @@ def test_sac_graph_epoch_is_bit_identical_to_eager_and_matches_oracle(dev, kind)
     np.testing.assert_allclose(b["stats"].numpy(), loop.stats, rtol=5e-4, atol=5e-5)
 
 
+def test_sac_trainer_picks_the_step_flavour_from_the_clip_rate(dev, monkeypatch):
+    """max_grad_norm small enough that every sgd_step clips: after the first epoch the trainer switches from the two-launch step
+    (a clip costs it a fix-up and a second pass) to the three-launch step, re-captures its hipGraph, and its state stays
+    bit-identical to a trainer pinned to the three-launch step; with the default max_grad_norm it keeps the two-launch step."""
+    from mbpo.optimizers.policy_optimizers.sac.sac import SAC
+    from mbpo.systems.brax_wrapper import BraxWrapper
+    monkeypatch.delenv("MBPO_SAC_TWO_LAUNCH", raising=False)
+
+    def run(max_norm, pinned):
+        if pinned:
+            monkeypatch.setenv("MBPO_SAC_TWO_LAUNCH", "0")
+        else:
+            monkeypatch.delenv("MBPO_SAC_TWO_LAUNCH", raising=False)
+        system, sp, _, X, U = _make_system(dev, "pendulum")
+        tb, tbs = _true_buffer(dev, X, U, 512)
+        env = BraxWrapper(system, sp, tbs, tb)
+        N, S = SAC_KW["num_envs"], SAC_KW["num_env_steps_between_updates"]
+        tr = SAC(environment=env, num_timesteps=64 + N * S * 4, use_graph=True, max_grad_norm=max_norm, **SAC_KW)
+        ts, es, bs = tr.init_training_state(7), tr.reset_envs(env, 11, N), tr.replay_buffer.init(13)
+        ts, es, bs, _ = tr.prefill_replay_buffer(ts, es, bs, 17)
+        flavours = [tr.updater.two_launch]
+        for key in (19, 23, 29):
+            ts, es, bs, _ = tr.training_epoch(ts, es, bs, key)
+            flavours.append(tr.updater.two_launch)
+        torch.cuda.synchronize()
+        return tr, flavours
+
+    a, fa = run(1e-3, pinned=False)
+    assert fa == [True, False, False, False], fa                 # one epoch observed, then the three-launch step
+    assert a.updater.clip_events() == 3 * 4 * SAC_KW["grad_updates_per_step"]
+    b, fb = run(1e-3, pinned=True)
+    assert fb == [False] * 4 and b.updater.two_launch_explicit
+    for name in ("params", "target_q", "adam_m", "adam_v"):
+        assert torch.equal(getattr(a.updater, name), getattr(b.updater, name)), name
+    c, fc = run(1e5, pinned=False)
+    assert fc == [True] * 4 and c.updater.clip_events() == 0
+
+
 def test_sac_steps_draw_fresh_noise_past_2_pow_24(dev):
     """the random streams must not depend on a float counter.  With the device step index at 2^24 - 1, 2^24 and
     2^24 + 1 (where a float32 `x + 1` stops moving) and beyond 2^32, consecutive replays still draw different numbers."""
