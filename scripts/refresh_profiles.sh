@@ -1,0 +1,26 @@
+#!/bin/bash
+# Copy what scripts/collect_profiles.sh + collect_pmc.sh + collect_pmc_sq.sh + the stamp scripts left under gpurun_out/ into
+# profiles/ under a round tag (default r02).  Run in the dev container after the gpurun call has merged gpurun_out/.
+set -e
+T=${1:-r02}
+R=$(cd "$(dirname "$0")/.." && pwd)
+cd $R
+python scripts/make_pmc_traffic.py gpurun_out/pmc_fetch_size gpurun_out/pmc_write_size profiles/${T}_pmc_traffic.json > /dev/null
+python scripts/make_pmc_sq.py gpurun_out/pmc_sq profiles/${T}_pmc_sq.json > /dev/null
+cp gpurun_out/kernel_rooflines.json profiles/${T}_kernel_rooflines.json
+cp $(ls -t gpurun_out/prof/runc/*_kernel_stats.csv | head -1) profiles/${T}_kernel_stats.csv
+cp gpurun_out/prof_bench.json profiles/${T}_prof_bench.json
+cp gpurun_out/bench.json profiles/${T}_bench.json
+mkdir -p profiles/pmc
+cp $(ls -t gpurun_out/pmc_fetch_size/runc/*counter_collection.csv | head -1) profiles/pmc/${T}_fetch_size_counter_collection.csv
+cp $(ls -t gpurun_out/pmc_write_size/runc/*counter_collection.csv | head -1) profiles/pmc/${T}_write_size_counter_collection.csv
+cp $(ls -t gpurun_out/pmc_sq/runc/*counter_collection.csv | head -1) profiles/pmc/${T}_sq_counter_collection.csv
+(echo "== scripts/sac_phase_stamps.py (k_sac_fwd_bwd<64,4,false,2>, three workgroups per tile + forward-mode actor role; tile 0)"; tail -22 gpurun_out/${T}_sac_stamps_64.txt
+ echo; echo "== scripts/sac_phase_stamps.py 128,128,128 (k_sac_fwd_bwd<128,4,false,2>)"; tail -22 gpurun_out/${T}_sac_stamps_128.txt
+ echo; echo "== scripts/rollout_phase_stamps.py"; grep -v amdgpu.ids gpurun_out/${T}_rollout_stamps.txt) > profiles/${T}_phase_stamps.txt
+tail -2 gpurun_out/tests_gpu.log
+python - <<PY
+import json
+b = json.load(open("profiles/${T}_bench.json"))
+print("bench:", round(b["value"] / 1e6, 3), "M transitions/s", round(b["ms_per_step"], 4), "ms/step; roofline", b["roofline"]["avg_launch_us"], "us frac", round(b["roofline"]["frac"], 4), "traffic", b["roofline"]["traffic"])
+PY
