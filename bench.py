@@ -310,7 +310,8 @@ def main():
             sys.path.insert(0, str(ROOT / "scripts"))
             from make_pmc_traffic import source_sha16
             pmc = json.loads((ROOT / "profiles" / "r02_pmc_traffic.json").read_text())
-            k = pmc["kernels"]["k_sac_fwd_bwd<64, 4, false, 2>"]     # the variant this workload launches (three workgroups per tile)
+            cand = {n: v for n, v in pmc["kernels"].items() if n.startswith("k_sac_fwd_bwd<64")}
+            k = max(cand.values(), key=lambda v: v["dispatches"])     # the variant this workload launches
             if pmc.get("source_sha16") != source_sha16():
                 traffic_note = ("profiles/r02_pmc_traffic.json was collected on other kernel sources (hash mismatch): refused; "
                                 "re-run scripts/collect_pmc.sh + scripts/make_pmc_traffic.py")
@@ -346,7 +347,7 @@ def main():
             "sac_updates_per_s": GRAD_UPDATES * args.steps / dt,
             "sac_update_samples_per_s": world * BATCH * GRAD_UPDATES * args.steps / dt,
             "params_finite": finite,
-            "roofline": {"bound": "mfma", "kernel": "k_sac_fwd_bwd<64,4,false,2>", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "k_sac_fwd_bwd<64,4,false,2,true>", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_us": t_kernel * 1e6, "algorithmic_flop_per_launch": BATCH * flop_per_sample,
                          "launches_per_step": GRAD_UPDATES},

@@ -495,17 +495,159 @@ __device__ __forceinline__ void dgrad_request(WSet<HT, SP> &S, const float *para
   else if (ln == 0 && want_dx && 16 * sub < K_in) wset_load_dg_in<HT, SP>(S, params, K_in, sub, lane);
 }
 
+// ------------------------------------------------------------------------------------------------ thin layers by VALU
+// A layer with K_in <= 8 inputs or N_out <= 4 outputs is 1/16 .. 1/8 of a hidden layer's arithmetic but cost a whole layer step
+// (request, LDS round trip, MFMA latency, epilogue, barrier: ~2 k cycles).  In `thin` mode (H == 64, SP == 4) the chain's four
+// waves do such a layer with plain FMAs — wave `sub` rows 4*sub .. 4*sub+3, lane = hidden column — in front of / behind the
+// runner, which then walks the H x H layers only.  Operands come from LDS by broadcast (x, dy) or coalesced (z, h, delta) reads.
+#define THIN_KMAX 8
+#define THIN_NMAX 4
+
+// forward: layer 1's image into A, this lane's column of layer 0 (K_in weights + bias) into tw
+template <int HT, int SP, bool WIDE = false>
+__device__ __forceinline__ void chain_fwd_prefetch_thin(WSet<HT, SP> &A, const NetShape sh, const float *params, int sub, int lane,
+                                                        float (&tw)[THIN_KMAX + 1]) {
+  constexpr int H = 16 * HT;
+  fwd_request<HT, SP, WIDE>(A, params + sh.K_in * H + H, 1, sh.L, sh.N_out, sub, lane);
+#pragma unroll
+  for (int k = 0; k < THIN_KMAX; ++k) {
+    const float w = params[(k < sh.K_in ? k : 0) * H + lane];
+    tw[k] = k < sh.K_in ? w : 0.f;
+  }
+  tw[THIN_KMAX] = params[sh.K_in * H + lane];
+}
+// dgrad: layer L-2's image into A, this lane's row of the output layer (N_out weights) into tw
+template <int HT, int SP>
+__device__ __forceinline__ void chain_dgrad_prefetch_thin(WSet<HT, SP> &A, const NetShape sh, const float *params, int sub, int lane,
+                                                          float (&tw)[THIN_KMAX + 1]) {
+  constexpr int H = 16 * HT;
+  const float *W1 = params + sh.K_in * H + H;
+  wset_load_dg_full<HT, SP>(A, W1 + (sh.L - 3) * (H * H + H), sub, lane);      // layer L-2 (>= 1)
+  const float *Wo = W1 + (sh.L - 2) * (H * H + H);                             // [H][N_out]
+#pragma unroll
+  for (int o = 0; o < THIN_NMAX; ++o) {
+    const float w = Wo[lane * sh.N_out + (o < sh.N_out ? o : 0)];
+    tw[o] = o < sh.N_out ? w : 0.f;
+  }
+}
+
+// layer 0 of a forward chain: h0 = act(x W0 + b0) for rows 4*sub .. 4*sub+3, column = lane; z0 and the tangent
+// d h0 / d x[k_tan] = act'(z0) W0[k_tan][col] are stored when asked for (tile layout [16][ldh]).
+// All LDS operands are requested up front (two 16-byte reads per row: the rows of an input tile are >= 8 floats apart and
+// 16-byte aligned); columns >= K_in are replaced by 0 (they are not initialised), the matching weights are loaded as 0.
+__device__ __forceinline__ void thin_fwd_first(const float (&tw)[THIN_KMAX + 1], int K_in, int act, const float *x, int ldx, float *h0,
+                                               float *z0, float *t0, int k_tan, int ldh, int sub, int lane) {
+  float xv[4][THIN_KMAX];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    load_vec_lds<4>(x + (4 * sub + i) * ldx, *reinterpret_cast<float(*)[4]>(&xv[i][0]));
+    load_vec_lds<4>(x + (4 * sub + i) * ldx + 4, *reinterpret_cast<float(*)[4]>(&xv[i][4]));
+  }
+  float wt = 0.f;
+#pragma unroll
+  for (int k = 0; k < THIN_KMAX; ++k) wt = (k == k_tan) ? tw[k] : wt;
+  float zv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float z = tw[THIN_KMAX];
+#pragma unroll
+    for (int k = 0; k < THIN_KMAX; ++k) z = fmaf(k < K_in ? xv[i][k] : 0.f, tw[k], z);
+    zv[i] = z;
+  }
+  if (z0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z0[(4 * sub + i) * ldh + lane] = zv[i];
+  }
+  if (t0) {
+    float tv[4] = {wt, wt, wt, wt};
+    act_grad_mul_vec<4>(tv, zv, act);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t0[(4 * sub + i) * ldh + lane] = tv[i];
+  }
+  act_apply_vec<4>(zv, act);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) h0[(4 * sub + i) * ldh + lane] = zv[i];
+}
+
+// delta_{L-2} = (dY Wout^T) * act'(z_{L-2}) for rows 4*sub .. 4*sub+3, column = lane (one 16-byte read of dY per row)
+__device__ __forceinline__ void thin_dgrad_out(const float (&tw)[THIN_KMAX + 1], int N_out, int act, const float *dY, int ldy,
+                                               const float *z, float *d_out, int ldh, int sub, int lane) {
+  float dv[4][THIN_NMAX], zv[4], sv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    load_vec_lds<4>(dY + (4 * sub + i) * ldy, dv[i]);
+    zv[i] = z[(4 * sub + i) * ldh + lane];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int o = 0; o < THIN_NMAX; ++o) s = fmaf(o < N_out ? dv[i][o] : 0.f, tw[o], s);
+    sv[i] = s;
+  }
+  act_grad_mul_vec<4>(sv, zv, act);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d_out[(4 * sub + i) * ldh + lane] = sv[i];
+}
+
+// output layer's weight gradient dW[c][o] = sum_r h[r][c] dY[r][o] (wave `sub` takes o = sub), db[o] = sum_r dY[r][o] (wave 0)
+template <int H>
+__device__ __forceinline__ void thin_wgrad_out(int N_out, const float *h, int ldh, const float *dY, int ldy, float *__restrict__ gW,
+                                               int sub, int lane) {
+  if (sub < N_out) {
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = fmaf(h[r * ldh + lane], dY[r * ldy + sub], acc);
+    gW[lane * N_out + sub] = acc;
+  }
+  if (sub == 0 && lane < N_out) {
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc += dY[r * ldy + lane];
+    gW[H * N_out + lane] = acc;
+  }
+}
+
+// layer 0's weight gradient dW0[k][c] = sum_r x[r][k] delta0[r][c] (wave `sub` takes k = sub, sub + 4), db0[c] (wave 3)
+template <int H>
+__device__ __forceinline__ void thin_wgrad_first(int K_in, const float *x, int ldx, const float *d0, int ldh, float *__restrict__ gW,
+                                                 int sub, int lane) {
+  float dv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dv[r] = d0[r * ldh + lane];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = sub + 4 * j;
+    if (k < K_in) {
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc = fmaf(x[r * ldx + k], dv[r], acc);
+      gW[k * H + lane] = acc;
+    }
+  }
+  if (sub == 3) {
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc += dv[r];
+    gW[K_in * H + lane] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ forward runner
 // x: network input tile [16][ldx].  Hidden outputs go to hbuf + l*T (when hbuf) or ping-pong pp0/pp1; pre-activations to
 // zbuf + l*T (when zbuf); the output layer to y [16][ldy].  A must hold layer 0's request (chain_fwd_prefetch).
 // Executes exactly n_steps workgroup barriers.
 // JVP: tp0 / tp1 (ping-pong hidden tiles for the tangent), ty [16][ldty] (tangent of the output) and k_tan (the input the tangent is
 // taken with respect to); tp0 == nullptr: no tangent.  Register-image path with a one-tile output only.
-template <int HT, int SP, bool WIDE = false, bool JVP = false>
+template <int HT, int SP, bool WIDE = false, bool JVP = false, bool THIN = false>
 __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__restrict__ params, const float *x, int ldx, float *pp0,
                                               float *pp1, float *zbuf, float *hbuf, float *y, int ldy, int ldh, int n_steps, int sub,
                                               int lane_, WSet<HT, SP> &A, unsigned long long *dbg = nullptr, float *tp0 = nullptr,
                                               float *tp1 = nullptr, float *ty = nullptr, int ldty = 0, int k_tan = 0) {
+  constexpr bool thin = THIN;
+  // thin (register-image path, L >= 3): the caller has computed layer 0 itself (thin_fwd_first: a K_in <= 8 layer is a handful
+  // of VALU FMAs per output, not worth a layer step with its barrier) and A holds layer 1's image (chain_fwd_prefetch_thin);
+  // the runner starts at layer 1 and executes one barrier fewer.
   constexpr int H = 16 * HT, CT = HT / SP;
   const int T = 16 * ldh, c0 = sub * 16 * CT;
   const int L = sh.L;
@@ -528,12 +670,15 @@ __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__
       const float *W1 = params + sh.K_in * H + H;   // layer 1
 #define request(S, ln, lane) fwd_request<HT, SP, WIDE>(S, W1, ln, L, sh.N_out, sub, lane)
       // ---- layer 0 (input image in A) ----
-      {
+      if constexpr (!thin) {
         const int lane = opaque(lane_);
         wset_wait(A);
         request(B, 1, lane);
         wset_fwd_hidden<HT, SP, true, JVP>(A, x, ldx, sh.K_in, hout(0), zout(0), ldh, sh.act, lane, nullptr, tout(0), k_tan);
         __syncthreads();
+      } else {
+        wset_wait(A);
+        B = A;      // layer 1's image was requested into A; the loop below expects it in B (a few register moves)
       }
       // ---- hidden layers 1 .. L-2, two per trip: B then A ----
       int l = 1;
@@ -614,7 +759,7 @@ __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__
     }
   }
 #pragma nounroll
-  for (int l = L; l < n_steps; ++l) __syncthreads();
+  for (int l = L - (thin ? 1 : 0); l < n_steps; ++l) __syncthreads();
 #undef hout
 #undef zout
 #undef hin
@@ -628,10 +773,14 @@ __device__ __forceinline__ void chain_fwd_run(const NetShape sh, const float *__
 // dY [16][ldy] is the delta of the output layer; deltas of hidden layers ping-pong through d0/d1 (layer l's dgrad writes
 // delta_{l-1} to (l&1 ? d1 : d0)); zbuf from the forward (layer l at + l*T); dX (optional) receives the input gradient.
 // A must hold layer L-1's request (chain_dgrad_prefetch).  Executes exactly n_steps workgroup barriers.
-template <int HT, int SP, bool WIDE = false>
+template <int HT, int SP, bool WIDE = false, bool THIN = false>
 __device__ __forceinline__ void chain_dgrad_run(const NetShape sh, const float *__restrict__ params, const float *dY, int ldy,
                                                 const float *zbuf, float *d0, float *d1, float *dX, int ld_dx, int ldh, int n_steps,
                                                 int sub, int lane_, WSet<HT, SP> &A) {
+  constexpr bool thin = THIN;
+  // thin (register-image path, L >= 3, no dX): the caller has formed delta_{L-2} itself (thin_dgrad_out: an N_out <= 4 output
+  // layer is a few FMAs per element) and A holds layer L-2's image (chain_dgrad_prefetch_thin); layers L-2 .. 1 run here:
+  // L - 2 barriers.
   constexpr int H = 16 * HT, CT = HT / SP;
   const int T = 16 * ldh, k0 = sub * 16 * CT;
   const int L = sh.L;
@@ -645,7 +794,10 @@ __device__ __forceinline__ void chain_dgrad_run(const NetShape sh, const float *
       WSet<HT, SP> B;
 #define request(S, ln, lane) dgrad_request<HT, SP>(S, params, W1, ln, sh.K_in, dX != nullptr, sub, lane)
       // ---- output layer L-1 (image in A) ----
-      {
+      if constexpr (thin) {
+        wset_wait(A);
+        B = A;
+      } else {
         const int lane = opaque(lane_);
         wset_wait(A);
         request(B, L - 2, lane);
@@ -683,7 +835,7 @@ __device__ __forceinline__ void chain_dgrad_run(const NetShape sh, const float *
         if (in_a) wset_dgrad_in<HT, SP>(A, din(0), ldh, sh.K_in, dX, ld_dx, sub, lane);
         else wset_dgrad_in<HT, SP>(B, din(0), ldh, sh.K_in, dX, ld_dx, sub, lane);
       }
-      __syncthreads();
+      if (!thin) __syncthreads();
     }
   } else {
     const float *W = W1 + (L - 2) * (H * H + H);   // layer L-1
@@ -708,7 +860,7 @@ __device__ __forceinline__ void chain_dgrad_run(const NetShape sh, const float *
     }
   }
 #pragma nounroll
-  for (int l = L; l < n_steps; ++l) __syncthreads();
+  for (int l = L - (thin ? 2 : 0); l < n_steps; ++l) __syncthreads();
 #undef din
 #undef dout
 #undef zprev
@@ -811,10 +963,13 @@ __device__ __forceinline__ void wgrad_tile_fast(const float *a_src, int lda, int
 // ------------------------------------------------------------------------------------------------ wgrad runner
 // Walks L-1..0 beside a dgrad runner that shares dY/d0/d1: dW_l, db_l from (h_{l-1} | x, delta_l) into `slab` (flat layout
 // of one net).  Executes n_steps barriers.
-template <int HT, int SP, bool WIDE = false>
+template <int HT, int SP, bool WIDE = false, bool THIN = false>
 __device__ __forceinline__ void chain_wgrad_run(const NetShape sh, const float *x, int ldx, const float *hbuf, const float *dY, int ldy,
                                                 const float *d0, const float *d1, float *__restrict__ slab, bool accumulate, int ldh,
                                                 int n_steps, int sub, int lane_, unsigned long long *dbg = nullptr) {
+  constexpr bool thin = THIN;
+  // thin: the output layer's and layer 0's weight gradients are formed by the caller (thin_wgrad_out / thin_wgrad_first);
+  // layers L-2 .. 1 run here: L - 2 barriers.
   constexpr int H = 16 * HT, CT = HT / SP;
   const int T = 16 * ldh;
   const int L = sh.L;
@@ -824,9 +979,10 @@ __device__ __forceinline__ void chain_wgrad_run(const NetShape sh, const float *
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
     dbg[i] = t_;                                                                     \
   }
-  float *gW = slab + (sh.K_in * H + H) + (L - 2) * (H * H + H);   // layer L-1
+  const int l_hi = thin ? L - 2 : L - 1, l_lo = thin ? 1 : 0;
+  float *gW = slab + (sh.K_in * H + H) + (l_hi - 1) * (H * H + H);   // layer l_hi
 #pragma nounroll
-  for (int l = L - 1; l >= 0; --l) {
+  for (int l = l_hi; l >= l_lo; --l) {
     const int lane = opaque(lane_);
     const bool out_layer = (l == L - 1);
     const int K = (l == 0) ? sh.K_in : H, N = out_layer ? sh.N_out : H;
@@ -871,7 +1027,7 @@ __device__ __forceinline__ void chain_wgrad_run(const NetShape sh, const float *
     gW -= (l - 1 == 0) ? (sh.K_in * H + H) : (H * H + H);
   }
 #pragma nounroll
-  for (int l = L; l < n_steps; ++l) __syncthreads();
+  for (int l = l_hi - l_lo + 1; l < n_steps; ++l) __syncthreads();
 }
 
 #undef DBG_STAMP

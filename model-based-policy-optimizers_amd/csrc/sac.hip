@@ -148,6 +148,7 @@ struct SacArgs {
   SacOptArgs opt;               // clip check of the previous speculative step
   float *step_count_rw;         // optimizer count: bumped by block 0 of every fwd/bwd launch
   int split;                    // 1: THREE workgroups per tile — critic 0, actor(+alpha), critic 1 (see k_sac_fwd_bwd)
+  int thin;                     // 1: layers with <= 8 inputs / <= 4 outputs by VALU around the runners (chain_run.hpp 'thin layers')
   int jvp;                      // 1 (u_dim == 1): the actor role gets dQ/da in FORWARD mode — the tangent rides along the critics' forward
                                 // pass (chain_run.hpp JVP) and the critics' input-gradient phase does not exist: 12 dependent layer
                                 // steps instead of 16 on the role that bounds the kernel
@@ -219,7 +220,7 @@ __device__ __forceinline__ ActSample normal_tanh_sample(float loc, float raw, fl
 // no role carries more than two chains at a time: at hidden width 128 that makes room for 4 waves per chain (8 waves, 2 per SIMD,
 // 256 VGPRs each) and with them for the register-image weight prefetch (a lane's share of a 128-wide layer is 64 weights + 2
 // biases per image, two images) that 16 waves x 128 VGPRs cannot hold.
-template <int H, int SP, bool WIDE, int NCH = 4>
+template <int H, int SP, bool WIDE, int NCH = 4, bool THIN = false>
 __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
@@ -317,6 +318,12 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
   //                 | E dL/dlogits | B3: c0 pi dgrad, c1 pi wgrad | E loss partials
   // What this wave walks in the current phase (wave-uniform scalars; LDS operands as offsets from smem, -1 = none).
   WSet<HT, SP> R;
+  constexpr int H_ = H;
+  constexpr bool THIN_OK = THIN;     // thin layers by VALU (chain_run.hpp): a kernel variant of its own, chosen by the host
+  static_assert(!THIN || (H_ == 64 && SP == 4 && !WIDE && NCH == 2), "thin layers: H = 64, four waves per chain, two chain slots");
+  float tw[THIN_KMAX + 1];                 // this lane's share of the next phase's thin layer (a column of W0 + bias, or a row of Wout)
+#pragma unroll
+  for (int k = 0; k <= THIN_KMAX; ++k) tw[k] = 0.f;
   int mode = CH_IDLE, netid = 0;
   const float *cparams = pi_p;
   float *cslab = nullptr;
@@ -336,18 +343,38 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
   for (int ph = -1; ph < nph; ++ph) {
     const int tid = opaque(tid_), lane = tid & 63;   // keeps per-lane addresses of all phases from being hoisted and spilled
     if (ph >= 0) {
-      const int len = (role == 0) ? (ph == 0 ? Lmax : QL) : ((ph == 0 || ph == nph - 1) ? PL : QL);
+      int len = (role == 0) ? (ph == 0 ? Lmax : QL) : ((ph == 0 || ph == nph - 1) ? PL : QL);
       const NetShape sh = netid == 0 ? A.sh_pi : A.sh_q;
+      constexpr bool thin = THIN_OK;
+      if constexpr (THIN_OK) {
+        {
+          // thin layers by VALU (chain_run.hpp): the chain's four waves form layer 0 of a forward chain, or delta_{L-2} and the
+          // output layer's weight gradient of a backward pair, from what the preceding section left in LDS; then the runners
+          // walk the H x H layers only (forward: L - 1 barriers instead of L, backward: L - 2)
+          if (mode == CH_FWD)
+            thin_fwd_first(tw, sh.K_in, sh.act, P(cx), cldx, chb >= 0 ? P(chb) : P(cpp0), P(czb), P(ctp0), X, ld_h, sub, lane);
+          else if (mode == CH_DGRAD)
+            thin_dgrad_out(tw, sh.N_out, sh.act, P(cy), ld_y, P(czb) + (sh.L - 2) * T, ((sh.L - 1) & 1) ? P(cpp1) : P(cpp0), ld_h, sub, lane);
+          else if (mode == CH_WGRAD)
+            thin_wgrad_out<H>(sh.N_out, P(chb) + (sh.L - 2) * T, ld_h, P(cy), ld_y,
+                              cslab + (sh.K_in * H + H) + (sh.L - 2) * (H * H + H), sub, lane);
+          __syncthreads();
+          len -= (ph == nph - 1) ? 2 : 1;
+        }
+      }
       if (mode == CH_FWD)
-        chain_fwd_run<HT, SP, WIDE, !WIDE>(sh, cparams, P(cx), cldx, P(cpp0), P(cpp1), P(czb), P(chb), P(cy), ld_y, ld_h, len, sub, lane, R,
+        chain_fwd_run<HT, SP, WIDE, !WIDE, THIN_OK>(sh, cparams, P(cx), cldx, P(cpp0), P(cpp1), P(czb), P(chb), P(cy), ld_y, ld_h, len, sub, lane, R,
                                            (A.stamps && tile == 0 && role == 1 && ph == 0 && wave == 0) ? A.stamps + 40 : nullptr,
                                            P(ctp0), P(ctp1), ctp0 >= 0 ? P(cdx) : nullptr, ld_xu, X);
       else if (mode == CH_DGRAD)
-        chain_dgrad_run<HT, SP, WIDE>(sh, cparams, P(cy), ld_y, P(czb), P(cpp0), P(cpp1), P(cdx), ld_xu, ld_h, len, sub, lane, R);
-      else if (mode == CH_WGRAD)
-        chain_wgrad_run<HT, SP, WIDE>(sh, P(cx), cldx, P(chb), P(cy), ld_y, P(cpp0), P(cpp1), cslab, false, ld_h, len, sub, lane,
+        chain_dgrad_run<HT, SP, WIDE, THIN_OK>(sh, cparams, P(cy), ld_y, P(czb), P(cpp0), P(cpp1), P(cdx), ld_xu, ld_h, len, sub, lane, R);
+      else if (mode == CH_WGRAD) {
+        chain_wgrad_run<HT, SP, WIDE, THIN_OK>(sh, P(cx), cldx, P(chb), P(cy), ld_y, P(cpp0), P(cpp1), cslab, false, ld_h, len, sub, lane,
                                 (A.stamps && tile == 0 && role == 0 && sub == 0 && chain == (A.split ? 1 : 2)) ? A.stamps + 48 : nullptr);
-      else
+        if constexpr (THIN_OK) {
+          thin_wgrad_first<H>(sh.K_in, P(cx), cldx, P(cpp1), ld_h, cslab, sub, lane);   // delta_0 is complete: the last barrier
+        }
+      } else
         chain_idle_run(len);
     }
     SAC_STAMP(2 * ph + 3);
@@ -363,8 +390,13 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
       cslab = cd.slab_sel == 1 ? A.slab_pi + (long long)tile * A.pi.n_params + cd.slab_off
                                : (cd.slab_sel == 2 ? A.slab_q + (long long)tile * (2 * A.q.n_params) + cd.slab_off : nullptr);
       const NetShape shn = netid == 0 ? A.sh_pi : A.sh_q;
-      if (mode == CH_FWD) chain_fwd_prefetch<HT, SP, WIDE>(R, shn, cparams, sub, lane);
-      else if (mode == CH_DGRAD) chain_dgrad_prefetch<HT, SP, WIDE>(R, shn, cparams, sub, lane);
+      if constexpr (THIN_OK) {
+        if (mode == CH_FWD) chain_fwd_prefetch_thin<HT, SP, WIDE>(R, shn, cparams, sub, lane, tw);
+        else if (mode == CH_DGRAD) chain_dgrad_prefetch_thin<HT, SP>(R, shn, cparams, sub, lane, tw);
+      } else {
+        if (mode == CH_FWD) chain_fwd_prefetch<HT, SP, WIDE>(R, shn, cparams, sub, lane);
+        else if (mode == CH_DGRAD) chain_dgrad_prefetch<HT, SP, WIDE>(R, shn, cparams, sub, lane);
+      }
     }
     if (A.stamps && tile == 0 && tid == 0 && ph == 1) {
       unsigned long long t_;
@@ -1120,6 +1152,14 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
   const bool reg_path = (pl.H == 64 || split) && !(net_is_wide(A.sh_pi) || net_is_wide(A.sh_q)) && pl.LH >= 2;
   const bool jvp = d->u_dim == 1 && reg_path && (jvp_env < 0 || jvp_env != 0);
   A.jvp = jvp ? 1 : 0;
+  // thin layers: the three-workgroup launch at H = 64 with forward-mode actor (no input-gradient chains), small input / output
+  // layers and at least one H x H layer in each network
+  {
+    const char *e = getenv("MBPO_SAC_THIN");
+    const bool want = e ? atoi(e) != 0 : true;
+    A.thin = (want && split && jvp && pl.H == 64 && A.sh_pi.K_in <= THIN_KMAX && A.sh_q.K_in <= THIN_KMAX && A.sh_pi.N_out <= THIN_NMAX &&
+              A.sh_q.N_out <= THIN_NMAX && A.sh_pi.L >= 3 && A.sh_q.L >= 3) ? 1 : 0;
+  }
   sac_chain_table(pl, d->row_len, &A, split, jvp);
   A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.D = d->row_len;
   A.batch = d->batch; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std;
@@ -1154,9 +1194,15 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
         if (rc != MBPO_OK) return rc;
         hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64, true>), dim3(wg_per_tile * pl.n_tiles), dim3(256 * SP64), pl.lds, st, A);
       } else if (split) {
-        rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64, false, 2>>(pl.lds, "sac_grads");
-        if (rc != MBPO_OK) return rc;
-        hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64, false, 2>), dim3(wg_per_tile * pl.n_tiles), dim3(128 * SP64), pl.lds, st, A);
+        if (A.thin) {
+          rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64, false, 2, true>>(pl.lds, "sac_grads");
+          if (rc != MBPO_OK) return rc;
+          hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64, false, 2, true>), dim3(wg_per_tile * pl.n_tiles), dim3(128 * SP64), pl.lds, st, A);
+        } else {
+          rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64, false, 2>>(pl.lds, "sac_grads");
+          if (rc != MBPO_OK) return rc;
+          hipLaunchKernelGGL((k_sac_fwd_bwd<64, SP64, false, 2>), dim3(wg_per_tile * pl.n_tiles), dim3(128 * SP64), pl.lds, st, A);
+        }
       } else {
         rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64, false>>(pl.lds, "sac_grads");
         if (rc != MBPO_OK) return rc;
