@@ -608,24 +608,22 @@ __device__ __forceinline__ void thin_wgrad_out(int N_out, const float *h, int ld
   }
 }
 
-// layer 0's weight gradient dW0[k][c] = sum_r x[r][k] delta0[r][c] (wave `sub` takes k = sub, sub + 4), db0[c] (wave 3)
+// layer 0's weight gradient dW0[k][c] = sum_r x[r][k] delta0[r][c] and db0[c] = sum_r delta0[r][c], column c = lane: wave `w8`
+// of the eight waves of a dgrad / wgrad pair takes input row k = w8 (< K_in <= 8); the bias goes to wave K_in, or, when all eight
+// carry a row, to wave 7 as well
 template <int H>
 __device__ __forceinline__ void thin_wgrad_first(int K_in, const float *x, int ldx, const float *d0, int ldh, float *__restrict__ gW,
-                                                 int sub, int lane) {
+                                                 int w8, int lane) {
   float dv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) dv[r] = d0[r * ldh + lane];
+  if (w8 < K_in) {
+    float acc = 0.f;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int k = sub + 4 * j;
-    if (k < K_in) {
-      float acc = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc = fmaf(x[r * ldx + k], dv[r], acc);
-      gW[k * H + lane] = acc;
-    }
+    for (int r = 0; r < 16; ++r) acc = fmaf(x[r * ldx + w8], dv[r], acc);
+    gW[w8 * H + lane] = acc;
   }
-  if (sub == 3) {
+  if (w8 == (K_in < 8 ? K_in : 7)) {
     float acc = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc += dv[r];

@@ -371,11 +371,14 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
       else if (mode == CH_WGRAD) {
         chain_wgrad_run<HT, SP, WIDE, THIN_OK>(sh, P(cx), cldx, P(chb), P(cy), ld_y, P(cpp0), P(cpp1), cslab, false, ld_h, len, sub, lane,
                                 (A.stamps && tile == 0 && role == 0 && sub == 0 && chain == (A.split ? 1 : 2)) ? A.stamps + 48 : nullptr);
-        if constexpr (THIN_OK) {
-          thin_wgrad_first<H>(sh.K_in, P(cx), cldx, P(cpp1), ld_h, cslab, sub, lane);   // delta_0 is complete: the last barrier
-        }
       } else
         chain_idle_run(len);
+      if constexpr (THIN_OK) {
+        // layer 0's weight gradient: delta_0 is complete (the runners' last barrier); the dgrad and the wgrad chain of the pair
+        // share input tile, delta tiles and slab, so all eight waves take one input row k (or the bias) each
+        if (ph == nph - 1 && (mode == CH_WGRAD || mode == CH_DGRAD))
+          thin_wgrad_first<H>(sh.K_in, P(cx), cldx, P(cpp1), ld_h, cslab, chain * SP + sub, lane);
+      }
     }
     SAC_STAMP(2 * ph + 3);
     // ---- the chain this wave walks in the NEXT phase; its first layer's weights are requested now ----
@@ -475,6 +478,7 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
           if (kq < 0 || k == kq) s_scal[32 + tid] = (k == 0 ? y_q1 : y_q2)[r * ld_y];
         }
       } else if (ph == 1) {
+        float e2 = 0.f;
         if (tid < 32) {
           const int k = tid >> 4, r = tid & 15;
           const bool ok = row0 + r < B;
@@ -493,15 +497,15 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
           const float target = rew * A.reward_scaling + disc * gamma * next_v;                     // :101-103
           const float trunc = s_row[r * D4 + D - 1];
           const float err = (ok && (kq < 0 || k == kq)) ? (s_scal[32 + tid] - target) * (1.f - trunc) : 0.f;   // q_error :104-108 (own critic)
-          s_scal[tid] = err * err;
+          e2 = err * err;
           // loss = 0.5*mean(err^2) over [B,2]  ->  dL/dq = err*(1-trunc)/(2B)
           s_dy[(k * 16 + r) * ld_y] = err * (1.f - trunc) * (0.5f * invB);
         }
-      } else {
-        if (tid == 0) {
-          float acc = 0.f;
-          for (int i = 0; i < 32; ++i) acc += s_scal[i];
-          A.slab_ex[tile * 4 + (kq == 1 ? 3 : 0)] = acc;     // (split: the two critics' partials in slots 0 and 3, added by the reduce)
+        // the tile's loss partial, formed here from the producers' registers (a shuffle tree over the first wave: fixed order)
+        // instead of by one thread re-reading 32 LDS words at the very end of the launch
+        if (wave == 0) {
+          const float acc = wave_sum64(e2);
+          if (tid == 0) A.slab_ex[tile * 4 + (kq == 1 ? 3 : 0)] = acc;     // (split: the two critics' partials in slots 0 and 3, added by the reduce)
         }
       }
     } else {
@@ -530,6 +534,7 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
           }
         }
       } else if (ph == 1) {
+        float l_al = 0.f, l_ac = 0.f;
         if (tid < 16) {
           const int r = tid;
           const bool ok = row0 + r < B;
@@ -539,10 +544,10 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
             lp_ac += s_lp[r * U + d];
           }
           // alpha_loss = alpha * stop_gradient(-log_prob - target_entropy); d/dlog_alpha = the same value   (:70-72)
-          s_scal[r] = ok ? alpha * (-lp_al - A.target_entropy) : 0.f;
+          l_al = ok ? alpha * (-lp_al - A.target_entropy) : 0.f;
           const float q0 = y_q1[r * ld_y], q1 = y_q2[r * ld_y];
           const float mq = fminf(q0, q1);
-          s_scal[32 + r] = ok ? (alpha * lp_ac - mq) : 0.f;   // actor_loss = alpha*log_prob - min_q   (:123-124)
+          l_ac = ok ? (alpha * lp_ac - mq) : 0.f;   // actor_loss = alpha*log_prob - min_q   (:123-124)
           // d(mean(-min_q))/dq_k: -1/B on the arg-min critic (ties split evenly, as jnp.min's gradient does)
           float g0 = 0.f, g1 = 0.f;
           if (ok) {
@@ -564,6 +569,13 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
             s_dy[(16 + r) * ld_y] = g1;
           }
         }
+        if (wave == 0) {     // the tile's loss partials from the producers' registers (shuffle tree: fixed order)
+          const float al = wave_sum64(l_al), ac = wave_sum64(l_ac);
+          if (tid == 0) {
+            A.slab_ex[tile * 4 + 1] = ac;
+            A.slab_ex[tile * 4 + 2] = al;
+          }
+        }
       } else if (ph == 2 && !A.jvp) {
         for (int i2 = tid; i2 < 16 * U; i2 += nthreads) {
           const int r = i2 & 15, d = i2 >> 4, idx = r * U + d;
@@ -575,16 +587,6 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
           const float gsig = gz * eps - alpha * invB / sg;
           s_dy[r * ld_y + d] = ok ? gz : 0.f;                              // d/dloc
           s_dy[r * ld_y + U + d] = ok ? gsig * fast_sigmoid(raw) : 0.f;    // d/draw = d/dsigma * softplus'(raw)
-        }
-      } else {
-        if (tid == 0) {
-          float al = 0.f, ac = 0.f;
-          for (int i = 0; i < 16; ++i) {
-            al += s_scal[i];
-            ac += s_scal[32 + i];
-          }
-          A.slab_ex[tile * 4 + 1] = ac;
-          A.slab_ex[tile * 4 + 2] = al;
         }
       }
     }

@@ -27,7 +27,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     e0.record()
     for _ in range(50): gr.replay()
     e1.record(); torch.cuda.synchronize()
-    print(json.dumps({"us_per_update": e0.elapsed_time(e1) / 50 / G * 1e3}))
+    print(json.dumps({"us_per_update": e0.elapsed_time(e1) / 50 / G * 1e3,
+                      "ptrs": [hex(t.data_ptr() & 0xffffffffff) for t in (up.params, up.workspace, batches, up.grads, up.adam_m)]}))
 else:
     libs = sys.argv[1:]
     for r in range(int(os.environ.get("ROUNDS", "3"))):
