@@ -642,7 +642,8 @@ struct SacReduceArgs {
 };
 
 // sum-of-squares partials per workgroup and optimizer group (0 policy, 1 critics, 2 alpha), fixed order
-__device__ __forceinline__ void group_sumsq(float g, int i, int P, int Q2, int NP, float *ss_part, float *quick = nullptr) {
+__device__ __forceinline__ void group_sumsq(float g, int i, int P, int Q2, int NP, float *ss_part, float *quick = nullptr,
+                                            float blk_lim = 0.f) {
   __shared__ float s_ss[3][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float gg = (i < NP) ? g * g : 0.f;
@@ -657,7 +658,17 @@ __device__ __forceinline__ void group_sumsq(float g, int i, int P, int Q2, int N
   if (tid < 3) {
     const float part = s_ss[tid][0] + s_ss[tid][1] + s_ss[tid][2] + s_ss[tid][3];
     ss_part[blockIdx.x * 3 + tid] = part;       // the canonical partials: summed in a FIXED order by whoever needs the norm
-    if (quick) atomicAdd(quick + tid, part);     // the quick sums: any order, for the conservative test only
+  }
+  // The quick clip test, without atomics: the groups share max_grad_norm, so if EVERY workgroup's sum over the three groups stays
+  // below limit / n_workgroups, every group's total is below the limit.  A workgroup that is not (or holds a NaN) raises the
+  // slot's word with a plain store (several may: same value); the reader's "word < limit" then fails and the canonical norms
+  // decide.  (Round 2 first added the per-group sums up with float atomics: 309 same-line atomics per launch, and a launch does
+  // not end before its last atomic has been performed — 0.5-0.9 us per update.)
+  if (quick && tid == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tot += s_ss[k][0] + s_ss[k][1] + s_ss[k][2] + s_ss[k][3];
+    if (!(tot < blk_lim)) quick[0] = 3.0e38f;
   }
 }
 
@@ -880,7 +891,8 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacReduceArgs A, SacOp
   }
   if (in) A.grads[i] = g;
   // (slot_word was published by this step's fwd/bwd launch: stable during this launch)
-  group_sumsq(g, i, A.P, A.Q2, NP, A.ss_part, reinterpret_cast<float *>(O.seq) + 2 + 3 * (O.slot_word[0] & 1u));   // ends in a __syncthreads
+  group_sumsq(g, i, A.P, A.Q2, NP, A.ss_part, reinterpret_cast<float *>(O.seq) + 2 + 3 * (O.slot_word[0] & 1u),
+              (O.max_norm / O.grad_scale) * (O.max_norm / O.grad_scale) * 0.9998f / (float)O.n_parts);   // ends in a __syncthreads
   if (!in) return;
   const int grp = (i < A.P) ? 0 : (i < A.P + A.Q2 ? 1 : 2);
   float *u_p = O.undo, *u_m = O.undo + NP, *u_v = O.undo + 2 * NP, *u_tq = O.undo + 3 * NP;
