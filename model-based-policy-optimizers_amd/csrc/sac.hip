@@ -851,6 +851,22 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacReduceArgs A, SacOp
   const bool crit = in && i >= A.P && i < A.P + A.Q2;
   const float tq_in = crit ? O.target_q[i - A.P] : 0.f;
   const float count = O.step_count[0];
+  // the launch's last element (log_alpha) also keeps the running metric sums and the sequence word: everything it will
+  // read-modify-write is requested HERE, beside its slab sums — one after the other behind them (a load of what it had just
+  // stored among them) these round trips were the tail of the launch: 0.45 us per update
+  const bool last = (i == NP - 1);
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f;
+  unsigned int seq0 = 0u;
+  if (last) {
+    seq0 = O.seq[0];
+    if (A.metrics_accum) {
+      acc0 = A.metrics_accum[0];
+      acc1 = A.metrics_accum[1];
+      acc2 = A.metrics_accum[2];
+      acc3 = A.metrics_accum[3];
+      acc4 = A.metrics_accum[4];
+    }
+  }
   unsigned epoch = 0, want = 0;
   if (EXCHANGE) {
     epoch = X.epoch[0];
@@ -871,18 +887,19 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacReduceArgs A, SacOp
                 al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
     const float invB = 1.0f / (float)A.B;
     g = al * invB;
-    A.metrics[0] = 0.5f * ce * (0.5f * invB);
-    A.metrics[1] = ac * invB;
-    A.metrics[2] = al * invB;
+    const float m0 = 0.5f * ce * (0.5f * invB), m1 = ac * invB, m2 = al * invB;
+    A.metrics[0] = m0;
+    A.metrics[1] = m1;
+    A.metrics[2] = m2;
     if (A.metrics_accum) {
-      A.metrics_accum[0] += A.metrics[0];
-      A.metrics_accum[1] += A.metrics[1];
-      A.metrics_accum[2] += A.metrics[2];
-      A.metrics_accum[4] += 1.0f;
+      A.metrics_accum[0] = acc0 + m0;
+      A.metrics_accum[1] = acc1 + m1;
+      A.metrics_accum[2] = acc2 + m2;
+      A.metrics_accum[4] = acc4 + 1.0f;
     }
     O.undo_count[0] = count;
-    O.undo_count[1] = A.metrics_accum ? A.metrics_accum[3] : 0.f;
-    O.seq[0] = O.seq[0] + 1u;      // one more speculative step whose clip check is pending
+    O.undo_count[1] = acc3;          // metrics_accum[3] before this step adds its 'alpha' (0 without running sums)
+    O.seq[0] = seq0 + 1u;            // one more speculative step whose clip check is pending
   }
   if (EXCHANGE) {
     p2p_push(X, epoch, i, NP, g);
@@ -911,7 +928,7 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacReduceArgs A, SacOp
     O.undo_count[3] = s_corr[1];
     const float al = expf(o.p);                                        // 'alpha' (sac.py:267); repaired by the fix-up if the group clips
     O.metrics[3] = al;
-    if (O.metrics_accum) O.metrics_accum[3] = O.undo_count[1] + al;    // same thread wrote undo_count[1] above
+    if (O.metrics_accum) O.metrics_accum[3] = acc3 + al;
   }
 }
 

@@ -13,6 +13,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     up.load_state((torch.randn(up.params.numel(), generator=g) * 0.1).to(dev))
     batches = torch.randn(G, B, 2 * X + U + 3, generator=g).to(dev)
     rng = ops.make_rng(dev, 5)
+    if os.environ.get("MBPO_AB_NO_ACCUM"):
+        up.desc.metrics_accum = None      # timing experiment: no running metric sums
     def scan():
         for i in range(G):
             up.sgd_step(batches[i], seed=0, offset=(16 + i) << 32, rng_dev=rng, defer_clip_check=True)
