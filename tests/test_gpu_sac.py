@@ -79,6 +79,33 @@ def test_sac_gradients_and_step(dev, X, U, hidden, B, normalize):
     assert float(up.step_count.cpu()) == 1.0
 
 
+@pytest.mark.parametrize("X,U,hidden,B", [
+    (4, 1, (64, 64, 64), 40),          # ragged tile (B not a multiple of 16)
+    (7, 1, (64, 64), 256),             # critic input x + u = 8: the widest layer the VALU form takes; one H x H layer per net
+    (3, 1, (64, 64, 64, 64), 48),      # an odd number of H x H layers (the runners' other register image holds the last one)
+])
+def test_sac_thin_layer_variant_matches_mfma_layers(dev, monkeypatch, X, U, hidden, B):
+    """k_sac_fwd_bwd<64,4,false,2,true> ('thin layers by VALU': layer 0 of the forward chains, the output layer's dgrad/wgrad and
+    layer 0's wgrad as plain FMAs around the runners) against the same launch with every layer on MFMA
+    (MBPO_SAC_THIN=0) and against the fp32 oracle: gradients, metrics and the optimizer step."""
+    cfg, st, batch, noise, nm, ns = _make(X, U, hidden, B, 2, True, discounting=0.97, reward_scaling=0.7, lr_policy=3e-4, lr_q=3e-4,
+                                           lr_alpha=3e-4, wd_q=1e-3)
+    g_ref, (cl, ac, al) = osac.grads(cfg, st.params, st.target_q, batch, *noise, nm, ns)
+    out = {}
+    for thin in ("1", "0"):
+        monkeypatch.setenv("MBPO_SAC_THIN", thin)
+        up = _updater(dev, cfg, B)
+        up.load_state(st.params.to(dev), st.target_q.to(dev))
+        up.sgd_step(batch.to(dev), nm.to(dev), ns.to(dev), *[n.to(dev) for n in noise])
+        torch.cuda.synchronize()
+        out[thin] = (up.grads.cpu().clone(), up.params.cpu().clone(), up.metrics.cpu().clone())
+    torch.testing.assert_close(out["1"][0], out["0"][0], atol=5e-7, rtol=2e-5)       # same arithmetic, another summation order
+    torch.testing.assert_close(out["1"][1], out["0"][1], atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(out["1"][2], out["0"][2], atol=1e-6, rtol=2e-5)
+    torch.testing.assert_close(out["1"][0], g_ref, atol=2e-6, rtol=2e-4)
+    np.testing.assert_allclose(out["1"][2].tolist()[:3], [cl, ac, al], rtol=5e-5, atol=2e-6)
+
+
 def test_sac_clip_triggers(dev):
     """max_grad_norm small enough to clip every group (the reference default 1e5 never does)."""
     cfg, st, batch, noise, nm, ns = _make(4, 1, (64, 64, 64), 64, 1, False, max_grad_norm=1e-3, lr_policy=1e-3, lr_q=1e-3,
