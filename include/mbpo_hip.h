@@ -209,12 +209,17 @@ int mbpo_philox_permutation(uint64_t seed, uint64_t offset, const uint64_t *rng_
  * The same update IS BPTT's Normalizer.update (bptt_optimizer.py:52-67) with summed_variance = std^2 * size:
  *   sum (x - new_mean)^2 + size*(mean - new_mean)^2 == sum d*(d - upd); its floor is std_min = 1e-8, no ceiling.
  * stats (device, fp32) = [count, mean[x], summed_variance[x], std[x]];
- * workspace >= mbpo_running_stats_workspace_floats(x_dim) floats (one partial per workgroup and column).
+ * workspace >= mbpo_running_stats_workspace_floats(x_dim) floats (one partial per workgroup, column and pass).
  */
 int64_t mbpo_running_stats_workspace_floats(int32_t x_dim);
 int mbpo_running_stats_reduce(const float *rows, int64_t n_rows, int32_t row_len, int32_t col_off, int32_t x_dim,
                               const float *stats, float *sums, float *workspace, int32_t pass, void *stream);
 int mbpo_running_stats_apply(float *stats, const float *sums, int32_t x_dim, float std_min, float std_max, void *stream);
+/* The same update for a SINGLE rank (nothing to all-reduce between the passes) in three launches instead of five: pass 0, then a
+ * pass 1 whose workgroups add the first pass's partials up themselves, then one workgroup that sums the second pass and applies.
+ * Bit-identical to reduce(pass 0) -> reduce(pass 1) -> apply; `sums` receives the same values. */
+int mbpo_running_stats_update(const float *rows, int64_t n_rows, int32_t row_len, int32_t col_off, int32_t x_dim, float *stats,
+                              float *sums, float *workspace, float std_min, float std_max, void *stream);
 
 /* ---- P4: GAE (ppo/losses.py:128-184) and B2: lambda-return (utils/optimizer_utils.py:119-152) -------
  * Reverse first-order linear recurrences evaluated as wavefront-shuffle segmented scans.

@@ -215,9 +215,8 @@ __global__ void __launch_bounds__(256) k_stats_partial(const float *rows, long l
 
 // column c's partials are summed by 256/X threads (slice sl takes partials sl, sl + nsl, ...; 8 loads in flight), the slices then
 // in slice order: a fixed order for given (n_parts, X)
-template <int PASS>
-__global__ void __launch_bounds__(256) k_stats_sums(const float *partial, int n_parts, int X, long long n_rows, float *sums) {
-  __shared__ float s_sl[256];
+// (workgroup function: 256 threads; returns column tid's total on threads tid < X; s_sl: 256 floats of LDS; ends behind a barrier)
+__device__ __forceinline__ float stats_column_sums(const float *partial, int n_parts, int X, float *s_sl) {
   const int tid = threadIdx.x;
   const int nsl = 256 / X, c = tid % X, sl = tid / X;
   float acc = 0.f;
@@ -234,17 +233,25 @@ __global__ void __launch_bounds__(256) k_stats_sums(const float *partial, int n_
   }
   s_sl[tid] = acc;
   __syncthreads();
-  if (tid < X) {
-    float a = 0.f;
+  float a = 0.f;
+  if (tid < X)
     for (int k = 0; k < nsl; ++k) a += s_sl[k * X + tid];
-    sums[1 + PASS * X + tid] = a;
-  }
+  __syncthreads();
+  return a;
+}
+
+template <int PASS>
+__global__ void __launch_bounds__(256) k_stats_sums(const float *partial, int n_parts, int X, long long n_rows, float *sums) {
+  __shared__ float s_sl[256];
+  const int tid = threadIdx.x;
+  const float a = stats_column_sums(partial, n_parts, X, s_sl);
+  if (tid < X) sums[1 + PASS * X + tid] = a;
   if (PASS == 0 && tid == 0) sums[0] = (float)n_rows;
 }
 
 extern "C" int64_t mbpo_running_stats_workspace_floats(int32_t x_dim) {
   if (x_dim <= 0 || x_dim > 128) return MBPO_ERR_ARG;
-  return (int64_t)STATS_WGS * x_dim;
+  return 2 * (int64_t)STATS_WGS * x_dim;      // one block of workgroup partials per pass (mbpo_running_stats_update keeps both)
 }
 
 extern "C" int mbpo_running_stats_reduce(const float *rows, int64_t n_rows, int32_t row_len, int32_t col_off, int32_t x_dim,
@@ -293,6 +300,84 @@ extern "C" int mbpo_running_stats_apply(float *stats, const float *sums, int32_t
   MBPO_REQUIRE(x_dim > 0 && x_dim <= 128, MBPO_ERR_ARG, "running_stats_apply: x_dim out of range");
   hipLaunchKernelGGL(k_stats_apply, dim3(1), dim3(128), 0, (hipStream_t)stream, stats, sums, x_dim, std_min, std_max);
   MBPO_CHECK_LAUNCH("running_stats_apply");
+  return MBPO_OK;
+}
+
+// ---- the whole update in THREE launches instead of five, for a single rank (no all-reduce between the passes): every workgroup of
+// the second pass adds the first pass's partials up itself (the same fixed order in each: identical totals), and the one workgroup
+// that sums the second pass's partials also applies the update.  Bit-identical to reduce(0) -> reduce(1) -> apply.
+__global__ void __launch_bounds__(256) k_stats_pass1_fused(const float *rows, long long n_rows, int D, int col_off, int X,
+                                                           const float *stats, const float *partial0, int n_parts0, float *sums,
+                                                           float *partial1) {
+  __shared__ float s_all[256];
+  __shared__ float s_sum0[128];
+  const int tid = threadIdx.x;
+  const float tot = stats_column_sums(partial0, n_parts0, X, s_all);
+  if (tid < X) {
+    s_sum0[tid] = tot;
+    if (blockIdx.x == 0) sums[1 + tid] = tot;
+  }
+  if (blockIdx.x == 0 && tid == 0) sums[0] = (float)n_rows;
+  __syncthreads();
+  const float *mean = stats + 1;
+  const int rows_per_pass = 256 / X;
+  const int c = tid % X, r0 = tid / X;
+  float acc = 0.f;
+  if (r0 < rows_per_pass) {
+    const float m = mean[c];
+    const float upd = s_sum0[c] / (stats[0] + (float)n_rows);
+    for (long long r = (long long)blockIdx.x * rows_per_pass + r0; r < n_rows; r += (long long)gridDim.x * rows_per_pass) {
+      float d = rows[r * D + col_off + c] - m;
+      acc += d * (d - upd);
+    }
+  }
+  s_all[tid] = acc;
+  __syncthreads();
+  if (tid < X) {
+    float a = 0.f;
+    for (int t = tid; t < rows_per_pass * X; t += X) a += s_all[t];
+    partial1[(long long)blockIdx.x * X + tid] = a;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_stats_sums1_apply(const float *partial1, int n_parts, int X, float *sums, float *stats,
+                                                           float std_min, float std_max) {
+  __shared__ float s_sl[256];
+  const int c = threadIdx.x;
+  const float a = stats_column_sums(partial1, n_parts, X, s_sl);
+  const float count = stats[0] + sums[0];
+  if (c < X) {
+    sums[1 + X + c] = a;
+    if (count > 0.f) {
+      float *mean = stats + 1, *sv = stats + 1 + X, *sd = stats + 1 + 2 * X;
+      mean[c] = mean[c] + sums[1 + c] / count;
+      float nsv = sv[c] + a;
+      sv[c] = nsv;
+      float s = sqrtf(fmaxf(nsv, 0.f) / count);
+      sd[c] = fminf(fmaxf(s, std_min), std_max);
+    }
+  }
+  __syncthreads();
+  if (c == 0) stats[0] = count;
+}
+
+extern "C" int mbpo_running_stats_update(const float *rows, int64_t n_rows, int32_t row_len, int32_t col_off, int32_t x_dim,
+                                         float *stats, float *sums, float *workspace, float std_min, float std_max, void *stream) {
+  MBPO_REQUIRE(stats && sums && workspace, MBPO_ERR_ARG, "running_stats_update: null pointer");
+  MBPO_REQUIRE(x_dim > 0 && x_dim <= 128 && row_len > 0 && col_off >= 0 && col_off + x_dim <= row_len, MBPO_ERR_ARG,
+               "running_stats_update: bad column range (x_dim must be <= 128)");
+  MBPO_REQUIRE(n_rows >= 0 && (n_rows == 0 || rows), MBPO_ERR_ARG, "running_stats_update: bad rows");
+  hipStream_t st = (hipStream_t)stream;
+  int rows_per_pass = 256 / x_dim;
+  long long want = (n_rows + rows_per_pass - 1) / rows_per_pass;
+  int grid = (int)(want < 1 ? 1 : (want < STATS_WGS ? want : STATS_WGS));
+  float *partial1 = workspace + (long long)STATS_WGS * x_dim;
+  hipLaunchKernelGGL(k_stats_partial<0>, dim3(grid), dim3(256), 0, st, rows, (long long)n_rows, row_len, col_off, x_dim,
+                     (const float *)stats, (const float *)sums, workspace);
+  hipLaunchKernelGGL(k_stats_pass1_fused, dim3(grid), dim3(256), 0, st, rows, (long long)n_rows, row_len, col_off, x_dim,
+                     (const float *)stats, (const float *)workspace, grid, sums, partial1);
+  hipLaunchKernelGGL(k_stats_sums1_apply, dim3(1), dim3(256), 0, st, (const float *)partial1, grid, x_dim, sums, stats, std_min, std_max);
+  MBPO_CHECK_LAUNCH("running_stats_update");
   return MBPO_OK;
 }
 

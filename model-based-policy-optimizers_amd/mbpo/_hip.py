@@ -197,6 +197,7 @@ def _bind_optional(lib: C.CDLL) -> None:
         "mbpo_replay_sample": [vp, i64, i32, vp, u64, u64, vp, i64, vp, vp, vp],
         "mbpo_running_stats_reduce": [vp, i64, i32, i32, i32, vp, vp, vp, i32, vp],
         "mbpo_running_stats_apply": [vp, vp, i32, f32, f32, vp],
+        "mbpo_running_stats_update": [vp, i64, i32, i32, i32, vp, vp, vp, f32, f32, vp],
         "mbpo_gae_scan": [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp],
         "mbpo_gae_scan_discounts": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
         "mbpo_lambda_return_scan": [vp, vp, vp, i64, i32, f32, f32, i32, vp],

@@ -443,6 +443,23 @@ def running_stats_update(rows: torch.Tensor, col_off: int, x_dim: int, stats: to
                          std_min: float = 1e-6, std_max: float = 1e6) -> None:
     """running_statistics.update(state, rows[:, col_off:col_off+x_dim]); `all_reduce(t)` sums `t` over ranks in place
     (the reference's psum under pmap_axis_name, sac/sac.py:298-301)."""
+    if all_reduce is None:
+        # a single rank: nothing sits between the passes — three launches instead of five, the same bits
+        lib = load()
+        _req(rows, "rows"); _req(stats, "stats")
+        if rows.dim() != 2 or stats.numel() != 1 + 3 * x_dim:
+            raise ValueError("rows must be [n, row_len] and stats [1 + 3*x_dim]")
+        if sums is None:
+            sums = torch.zeros(1 + 2 * x_dim, device=rows.device, dtype=torch.float32)
+        if workspace is None:
+            workspace = torch.empty(stats_workspace_floats(x_dim), device=rows.device, dtype=torch.float32)
+        _req(sums, "sums"); _req(workspace, "workspace")
+        if workspace.numel() < stats_workspace_floats(x_dim):
+            raise ValueError(f"workspace must hold {stats_workspace_floats(x_dim)} floats, got {workspace.numel()}")
+        check(lib.mbpo_running_stats_update(rows.data_ptr(), rows.shape[0], rows.shape[1], col_off, x_dim, stats.data_ptr(),
+                                            sums.data_ptr(), workspace.data_ptr(), std_min, std_max, current_stream_ptr()),
+              "mbpo_running_stats_update")
+        return
     sums = running_stats_reduce(rows, col_off, x_dim, stats, 0, sums=sums, workspace=workspace)
     if all_reduce is not None:
         all_reduce(sums)

@@ -93,6 +93,23 @@ def test_running_stats(dev, X, D, off, n):
         stats = got.copy()
 
 
+@pytest.mark.parametrize("X,D,off,n", [(4, 12, 0, 20480), (3, 10, 2, 1), (17, 40, 5, 100000), (128, 128, 0, 700)])
+def test_running_stats_fused_update_is_bit_identical_to_the_split_path(dev, X, D, off, n):
+    """mbpo_running_stats_update (single rank: 3 launches) vs reduce(pass 0) -> reduce(pass 1) -> apply (what a process group
+    runs, with its all-reduces in between): the same bits in stats and sums, over several chained updates."""
+    from mbpo import ops
+    g = torch.Generator().manual_seed(5)
+    a = torch.from_numpy(orep.stats_init(X)).to(dev)
+    b = a.clone()
+    sums_a, sums_b = torch.zeros(1 + 2 * X, device=dev), torch.zeros(1 + 2 * X, device=dev)
+    for it in range(3):
+        rows = (torch.randn(n, D, generator=g) * 2.5 + 0.7).to(dev)
+        ops.running_stats_update(rows, off, X, a, sums=sums_a)                                   # fused
+        ops.running_stats_update(rows, off, X, b, all_reduce=lambda t: None, sums=sums_b)        # split (identity all-reduce)
+        assert torch.equal(a, b), it
+        assert torch.equal(sums_a, sums_b), it
+
+
 def test_running_stats_first_update_from_init(dev):
     """init_state then one update == plain batch mean/std (count=n), incl. the std clip at 1e-6 for constant columns."""
     from mbpo import ops
