@@ -317,6 +317,9 @@ int mbpo_sac_apply(const mbpo_sac_desc *d, void *stream);
  * metrics[3] ('alpha') of a step becomes valid when its check has been resolved.  `workspace` must be zero before the first call. */
 int mbpo_sac_step(const mbpo_sac_desc *d, void *stream);
 int mbpo_sac_finalize(const mbpo_sac_desc *d, void *stream);
+/* mbpo_sac_finalize and mbpo_rng_advance(rng_dev, inc) in ONE launch: the end of a training step (sac.py:306-327 — after the scan
+ * of sgd_steps the step's randomness is used up and the device counter moves on). */
+int mbpo_sac_finalize_advance(const mbpo_sac_desc *d, uint64_t *rng_dev, uint64_t inc, void *stream);
 
 /* ---- P1-P3: PPO minibatch update (ppo/ppo.py:142-156, ppo/losses.py:56-126) -----------------------
  * replaces: PPO.minibatch_step = value_and_grad(PPOLoss.loss) + optax.adamw(lr, wd) over {policy, value} (ppo.py:128,139-140;

@@ -934,9 +934,11 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacReduceArgs A, SacOp
 
 // Resolves the clip check of the last speculative step when no further fwd/bwd launch will (end of training_step's sgd scan,
 // a single sgd_step of the eager API): one workgroup.  Idempotent.
-__global__ void __launch_bounds__(1024) k_sac_finalize(SacOptArgs O) {
+__global__ void __launch_bounds__(1024) k_sac_finalize(SacOptArgs O, unsigned long long *rng_dev, unsigned long long rng_inc) {
   __shared__ float s_gn[4];
   const int tid = threadIdx.x;
+  // (mbpo_sac_finalize_advance) the end of a training step: the device RNG's step counter moves on in this launch as well
+  if (rng_dev && tid == 0) rng_dev[1] += rng_inc;
   if (O.seq[0] == O.seq[1]) return;
   sac_group_norms(O, s_gn, tid);
   __syncthreads();
@@ -1345,7 +1347,19 @@ extern "C" int mbpo_sac_finalize(const mbpo_sac_desc *d, void *stream) {
   if (rc != MBPO_OK) return rc;
   SacOptArgs A;
   sac_fill_opt(d, pl, &A);
-  hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
+  hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(1024), 0, (hipStream_t)stream, A, (unsigned long long *)nullptr, 0ull);
   MBPO_CHECK_LAUNCH("sac_finalize");
+  return MBPO_OK;
+}
+
+extern "C" int mbpo_sac_finalize_advance(const mbpo_sac_desc *d, uint64_t *rng_dev, uint64_t inc, void *stream) {
+  MBPO_REQUIRE(rng_dev, MBPO_ERR_ARG, "sac_finalize_advance: null rng_dev");
+  SacPlan pl;
+  int rc = sac_plan(d, &pl, true);
+  if (rc != MBPO_OK) return rc;
+  SacOptArgs A;
+  sac_fill_opt(d, pl, &A);
+  hipLaunchKernelGGL(k_sac_finalize, dim3(1), dim3(1024), 0, (hipStream_t)stream, A, (unsigned long long *)rng_dev, (unsigned long long)inc);
+  MBPO_CHECK_LAUNCH("sac_finalize_advance");
   return MBPO_OK;
 }

@@ -217,6 +217,10 @@ def _bind_optional(lib: C.CDLL) -> None:
         if fn is not None:
             fn.restype = C.c_int
             fn.argtypes = [C.POINTER(SacDesc), vp]
+    fn = getattr(lib, "mbpo_sac_finalize_advance", None)
+    if fn is not None:
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(SacDesc), vp, u64, vp]
     for name in ("mbpo_ppo_grads", "mbpo_ppo_apply"):
         fn = getattr(lib, name, None)
         if fn is not None:

@@ -664,9 +664,14 @@ class SacUpdater:
             check(self.lib.mbpo_sac_grad_norms(C.byref(d), st), "mbpo_sac_grad_norms")
         check(self.lib.mbpo_sac_apply(C.byref(d), st), "mbpo_sac_apply")
 
-    def finalize(self) -> None:
-        """Resolve the pending clip check of the last two-launch step (mbpo_sac_finalize; a no-op when nothing is pending)."""
-        check(self.lib.mbpo_sac_finalize(C.byref(self.desc), current_stream_ptr()), "mbpo_sac_finalize")
+    def finalize(self, rng_dev: Optional[torch.Tensor] = None, rng_inc: int = 1) -> None:
+        """Resolve the pending clip check of the last two-launch step (mbpo_sac_finalize; a no-op when nothing is pending).
+        With `rng_dev` the same launch also advances the device RNG's step counter (the end of a training step)."""
+        if rng_dev is not None:
+            check(self.lib.mbpo_sac_finalize_advance(C.byref(self.desc), rng_ptr(rng_dev), int(rng_inc), current_stream_ptr()),
+                  "mbpo_sac_finalize_advance")
+        else:
+            check(self.lib.mbpo_sac_finalize(C.byref(self.desc), current_stream_ptr()), "mbpo_sac_finalize")
 
 
 # ------------------------------------------------------------------------------------------------ PPO minibatch update (P1-P3)

@@ -329,8 +329,7 @@ class SAC:
         for g in range(self.grad_updates_per_step):                                                # scan :324
             # each step's clip check is resolved by the next step's first launch; the last one by finalize (ops.SacUpdater)
             self.sgd_step(rows[g * B:(g + 1) * B], normalizer_params, g=g, defer_clip_check=True)
-        self.updater.finalize()
-        ops.rng_advance(self._rng)
+        self.updater.finalize(rng_dev=self._rng)          # + the device RNG's step counter moves on (one launch)
         return training_state, env_state, buffer_state
 
     def prefill_replay_buffer(self, training_state: TrainingState, env_state: State, buffer_state: ReplayBufferState, key: int):
