@@ -227,10 +227,11 @@ def test_two_launch_step_matches_three_launch_path(dev, max_norm, mode):
     torch.testing.assert_close(a.metrics_accum, b.metrics_accum, atol=0, rtol=0)
 
 
-def test_sac_non_equidistant_time_target(dev):
+@pytest.mark.parametrize("U", [2, 1])        # u = 1: the forward-mode actor / thin-layer kernel variant
+def test_sac_non_equidistant_time_target(dev, U):
     """N1 (sac/losses.py:90-98): the critic target's discount is exp(-continuous_discounting * t) per sample, t decoded from the
     last action component, affinely mapped to [min, max]_time_between_switches and floored to multiples of env_dt."""
-    X, U, B = 4, 2, 96
+    X, B = 4, 96
     kw = dict(non_equidistant_time=True, continuous_discounting=0.9, min_time_between_switches=0.05, max_time_between_switches=0.75,
               env_dt=0.05)
     cfg, st, batch, noise, nm, ns = _make(X, U, (64, 64, 64), B, 4, True, reward_scaling=1.5, lr_policy=3e-4, lr_q=3e-4,
