@@ -320,19 +320,27 @@ __global__ void __launch_bounds__(256) k_ppo_reduce(PpoReduceArgs A) {
   const float gsum = slab_sum_wg64(A.slabs, A.NPV, A.n_slabs, i, i < A.NPV);
   if (threadIdx.x < 64 && i < A.NPV) A.grads[i] = gsum;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // (what this thread read-modify-writes is requested before its slab sums: behind them, one after the other — with a load of
+    //  what it had just stored among them — these round trips were the tail of the launch, as in k_sac_reduce_apply)
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (A.metrics_accum) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) acc[k] = A.metrics_accum[k];
+    }
+    const float count = A.step_count[0];
     const float a = slab_sum<16>(A.extras, 4, A.n_slabs, 0), b = slab_sum<16>(A.extras, 4, A.n_slabs, 1),
                 c = slab_sum<16>(A.extras, 4, A.n_slabs, 2);
     const float invM = 1.0f / (float)A.M;
     const float pl = a * invM, vl = b * invM, el = A.entropy_cost * -(c * invM);
-    A.metrics[0] = pl + vl + el;   // total_loss
-    A.metrics[1] = pl;
-    A.metrics[2] = vl;
-    A.metrics[3] = el;
+    const float m[4] = {pl + vl + el, pl, vl, el};   // m[0]: total_loss
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A.metrics[k] = m[k];
     if (A.metrics_accum) {
-      for (int k = 0; k < 4; ++k) A.metrics_accum[k] += A.metrics[k];
-      A.metrics_accum[4] += 1.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) A.metrics_accum[k] = acc[k] + m[k];
+      A.metrics_accum[4] = acc[4] + 1.0f;
     }
-    A.step_count[0] = A.step_count[0] + 1.0f;
+    A.step_count[0] = count + 1.0f;
   }
 }
 

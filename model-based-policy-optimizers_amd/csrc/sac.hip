@@ -687,14 +687,16 @@ __global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
                 al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
     const float invB = 1.0f / (float)A.B;
     g = al * invB;                          // d alpha_loss / d log_alpha
-    A.metrics[0] = 0.5f * ce * (0.5f * invB);  // critic_loss = 0.5 * mean over [B,2]
-    A.metrics[1] = ac * invB;
-    A.metrics[2] = al * invB;
-    if (A.metrics_accum) {
-      A.metrics_accum[0] += A.metrics[0];
-      A.metrics_accum[1] += A.metrics[1];
-      A.metrics_accum[2] += A.metrics[2];
-      A.metrics_accum[4] += 1.0f;
+    const float m0 = 0.5f * ce * (0.5f * invB), m1 = ac * invB, m2 = al * invB;   // critic_loss = 0.5 * mean over [B,2]
+    A.metrics[0] = m0;
+    A.metrics[1] = m1;
+    A.metrics[2] = m2;
+    if (A.metrics_accum) {       // (no load of what was just stored: each such round trip is part of the launch's tail)
+      const float a0 = A.metrics_accum[0], a1 = A.metrics_accum[1], a2 = A.metrics_accum[2], a4 = A.metrics_accum[4];
+      A.metrics_accum[0] = a0 + m0;
+      A.metrics_accum[1] = a1 + m1;
+      A.metrics_accum[2] = a2 + m2;
+      A.metrics_accum[4] = a4 + 1.0f;
     }
   }
   if (i < NP) A.grads[i] = g;
@@ -718,14 +720,16 @@ __global__ void __launch_bounds__(256) k_sac_reduce_push(SacReduceArgs A, P2pDev
                 al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
     const float invB = 1.0f / (float)A.B;
     g = al * invB;
-    A.metrics[0] = 0.5f * ce * (0.5f * invB);
-    A.metrics[1] = ac * invB;
-    A.metrics[2] = al * invB;
-    if (A.metrics_accum) {
-      A.metrics_accum[0] += A.metrics[0];
-      A.metrics_accum[1] += A.metrics[1];
-      A.metrics_accum[2] += A.metrics[2];
-      A.metrics_accum[4] += 1.0f;
+    const float m0 = 0.5f * ce * (0.5f * invB), m1 = ac * invB, m2 = al * invB;
+    A.metrics[0] = m0;
+    A.metrics[1] = m1;
+    A.metrics[2] = m2;
+    if (A.metrics_accum) {       // (no load of what was just stored: each such round trip is part of the launch's tail)
+      const float a0 = A.metrics_accum[0], a1 = A.metrics_accum[1], a2 = A.metrics_accum[2], a4 = A.metrics_accum[4];
+      A.metrics_accum[0] = a0 + m0;
+      A.metrics_accum[1] = a1 + m1;
+      A.metrics_accum[2] = a2 + m2;
+      A.metrics_accum[4] = a4 + 1.0f;
     }
   }
   p2p_push(X, epoch, i, NP, g);
@@ -764,14 +768,16 @@ __global__ void __launch_bounds__(256) k_sac_reduce_exchange(SacReduceArgs A, P2
                 al = slab_sum<16>(A.slab_ex, 4, A.n_tiles, 2);
     const float invB = 1.0f / (float)A.B;
     g = al * invB;
-    A.metrics[0] = 0.5f * ce * (0.5f * invB);
-    A.metrics[1] = ac * invB;
-    A.metrics[2] = al * invB;
-    if (A.metrics_accum) {
-      A.metrics_accum[0] += A.metrics[0];
-      A.metrics_accum[1] += A.metrics[1];
-      A.metrics_accum[2] += A.metrics[2];
-      A.metrics_accum[4] += 1.0f;
+    const float m0 = 0.5f * ce * (0.5f * invB), m1 = ac * invB, m2 = al * invB;
+    A.metrics[0] = m0;
+    A.metrics[1] = m1;
+    A.metrics[2] = m2;
+    if (A.metrics_accum) {       // (no load of what was just stored: each such round trip is part of the launch's tail)
+      const float a0 = A.metrics_accum[0], a1 = A.metrics_accum[1], a2 = A.metrics_accum[2], a4 = A.metrics_accum[4];
+      A.metrics_accum[0] = a0 + m0;
+      A.metrics_accum[1] = a1 + m1;
+      A.metrics_accum[2] = a2 + m2;
+      A.metrics_accum[4] = a4 + 1.0f;
     }
   }
   p2p_push(X, epoch, i, NP, g);
