@@ -10,8 +10,13 @@ One "step" = one SAC.training_step (sac/sac.py:306-327): fused rollout of S*N tr
 replay insert + sample of B*G rows + G sgd_steps (each: fwd/bwd of the three losses, [all-reduce,] clip+AdamW+Polyak).
 value = transitions written per second by the whole job = n_gpus * N * S * steps / time  (weak scaling: per-GPU work fixed).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]      # N > 1 without WORLD_SIZE in the environment: bench.py starts its N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+After the headline measurement rank 0 (single-GPU run only) also measures, and appends as extra keys of the same JSON line:
+  steady_ms_per_step   the same hipGraph replayed >= 500 times (the timed region of the contract is K steps = tens of ms)
+  ppo_c3               BASELINE configs[2]: PPO.training_step at N=16384, B=512, M=32, T=40 and T=5 (ppo/ppo.py:179-247)
+  bptt_c5              BASELINE configs[4] per-GPU shape: BPTTOptimizer train step, E=10, H=32, x=17, u=6, n=4096 (bptt_optimizer.py:355-437)
 """
 from __future__ import annotations
 
@@ -150,6 +155,172 @@ def cpu_baseline(budget_s=12.0):
             "sac_updates_per_s": GRAD_UPDATES * n / dt}
 
 
+def _events_ms(fn, reps):
+    """Device time of `reps` calls of fn() on the current stream, ms per call (HIP events on the launch stream)."""
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(st)
+    for _ in range(reps):
+        fn()
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def ppo_c3_extra(device, unroll_length: int, steps: int = 10):
+    """BASELINE configs[2]: PPO.training_step (ppo/ppo.py:179-233) at N = 16384 envs, B = 512, M = 32 (B*M = N: one
+    unroll per step), num_updates_per_batch = 8, gamma .99, lambda .95, eps .3, 64x3 nets, Pendulum model; one hipGraph replay per
+    step (the reference compiles the epoch scan into one XLA computation, ppo.py:235-247).  GAE elements per step = E*M*B*T: every
+    minibatch_step runs compute_gae (ppo/losses.py:128-184) over its [T, B] block."""
+    from mbpo.optimizers.policy_optimizers.ppo.ppo import PPO
+    from mbpo.replay import UniformSamplingQueue
+    from mbpo.systems import PendulumSystem
+    from mbpo.systems.brax_wrapper import BraxWrapper
+    from mbpo.types import Transition
+    N, B, M, E, T = 16384, 512, 32, 8, unroll_length
+    system = PendulumSystem()
+    sp = system.init_params(1)
+    g = torch.Generator().manual_seed(0)
+    n_true = 2 ** 16
+    th = (torch.rand(n_true, generator=g) * 2 - 1) * 3.14159265
+    obs = torch.stack([torch.cos(th), torch.sin(th), (torch.rand(n_true, generator=g) * 2 - 1) * 8], dim=1)
+    act = torch.rand(n_true, 1, generator=g) * 2 - 1
+    dummy = Transition(observation=torch.zeros(3), action=torch.zeros(1), reward=torch.zeros(1), discount=torch.zeros(1),
+                       next_observation=torch.zeros(3))
+    tb = UniformSamplingQueue(n_true, dummy, 1, device=device)
+    tbs = tb.insert_rows(tb.init(0), torch.cat([obs, act, torch.zeros(n_true, 1), torch.ones(n_true, 1), obs], dim=1).to(device))
+    env = BraxWrapper(system, sp, tbs, tb)
+    tr = PPO(environment=env, num_timesteps=B * M * T * 1000, episode_length=200, num_envs=N, unroll_length=T, batch_size=B,
+             num_minibatches=M, num_updates_per_batch=E, normalize_observations=True, discounting=0.99, gae_lambda=0.95,
+             clipping_epsilon=0.3, entropy_cost=1e-2, lr=3e-4, reward_scaling=1.0, policy_hidden_layer_sizes=HIDDEN,
+             critic_hidden_layer_sizes=HIDDEN)
+    ts = tr.init_training_state(7)
+    es = env.reset([1000 + i for i in range(N)])
+    tr.rekey(23)
+    ts, es, _ = tr.training_step(ts, es)            # eager: warms every kernel
+    torch.cuda.synchronize()
+    graph = None
+    if tr._capturable():
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            tr.training_step(ts, es)
+        graph.replay()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            tr.training_step(ts, es)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    finite = bool(torch.isfinite(tr.updater.params).all())
+    launches = 1 + 3 + E * (2 + 1 + M * 6) + 1
+    tr.close()
+    return {"N": N, "B": B, "M": M, "T": T, "num_updates_per_batch": E, "ms_per_step": ms, "graph": graph is not None,
+            "gae_elements_per_s": E * M * B * T / (ms * 1e-3), "transitions_per_s": B * M * T / (ms * 1e-3),
+            "minibatch_steps_per_s": E * M / (ms * 1e-3), "params_finite": finite, "steps_timed": steps,
+            "approx_launches_per_step": launches}
+
+
+def bptt_c5_extra(device, steps=(6, 26)):
+    """BASELINE configs[4] at its per-GPU shape: BPTTOptimizer train steps (bptt_optimizer.py:355-437: actor gradient
+    through a 10-member ensemble over H = 32 steps from n = 4096 initial states, AdamW, one critic regression update, normalisers,
+    buffer insert), x = 17, u = 6, 64x3 nets.  Timed through the public train(): two calls with different train_steps, the
+    difference divided by the difference in steps (set-up cancels).  (state x step)/s = n*H per train step."""
+    from mbpo.optimizers import BPTTOptimizer
+    from mbpo.replay import UniformSamplingQueue
+    from mbpo.systems import EnsembleDynamics, EnsembleSystem, QuadraticReward
+    from mbpo.types import Transition
+    X, U, E, H, n = 17, 6, 10, 32, 4096
+    dyn = EnsembleDynamics(X, U, n_members=E, hidden_layer_sizes=HIDDEN, device=device)
+    system = EnsembleSystem(dyn, QuadraticReward(X, U), mode="mean", predict_delta=True)
+    g = torch.Generator().manual_seed(0)
+    rows = 2 ** 14
+    obs = torch.randn(rows, X, generator=g)
+    dummy = Transition(observation=torch.zeros(X), action=torch.zeros(U), reward=torch.zeros(1), discount=torch.zeros(1),
+                       next_observation=torch.zeros(X))
+    tb = UniformSamplingQueue(rows, dummy, 1, device=device)
+    tbs = tb.insert_rows(tb.init(0), torch.cat([obs, torch.zeros(rows, U), torch.zeros(rows, 1), torch.ones(rows, 1), obs], dim=1).to(device))
+    times = []
+    for k in steps:
+        opt = BPTTOptimizer(action_dim=U, obs_dim=X, horizon=H, num_samples_per_gradient_update=n, train_steps=k,
+                            critic_updates_per_policy_update=1, sampling_buffer_size=rows + (max(steps) + 2) * n * H)
+        opt.set_system(system)
+        st = opt.init(key=5, true_buffer_state=tbs)
+        st.system_params.dynamics_params.params.mul_(0.5)        # keep 32-step rollouts of a random ensemble O(1), as the headline does
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = opt.train(st)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        finite = bool(torch.isfinite(out.optimizer_state.actor_params).all())
+        del opt, out
+    ms = (times[1] - times[0]) / (steps[1] - steps[0]) * 1e3
+    return {"E": E, "H": H, "x": X, "u": U, "n": n, "ms_per_train_step": ms, "state_steps_per_s": n * H / (ms * 1e-3),
+            "params_finite": finite, "graph": True, "timed": f"train(train_steps={steps[1]}) - train(train_steps={steps[0]})"}
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` (N > 1) as ONE command: start N fresh rank processes of this same file — RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set — relay rank 0's single JSON line and
+    return non-zero if any rank failed.  This parent never touches the GPU (no torch.cuda call that initialises it): the ranks are
+    children created before anything here could."""
+    import socket
+    import subprocess
+    share = os.environ.get("MBPO_BENCH_SHARE_GPU") == "1"
+    n_dev = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    if n_dev < n and not share:
+        print(f"bench.py --gpus {n}: only {n_dev} GPU(s) visible (MBPO_BENCH_SHARE_GPU=1 rehearses all ranks on one GPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = b""
+    import threading
+    def drain():
+        nonlocal out0
+        out0 = procs[0].stdout.read()
+    th = threading.Thread(target=drain, daemon=True)
+    th.start()
+    rc, deadline = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad and deadline is None:            # one rank died: its peers would wait in a collective for ever
+            deadline = time.time() + 20.0
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                    # exact PIDs this parent started
+        time.sleep(0.2)
+    th.join(timeout=5.0)
+    codes = [p.returncode for p in procs]
+    if any(codes):
+        print(f"bench.py --gpus {n}: rank exit codes {codes}", file=sys.stderr)
+        rc = next(c for c in codes if c) or 1
+    lines = [l for l in out0.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        print(f"bench.py --gpus {n}: rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -162,6 +333,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the ppo_c3 / bptt_c5 extra measurements")
     args = ap.parse_args()
 
     # Libraries (RCCL's version banner) write to fd 1; the contract is ONE JSON line on stdout, so fd 1 points at stderr
@@ -170,12 +342,14 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.dup2(saved_stdout, 1)
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py with --gpus equal to the number of ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # rehearsal only (one-GPU box): MBPO_BENCH_SHARE_GPU=1 puts every rank on cuda:0, MBPO_BENCH_BACKEND=gloo replaces RCCL
@@ -293,6 +467,15 @@ def main():
 
     log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
     finite = bool(torch.isfinite(trainer.updater.params).all())
+    # which device every rank sits on, and — if the peer exchange was declined — why (for whoever reads an 8-GPU run's line)
+    from mbpo.parallel import P2PExchange
+    dev_ids, p2p_reasons = [torch.cuda.current_device()], [P2PExchange.last_decline_reason]
+    if pg is not None:
+        import torch.distributed as dist
+        gathered = [None] * dist.get_world_size(pg)
+        dist.all_gather_object(gathered, (torch.cuda.current_device(), os.getpid(), P2PExchange.last_decline_reason), group=pg)
+        dev_ids = [g_[0] for g_ in gathered]
+        p2p_reasons = [g_[2] for g_ in gathered]
     if rank == 0:
         P = mlp_macs([X_DIM, *HIDDEN, 2 * U_DIM])
         Q = mlp_macs([X_DIM + U_DIM, *HIDDEN, 1])
@@ -343,7 +526,9 @@ def main():
                                          if getattr(trainer, "p2p", None) is not None and hasattr(trainer.p2p, "timing_ms") else None),
                        "p2p_fused_exchange": bool(getattr(trainer.updater, "p2p_fused", False)) if getattr(trainer, "p2p", None) is not None else None,
                        "pg_backend": (None if pg is None else __import__("torch.distributed").distributed.get_backend(pg)),
-                       "pg_world_size": (None if pg is None else __import__("torch.distributed").distributed.get_world_size(pg))},
+                       "pg_world_size": (None if pg is None else __import__("torch.distributed").distributed.get_world_size(pg)),
+                       "rank_device_ids": dev_ids,
+                       "p2p_decline_reason": (None if getattr(trainer, "p2p", None) is not None or pg is None else p2p_reasons)},
             "sac_updates_per_s": GRAD_UPDATES * args.steps / dt,
             "sac_update_samples_per_s": world * BATCH * GRAD_UPDATES * args.steps / dt,
             "params_finite": finite,
@@ -357,6 +542,26 @@ def main():
                                "frac_of_fp32_mfma_peak": N_ENVS * S_STEPS * flop_per_transition / t_roll / 1e12 / FP32_MFMA_PEAK_TFLOPS},
         }
         log("kernel timings done")
+        if graph is not None:
+            # the contract's timed region is K steps (tens of ms); the same graph over >= 500 replays, device time
+            n_steady = max(500, args.steps)
+            out["steady_ms_per_step"] = _events_ms(graph.replay, n_steady)
+            out["steady_replays"] = n_steady
+            out["steady_transitions_per_s"] = world * N_ENVS * S_STEPS / (out["steady_ms_per_step"] * 1e-3)
+            log(f"steady state over {n_steady} replays: {out['steady_ms_per_step']:.4f} ms/step")
+        if world == 1 and pg is None and not args.no_extras:
+            del graph
+            trainer.close()
+            try:
+                out["ppo_c3"] = {"T40": ppo_c3_extra(device, 40), "T5": ppo_c3_extra(device, 5, steps=20)}
+                log(f"ppo_c3: T=40 {out['ppo_c3']['T40']['ms_per_step']:.2f} ms/step, T=5 {out['ppo_c3']['T5']['ms_per_step']:.2f} ms/step")
+            except Exception as e:      # noqa: BLE001 — an extra must never cost the headline line
+                out["ppo_c3"] = {"error": repr(e)}
+            try:
+                out["bptt_c5"] = bptt_c5_extra(device)
+                log(f"bptt_c5: {out['bptt_c5']['ms_per_train_step']:.2f} ms per train step")
+            except Exception as e:      # noqa: BLE001
+                out["bptt_c5"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
             log("cpu baseline done")

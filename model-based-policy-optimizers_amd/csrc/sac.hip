@@ -273,15 +273,15 @@ __global__ void __launch_bounds__(64 * SP * NCH) k_sac_fwd_bwd(SacArgs A) {
     const int tid = tid_;
     SAC_STAMP(0);
   }
-  // Clip check of the previous speculative optimizer step (k_sac_reduce_apply): the partial sums are requested now, next to the
-  // tile and log_alpha loads, and looked at after the section's barrier.
-  // Clip check of the previous speculative optimizer step.  Nothing here may WAIT for a load (a branch on these words at this
-  // point put a whole cold-miss latency in front of the tile loads: +2 us per launch), nothing may add work to a wave the other
-  // waves wait for, and nothing may live in registers across the phase loop (this kernel is short of scalar registers; every
-  // such value costs the lone waves spill code in every phase — measured 0.2-0.4 us each).  So: ONE scalar load of eight words
-  // here; after the first barrier they are folded into one flag — "a group's QUICK norm (float atomics of the reduce launch, any
-  // order) is within 1e-4 of max_norm or beyond": practically never.  Only then, behind the phases, are the canonical norms formed
-  // (fixed order: the clip decision and the clipped step are bit-identical to mbpo_sac_apply's).
+  // Clip check of the previous speculative optimizer step (k_sac_reduce_apply).  Nothing here may WAIT for a load (a branch on these
+  // words at this point put a whole cold-miss latency in front of the tile loads: +2 us per launch), nothing may add work to a wave
+  // the other waves wait for, and nothing may live in registers across the phase loop (this kernel is short of scalar registers;
+  // every such value costs the lone waves spill code in every phase — measured 0.2-0.4 us each).  So: ONE scalar load of eight
+  // words here (sequence numbers + the two slots of the quick verdict); after the first barrier they are folded into one flag —
+  // "some workgroup of the reduce launch found its sum of squares at or above limit / n_workgroups, or not finite, and raised the
+  // slot's word to +inf with a plain store" (group_sumsq): practically never at the reference's max_grad_norm = 1e5.  Only then,
+  // behind the phases, are the canonical norms formed (fixed order: the clip decision and the clipped step are bit-identical to
+  // mbpo_sac_apply's).
   // Warm the scalar cache with the whole kernel-argument block.  The phase loop fetches its operands lazily — the 64-byte chain
   // descriptor of each phase, network shapes, slab pointers — and every first touch of a kernarg line was a miss to memory
   // (the block is fresh for every launch): ~2 k cycles of "chain set-up" per phase, on every wave.  The LAST wave, which has no
@@ -639,6 +639,12 @@ struct SacReduceArgs {
   const float *slab_pi, *slab_q, *slab_ex;
   int n_tiles, P, Q2, B;
   float *grads, *metrics, *metrics_accum, *ss_part, *step_count;
+  // sequence words {issued, resolved} of the speculative two-launch steps (SacOptArgs::seq).  The reduce launch of EVERY step
+  // flavour records that whatever was pending before this step's fwd/bwd launch has been resolved by it (its prologue ran the
+  // check and the fix-up) — this launch overwrites ss_part, the operands of that check, so a later reader must not repeat it on
+  // the new step's partials (mbpo_sac_step -> mbpo_sac_grads + mbpo_sac_apply -> mbpo_sac_finalize).  Written by the
+  // launch AFTER the fwd/bwd launch, never from inside it: late-starting workgroups read these words at their top.
+  unsigned int *seq;
 };
 
 // sum-of-squares partials per workgroup and optimizer group (0 policy, 1 critics, 2 alpha), fixed order
@@ -668,13 +674,17 @@ __device__ __forceinline__ void group_sumsq(float g, int i, int P, int Q2, int N
     float tot = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) tot += s_ss[k][0] + s_ss[k][1] + s_ss[k][2] + s_ss[k][3];
-    if (!(tot < blk_lim)) quick[0] = 3.0e38f;
+    // +inf, not a large finite number: with max_grad_norm so large that the limits overflow to +inf (clipping "disabled") a
+    // non-finite gradient must still fail the reader's `word < limit` (inf < inf is false), as the three-launch path's
+    // canonical check does
+    if (!(tot < blk_lim)) quick[0] = __builtin_inff();
   }
 }
 
 __global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
   const int NP = A.P + A.Q2 + 1;
   const int i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned int seq_issued = (i == NP - 1) ? A.seq[0] : 0u;      // requested beside the slab sums
   float g = 0.f;
   if (i < A.P) {
     g = slab_sum<16>(A.slab_pi, A.P, A.n_tiles, i);
@@ -690,6 +700,7 @@ __global__ void __launch_bounds__(256) k_sac_reduce(SacReduceArgs A) {
     const float m0 = 0.5f * ce * (0.5f * invB), m1 = ac * invB, m2 = al * invB;   // critic_loss = 0.5 * mean over [B,2]
     A.metrics[0] = m0;
     A.metrics[1] = m1;
+    A.seq[1] = seq_issued;       // nothing is pending any more: this step is not speculative
     A.metrics[2] = m2;
     if (A.metrics_accum) {       // (no load of what was just stored: each such round trip is part of the launch's tail)
       const float a0 = A.metrics_accum[0], a1 = A.metrics_accum[1], a2 = A.metrics_accum[2], a4 = A.metrics_accum[4];
@@ -708,6 +719,7 @@ __global__ void __launch_bounds__(256) k_sac_reduce_push(SacReduceArgs A, P2pDev
   const int NP = A.P + A.Q2 + 1;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const unsigned epoch = X.epoch[0];
+  const unsigned int seq_issued = (i == NP - 1) ? A.seq[0] : 0u;      // requested beside the slab sums
   float g = 0.f;
   if (i < A.P) {
     g = slab_sum<16>(A.slab_pi, A.P, A.n_tiles, i);
@@ -723,6 +735,7 @@ __global__ void __launch_bounds__(256) k_sac_reduce_push(SacReduceArgs A, P2pDev
     const float m0 = 0.5f * ce * (0.5f * invB), m1 = ac * invB, m2 = al * invB;
     A.metrics[0] = m0;
     A.metrics[1] = m1;
+    A.seq[1] = seq_issued;       // nothing is pending any more: this step is not speculative
     A.metrics[2] = m2;
     if (A.metrics_accum) {       // (no load of what was just stored: each such round trip is part of the launch's tail)
       const float a0 = A.metrics_accum[0], a1 = A.metrics_accum[1], a2 = A.metrics_accum[2], a4 = A.metrics_accum[4];
@@ -757,6 +770,7 @@ __global__ void __launch_bounds__(256) k_sac_reduce_exchange(SacReduceArgs A, P2
   const int NP = A.P + A.Q2 + 1;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const unsigned epoch = X.epoch[0], want = X.epoch[1];
+  const unsigned int seq_issued = (i == NP - 1) ? A.seq[0] : 0u;      // requested beside the slab sums
   float g = 0.f;
   if (i < A.P) {
     g = slab_sum<16>(A.slab_pi, A.P, A.n_tiles, i);
@@ -771,6 +785,7 @@ __global__ void __launch_bounds__(256) k_sac_reduce_exchange(SacReduceArgs A, P2
     const float m0 = 0.5f * ce * (0.5f * invB), m1 = ac * invB, m2 = al * invB;
     A.metrics[0] = m0;
     A.metrics[1] = m1;
+    A.seq[1] = seq_issued;       // nothing is pending any more: this step is not speculative
     A.metrics[2] = m2;
     if (A.metrics_accum) {       // (no load of what was just stored: each such round trip is part of the launch's tail)
       const float a0 = A.metrics_accum[0], a1 = A.metrics_accum[1], a2 = A.metrics_accum[2], a4 = A.metrics_accum[4];
@@ -905,7 +920,8 @@ __global__ void __launch_bounds__(256) k_sac_reduce_apply(SacReduceArgs A, SacOp
     }
     O.undo_count[0] = count;
     O.undo_count[1] = acc3;          // metrics_accum[3] before this step adds its 'alpha' (0 without running sums)
-    O.seq[0] = seq0 + 1u;            // one more speculative step whose clip check is pending
+    O.seq[1] = seq0;                 // everything before this step was resolved by this step's fwd/bwd launch ...
+    O.seq[0] = seq0 + 1u;            // ... and this one speculative step is pending now
   }
   if (EXCHANGE) {
     p2p_push(X, epoch, i, NP, g);
@@ -1265,6 +1281,7 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
   R.slab_pi = A.slab_pi; R.slab_q = A.slab_q; R.slab_ex = A.slab_ex;
   R.n_tiles = pl.n_tiles; R.P = pl.P; R.Q2 = 2 * pl.Q; R.B = d->batch_size;
   R.grads = d->grads; R.metrics = d->metrics; R.metrics_accum = d->metrics_accum; R.ss_part = d->workspace + pl.off_ss; R.step_count = d->step_count;
+  R.seq = A.opt.seq;
   if (apply_in_reduce) {
     if (xd) hipLaunchKernelGGL(k_sac_reduce_apply<true>, dim3(pl.n_red), dim3(256), 0, st, R, A.opt, X);
     else hipLaunchKernelGGL(k_sac_reduce_apply<false>, dim3(pl.n_red), dim3(256), 0, st, R, A.opt, X);

@@ -363,11 +363,16 @@ def replay_insert(data: torch.Tensor, state: torch.Tensor, rows: torch.Tensor) -
                                  rows.shape[0], current_stream_ptr()), "mbpo_replay_insert")
 
 
-def replay_gather(data: torch.Tensor, state: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+def replay_gather(data: torch.Tensor, state: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """jnp.take(data_logical, idx, axis=0, mode='wrap')."""
     lib = load()
     _req(data, "data"); _req(state, "state", torch.int32); _req(idx, "idx", torch.int32)
-    out = torch.empty((idx.numel(), data.shape[1]), device=data.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((idx.numel(), data.shape[1]), device=data.device, dtype=torch.float32)
+    else:
+        _req(out, "out")
+        if out.numel() != idx.numel() * data.shape[1]:
+            raise ValueError(f"out must hold {idx.numel()} rows of {data.shape[1]} floats")
     check(lib.mbpo_replay_gather(data.data_ptr(), data.shape[0], data.shape[1], state.data_ptr(), idx.data_ptr(),
                                  idx.numel(), out.data_ptr(), current_stream_ptr()), "mbpo_replay_gather")
     return out

@@ -86,7 +86,8 @@ class PPO:
                  critic_hidden_layer_sizes: Sequence[int] = (64, 64, 64),
                  critic_activation: str = "swish",
                  wandb_logging: bool = False,
-                 # --- MI355X-side knob (not in the reference) ---
+                 # --- MI355X-side knobs (not in the reference) ---
+                 use_graph: bool = True,
                  process_group=None,
                  ):
         if wandb_logging:
@@ -149,6 +150,10 @@ class PPO:
         self._perm = torch.zeros(n_traj, dtype=torch.int32, device=self.device)
         self._perm_ws = torch.zeros(n_traj, dtype=torch.int32, device=self.device)
         self._rng = ops.make_rng(self.device)       # device uint64[2]: {epoch key, training-step index}
+        self.use_graph = use_graph
+        self._graph = None
+        self._graph_key = None
+        self._graph_refs = None
 
     # ------------------------------------------------------------------------------------------------ policy / state
     def _norm(self, normalizer_params: RunningStatisticsState):
@@ -211,8 +216,8 @@ class PPO:
                                       workspace=self._perm_ws)
         # every leaf is permuted with the SAME key (ppo.py:166-169) == one row gather of whole trajectories
         flat = data.reshape(n, -1)
-        shuffled = ops.replay_gather(flat, self._ring_state, perm).reshape(self.num_minibatches, self.batch_size,
-                                                                            self.unroll_length, self.row_len)
+        shuffled = ops.replay_gather(flat, self._ring_state, perm, out=self._shuffled).reshape(
+            self.num_minibatches, self.batch_size, self.unroll_length, self.row_len)
         for m in range(self.num_minibatches):
             self.minibatch_step(shuffled[m], normalizer_params, e=e, m=m)
 
@@ -248,11 +253,30 @@ class PPO:
         return training_state, state, new_key
 
     def training_epoch(self, training_state: TrainingState, state: State, key: int):
-        """ppo.py:235-247."""
+        """ppo.py:235-247.  The reference compiles the whole epoch scan into ONE XLA computation; here a training_step — K rollouts,
+        3 statistics launches, E x (permutation, gather, M x minibatch_step) and the RNG advance, ~1.3 k launches at C3 — is captured
+        once into a hipGraph and replayed (every launch reads its counters / RNG words from device memory, so a replayed step is bit
+        for bit the eagerly issued one: tests/test_gpu_trainer_parity.py).  First step of an epoch eager, as in SAC.training_epoch."""
         self.updater.metrics_accum.zero_()
         self.rekey(key)
-        for _ in range(self.num_training_steps_per_epoch):
+        n = self.num_training_steps_per_epoch
+        done_steps = 0
+        if self.use_graph and n >= 3 and self._capturable():
             training_state, state, _ = self.training_step(training_state, state)
+            gkey, refs = self._graph_signature(state)
+            if self._graph is None or self._graph_key != gkey:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self.training_step(training_state, state)
+                self._graph, self._graph_key, self._graph_refs = graph, gkey, refs
+            for _ in range(n - 1):
+                self._graph.replay()
+            training_state = training_state.replace(env_steps=training_state.env_steps + (n - 1) * self.env_step_per_training_step)
+            done_steps = n
+        while done_steps < n:
+            training_state, state, _ = self.training_step(training_state, state)
+            done_steps += 1
         acc = self.updater.metrics_accum.cpu()
         if self.p2p is not None and self.p2p.status() != 0:
             raise _hip.MbpoHipError("PPO: the peer-memory gradient exchange timed out on this rank; "
@@ -261,6 +285,25 @@ class PPO:
         metrics = {'total_loss': float(acc[0]) / cnt, 'policy_loss': float(acc[1]) / cnt, 'v_loss': float(acc[2]) / cnt,
                    'entropy_loss': float(acc[3]) / cnt}
         return training_state, state, metrics
+
+    def _capturable(self) -> bool:
+        """As SAC._capturable: plain kernels only — single rank, the peer-memory exchange, or RCCL collectives (stream-ordered
+        kernels); never a host-side (gloo) collective, never a user-defined System (user code runs between the kernels)."""
+        if not self.env.system.fused:
+            return False
+        if self.dp.group is None or self.p2p is not None:
+            return True
+        import os
+        import torch.distributed as dist
+        return dist.get_backend(self.dp.group) == "nccl" and os.environ.get("MBPO_GRAPH_NCCL", "1") != "0"
+
+    def _graph_signature(self, state: State):
+        """Every device address a captured training_step bakes in; the tensors are kept alive with the graph."""
+        spec = self.env.system.rollout_spec(state.system_params, self.device)
+        tensors = [state.obs, state.info['first_obs'], state.info['steps'], state.done, self._data, self._shuffled, self._stats_vec,
+                   self._rng, self._perm, self._perm_ws]
+        tensors += [v for v in spec.values() if isinstance(v, torch.Tensor)]
+        return tuple(t.data_ptr() for t in tensors), tensors
 
     def training_epoch_with_timing(self, training_state, env_state, key):
         """ppo.py:249-263."""
@@ -299,6 +342,7 @@ class PPO:
         return self._snapshot(training_state), all_metrics
 
     def close(self) -> None:
+        self._graph = self._graph_key = self._graph_refs = None
         if self.p2p is not None:
             self.p2p.close()
             self.p2p = None

@@ -507,18 +507,11 @@ def _advance_mirror(q: UniformSamplingQueue, bs: ReplayBufferState, n: int) -> R
 
 def policy_act(policy_params: torch.Tensor, policy_spec: ops.MlpSpec, obs: torch.Tensor, norm_mean, norm_std,
                deterministic: bool, key: int) -> torch.Tensor:
-    """Policy inference for `act` (sac_networks.py:63-69): one MLP forward + NormalTanh mode/sample.
-    The MLP runs in mbpo_ensemble_mlp_forward; the distribution head is a few elementwise device ops (not a hot path)."""
-    x = obs if norm_mean is None else ((obs - norm_mean) / norm_std).contiguous()
-    logits = ops.ensemble_mlp_forward(policy_params, policy_spec, x)[0]
-    u = logits.shape[-1] // 2
-    loc, raw = logits[:, :u], logits[:, u:]
-    if deterministic:
-        return torch.tanh(loc)
-    scale = torch.nn.functional.softplus(raw) + 0.001
-    gen = torch.Generator(device=obs.device).manual_seed(int(key) % (2 ** 63))
-    eps = torch.randn(loc.shape, device=obs.device, generator=gen)
-    return torch.tanh(loc + scale * eps)
+    """Policy inference for `act` (sac_networks.py:58-73 / ppo_network.py:59-84): normalise -> MLP -> NormalTanh mode / sample, ONE
+    launch of mbpo_policy_act — the kernel and Philox stream the trainers' rollouts use (stream POLICY_NOISE, seed = the key split
+    off for this call, element = row * u + column), so inference and training sample one and the same distribution code."""
+    return ops.policy_act(policy_params, policy_spec, obs, norm_mean, norm_std, deterministic=deterministic,
+                          seed=K.PRNGKey(key), offset=0)
 
 
 class Evaluator:

@@ -86,6 +86,9 @@ class P2PExchange:
     MBPO_P2P_ALLREDUCE=0, or when the self-check — one exchange of a rank-dependent vector compared with
     torch.distributed.all_reduce — does not reproduce the library's result on every rank."""
 
+    # why the most recent create() returned None on this rank (bench.py prints it; None after a successful create)
+    last_decline_reason: Optional[str] = None
+
     def __init__(self, dp: "DataParallel", n_max: int, device: torch.device):
         from mbpo import _hip
         self.lib = _hip.load()
@@ -99,9 +102,15 @@ class P2PExchange:
     def create(cls, dp: "DataParallel", n_max: int, device) -> Optional["P2PExchange"]:
         """Collective over dp.group.  Every step that can fail locally is followed by an agreement (MIN all-reduce of an ok
         flag) before the next collective, so one rank's failure turns into `None` on every rank instead of a deadlock."""
-        if dp.group is None or dp.world_size < 2 or os.environ.get("MBPO_P2P_ALLREDUCE", "1") == "0":
+        cls.last_decline_reason = None
+        if dp.group is None or dp.world_size < 2:
+            cls.last_decline_reason = "single rank: nothing to exchange"
+            return None
+        if os.environ.get("MBPO_P2P_ALLREDUCE", "1") == "0":
+            cls.last_decline_reason = "disabled by MBPO_P2P_ALLREDUCE=0"
             return None
         if not torch.cuda.is_available():       # no device, no peer memory: the (gloo) collective stays
+            cls.last_decline_reason = "no GPU visible"
             return None
         import torch.distributed as dist
         device = torch.device(device)
@@ -119,6 +128,7 @@ class P2PExchange:
         except Exception as e:      # noqa: BLE001 — any failure means: use the library collective
             ex._err = repr(e)
         if not agree(handle is not None):
+            cls.last_decline_reason = f"region allocation / IPC handle failed on some rank (this rank: {getattr(ex, '_err', 'ok')})"
             ex.close()
             return None
         # 2. exchange the handles (collective), map the peers (local)
@@ -132,11 +142,17 @@ class P2PExchange:
             ok = False
             ex._err = repr(e)
         if not agree(ok):
+            cls.last_decline_reason = f"mapping a peer's region failed on some rank (this rank: {getattr(ex, '_err', 'ok')})"
             ex.close()
             return None
         # 3. three exchanges against the library all-reduce, then — only if EVERY rank passed them — the timing of both
         #    (the timing stage contains collectives of its own: it must not start on some ranks only)
         if not run_agreed_stages([ex._check_correctness, ex._check_timing], agree):
+            tm = getattr(ex, "timing_ms", None)
+            cls.last_decline_reason = (
+                f"start-up check failed on some rank (this rank: status {ex._safe_status()}, "
+                + (f"exchange {tm[0]:.3f} ms vs library all-reduce {tm[1]:.3f} ms" if tm else "correctness stage")
+                + f", error {getattr(ex, '_err', None)})")
             ex.close()
             return None
         return ex
@@ -180,6 +196,12 @@ class P2PExchange:
         self._hip.check(self.lib.mbpo_p2p_status(C.byref(self.desc), C.byref(v)), "mbpo_p2p_status")
         return int(v.value)
 
+    def _safe_status(self):
+        try:
+            return self.status()
+        except Exception:      # noqa: BLE001
+            return "unreadable"
+
     def _check_correctness(self) -> bool:
         import torch.distributed as dist
         n = min(self.n_max, 4099)
@@ -209,6 +231,20 @@ class P2PExchange:
         y = torch.zeros(n, device=self.device)
         reps = 10
 
+        local_ok = [True]
+
+        def guarded_exchange():
+            # only the peer exchange may fail on one rank alone (HIP error, bad status): it is recorded, never raised — the
+            # library collectives of this stage (the barriers, the all-reduce loop) are issued by EVERY rank whatever happened,
+            # so a local failure cannot leave the peers in mismatched collectives
+            try:
+                if os.environ.get("MBPO_P2P_TEST_RAISE_TIMING_RANK") == str(self.dp.rank):     # test hook
+                    raise RuntimeError("forced failure of the peer exchange in the timing stage")
+                self.all_reduce_sum(x)
+            except Exception as e:      # noqa: BLE001
+                local_ok[0] = False
+                self._err = repr(e)
+
         def timed(fn):
             fn()
             dist.barrier(group=self.dp.group)
@@ -221,10 +257,10 @@ class P2PExchange:
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
 
-        t_p2p = timed(lambda: self.all_reduce_sum(x))
+        t_p2p = timed(guarded_exchange)
         t_lib = timed(lambda: dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.dp.group))
         self.timing_ms = (t_p2p, t_lib)
-        return self.status() == 0 and t_p2p <= 4.0 * t_lib + 0.05
+        return local_ok[0] and self.status() == 0 and t_p2p <= 4.0 * t_lib + 0.05
 
     def close(self):
         for p in self.peers.values():

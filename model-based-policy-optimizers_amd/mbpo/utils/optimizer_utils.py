@@ -40,10 +40,27 @@ def rollout_actions(system: System, system_params: SystemParams, init_state: tor
     acts = actions.reshape(horizon, -1, U).to(dev, torch.float32)
     if acts.shape[1] != N:
         raise ValueError(f"actions must be [H,u] or [H,{N},u]")
+    spec = system.rollout_spec(system_params, dev)
+    if spec["system_kind"] == _hip.SYS_GENERIC:
+        # a user-defined System: the reference's scan (:31-47) is a plain loop over System.step — it ignores SystemState.done (no
+        # Episode / AutoReset bookkeeping on this path: a terminating System keeps propagating x_next) and carries system_params
+        sp, o, r, n = system_params, [], [], []
+        for h in range(horizon):
+            out = system.step(x=obs, u=acts[h].contiguous(), system_params=sp)
+            o.append(obs)
+            r.append(torch.as_tensor(out.reward, device=dev, dtype=torch.float32).reshape(-1).expand(N))
+            n.append(out.x_next.reshape(-1, X).to(torch.float32))
+            obs, sp = n[-1], out.system_params
+        rew = torch.stack(r)
+        tr = Transition(observation=torch.stack(o), action=acts, reward=rew, discount=torch.ones_like(rew), next_observation=torch.stack(n))
+        if single:
+            tr = Transition(observation=tr.observation[:, 0], action=tr.action[:, 0], reward=tr.reward[:, 0], discount=tr.discount[:, 0],
+                            next_observation=tr.next_observation[:, 0])
+        return tr
+    # fused systems (Pendulum, learned ensemble) never report done and the episode never ends: one launch for all steps
     z = torch.zeros(N, device=dev)
     rows = ops.model_rollout(x_dim=X, u_dim=U, actions=acts.contiguous(), obs=obs, first_obs=obs.clone(), steps=z, done=z.clone(),
-                             n_steps=horizon, episode_length=2 ** 30, seed=system_params.key,
-                             **system.rollout_spec(system_params, dev))
+                             n_steps=horizon, episode_length=2 ** 30, seed=system_params.key, **spec)
     return _transition_from_rows(rows, X, U, horizon, N, single)
 
 

@@ -314,7 +314,9 @@ def _trainer_dp_worker(rank, world, port, tmpdir, fail_rank):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if fail_rank >= 0:
+    if fail_rank >= 100:          # the peer exchange RAISES on that rank inside the timing stage: still no deadlock
+        os.environ["MBPO_P2P_TEST_RAISE_TIMING_RANK"] = str(fail_rank - 100)
+    elif fail_rank >= 0:
         os.environ["MBPO_P2P_TEST_FAIL_RANK"] = str(fail_rank)
     else:
         os.environ["MBPO_P2P_ALLREDUCE"] = "0"                    # library collective: the eager, uncaptured path
@@ -324,6 +326,8 @@ def _trainer_dp_worker(rank, world, port, tmpdir, fail_rank):
     try:
         tr, env = _trainer_setup(dev, dist.group.WORLD)
         assert tr.p2p is None                                      # declined (forced failure) or switched off — on every rank
+        from mbpo.parallel import P2PExchange
+        assert P2PExchange.last_decline_reason                     # and every rank can say why (bench.py prints it)
         assert not tr._capturable()
         ts, es, bs, m = _run_epoch(tr, env)
         assert tr._graph is None                                   # never captured with a host-side collective inside
@@ -342,9 +346,9 @@ def _trainer_dp_worker(rank, world, port, tmpdir, fail_rank):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("fail_rank", [-1, 1])
+@pytest.mark.parametrize("fail_rank", [-1, 1, 101])
 def test_sac_trainer_two_ranks_rank_keys_and_guarded_capture(tmp_path, fail_rank):
     world = 2
-    port = 41500 + (os.getpid() % 2000) + (11 if fail_rank >= 0 else 0)
+    port = 41500 + (os.getpid() % 2000) + (11 if fail_rank >= 0 else 0) + (7 if fail_rank >= 100 else 0)
     mp.spawn(_trainer_dp_worker, args=(world, port, str(tmp_path), fail_rank), nprocs=world, join=True)
     assert all((tmp_path / f"dp_ok{r}").exists() for r in range(world))

@@ -189,3 +189,73 @@ def test_policy_act_matches_oracle_and_bad_shapes(dev):
     torch.testing.assert_close(mode.cpu(), torch.tanh(logits[:, :3]).clamp(-0.5, 0.5), atol=2e-5, rtol=2e-5)
     with pytest.raises(ValueError):
         ops.policy_act(ppar2.to(dev), ops.MlpSpec(pd2), obs0[:, :2].contiguous().to(dev))
+
+
+def test_rollout_actions_ignores_done_of_a_terminating_system(dev):
+    """the reference's rollout_actions (utils/optimizer_utils.py:12-59) is a plain scan of System.step — it ignores
+    SystemState.done and carries system_params; no Episode / AutoReset bookkeeping.  A user System that reports done mid-rollout
+    must keep propagating x_next (compared with a plain step loop of the oracle's Pendulum)."""
+    from mbpo.utils.optimizer_utils import rollout_actions
+    user = _user_pendulum()(fall_done=True)
+    sp = user.init_params(0)
+    H, N = 25, 9
+    g = torch.Generator().manual_seed(5)
+    actions = torch.rand(H, N, 1, generator=g) * 2 - 1
+    th = torch.linspace(0.5, 3.0, N)
+    x0 = torch.stack([torch.cos(th), torch.sin(th), torch.linspace(-2.5, 2.5, N)], 1)
+    tr = rollout_actions(user, sp, x0.to(dev), actions.to(dev), H)
+    assert user.calls == H
+    ref = osys.PendulumSystem()
+    x, nxt, rew, fell = x0, [], [], 0
+    for t in range(H):
+        xn, r = ref.step(x, actions[t])
+        fell += int((xn[:, 2].abs() > 3.0).sum())
+        nxt.append(xn); rew.append(r); x = xn
+    assert fell > 0                                              # the System did report done along the way
+    torch.testing.assert_close(tr.next_observation.cpu(), torch.stack(nxt), atol=2e-4, rtol=2e-4)
+    torch.testing.assert_close(tr.reward.cpu(), torch.stack(rew), atol=5e-4, rtol=2e-4)
+    assert torch.equal(tr.observation[1:], tr.next_observation[:-1]) and torch.equal(tr.observation[0].cpu(), x0)
+    assert torch.equal(tr.discount.cpu(), torch.ones(H, N))
+
+
+def test_optimizer_act_runs_the_trainers_policy_head(dev):
+    """SACOptimizer.act / PPOOptimizer.act (brax_optimizers.py:74-83, sac_networks.py:58-73) go through
+    mbpo_policy_act — the normalise -> chain -> NormalTanh kernel and Philox stream of the training rollouts — not a torch
+    restatement with a torch.Generator.  mode (evaluate=True) and sample (evaluate=False) against oracle/nets.py with the Philox
+    noise the call's key selects; the key is split exactly once per call (:81-83)."""
+    from mbpo.optimizers import PPOOptimizer, SACOptimizer
+    from mbpo.replay import UniformSamplingQueue
+    from mbpo.systems import PendulumSystem
+    from mbpo.types import Transition
+    from mbpo.utils import keys as K
+    system = PendulumSystem()
+    s0 = system.reset()
+    dummy = Transition(observation=s0.x_next, action=torch.zeros(1, device=dev), reward=s0.reward, discount=torch.tensor(0.99, device=dev),
+                       next_observation=s0.x_next)
+    buf = UniformSamplingQueue(10, dummy, 1, device=dev)
+    for cls, kw in ((SACOptimizer, dict(num_timesteps=1000, episode_length=20, num_envs=4, batch_size=16, normalize_observations=True,
+                                        policy_hidden_layer_sizes=(64, 64), critic_hidden_layer_sizes=(64, 64))),
+                    (PPOOptimizer, dict(num_timesteps=1000, episode_length=20, num_envs=4, batch_size=4, num_minibatches=1,
+                                        unroll_length=5, normalize_observations=True, policy_hidden_layer_sizes=(32, 32),
+                                        critic_hidden_layer_sizes=(32, 32)))):
+        opt = cls(system=system, true_buffer=buf, **kw)
+        st = opt.init(key=7)
+        norm, pol = st.policy_params
+        # a non-trivial normaliser so that the normalise step is exercised
+        norm.vec[1:4] = torch.tensor([0.1, -0.2, 0.3], device=dev)
+        norm.vec[7:10] = torch.tensor([0.7, 1.3, 2.0], device=dev)
+        tr = opt.dummy_trainer
+        dims = tr.policy_dims
+        g = torch.Generator().manual_seed(3)
+        obs = torch.randn(33, 3, generator=g)
+        logits = onets.mlp_forward(pol.cpu(), dims, onets.normalize(obs, norm.mean.cpu(), norm.std.cpu()))
+        a_mode, st1 = opt.act(obs.to(dev), st, evaluate=True)
+        torch.testing.assert_close(a_mode.cpu(), onets.mode(logits), atol=2e-5, rtol=2e-5)
+        key, subkey = K.split(st.key)
+        assert st1.key == key
+        a_smp, st2 = opt.act(obs.to(dev), st, evaluate=False)
+        eps = torch.from_numpy(philox.philox_normal(K.PRNGKey(subkey), 0, philox.STREAM_POLICY_NOISE, np.arange(33, dtype=np.uint64))).reshape(33, 1)
+        torch.testing.assert_close(a_smp.cpu(), onets.postprocess(onets.sample_no_postprocessing(logits, eps)), atol=5e-5, rtol=5e-5)
+        # a single observation [x] gives a single action [u], the same numbers as row 0 of the batch of one
+        a1, _ = opt.act(obs[0].to(dev), st, evaluate=True)
+        assert a1.shape == (1,) and torch.allclose(a1.cpu(), onets.mode(logits)[0], atol=2e-5)

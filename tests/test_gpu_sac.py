@@ -227,6 +227,54 @@ def test_two_launch_step_matches_three_launch_path(dev, max_norm, mode):
     torch.testing.assert_close(a.metrics_accum, b.metrics_accum, atol=0, rtol=0)
 
 
+@pytest.mark.parametrize("max_norm", [0.05, 0.4, float("inf")])
+def test_mixed_two_and_three_launch_steps_on_one_state(dev, max_norm):
+    """the header allows mbpo_sac_step -> mbpo_sac_grads + mbpo_sac_apply -> ... -> mbpo_sac_finalize on ONE
+    state without a finalize in between.  The three-launch step's fwd/bwd prologue resolves the pending speculative step; its
+    reduce launch must RECORD that (seq[1] = seq[0]) because it overwrites the clip-norm partials — otherwise the final finalize
+    repeats the old step's check on the new step's partials and reverts parameters from a stale undo log.  Compared bit for bit
+    with the pure three-launch path; max_norm 0.05 clips every step, 0.4 some, inf none (and inf makes the quick-check limits
+    overflow: the flag must be +inf for a non-finite gradient to fail `flag < limit`)."""
+    from mbpo import ops, _hip
+    import ctypes as C
+    X, U, B = 4, 1, 256
+    g = torch.Generator().manual_seed(11)
+    mk = lambda two: ops.SacUpdater(x_dim=X, u_dim=U, policy_dims=[X, 64, 64, 64, 2 * U], q_dims=[X + U, 64, 64, 64, 1], batch_size=B,
+                                    device=dev, seed=5, max_grad_norm=max_norm, lr_policy=1e-3, lr_q=1e-3, lr_alpha=1e-3, two_launch=two)
+    mixed, ref = mk(True), mk(False)
+    init = torch.randn(ref.NP, generator=g) * 0.1
+    for up in (mixed, ref):
+        up.load_state(init.to(dev))
+    D = 2 * X + U + 3
+    # flavour per step on the mixed updater: T = two-launch deferred, 3 = grads + apply through the raw entry points (no finalize)
+    plan = "T3T33TT3"
+    for it, kind in enumerate(plan):
+        batch = torch.randn(B, D, generator=g).to(dev)
+        if max_norm == float("inf") and it == 4:
+            batch[0, 0] = float("inf")          # an overflowing gradient: clip_by_global_norm gives g/inf*inf = NaN on both paths
+        batch[:, -1] = (torch.rand(B, generator=g) < 0.1).float().to(dev)
+        ref.sgd_step(batch, offset=it)
+        if kind == "T":
+            mixed.sgd_step(batch, offset=it, defer_clip_check=True)
+        else:
+            d = mixed.desc
+            d.batch, d.offset = batch.data_ptr(), it
+            d.norm_mean = d.norm_std = d.noise_alpha = d.noise_critic = d.noise_actor = None
+            st = _hip.current_stream_ptr()
+            _hip.check(mixed.lib.mbpo_sac_grads(C.byref(d), st), "mbpo_sac_grads")
+            _hip.check(mixed.lib.mbpo_sac_apply(C.byref(d), st), "mbpo_sac_apply")
+    mixed.finalize()
+    torch.cuda.synchronize()
+    assert float(mixed.step_count) == float(ref.step_count) == len(plan)
+    for name in ("params", "target_q", "adam_m", "adam_v", "grads"):
+        a, b = getattr(mixed, name), getattr(ref, name)
+        assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0)), name
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), name
+    if max_norm != float("inf"):
+        assert bool(torch.isfinite(ref.params).all())
+        assert mixed.clip_events() == ref.clip_events()
+
+
 @pytest.mark.parametrize("U", [2, 1])        # u = 1: the forward-mode actor / thin-layer kernel variant
 def test_sac_non_equidistant_time_target(dev, U):
     """N1 (sac/losses.py:90-98): the critic target's discount is exp(-continuous_discounting * t) per sample, t decoded from the

@@ -272,6 +272,41 @@ def test_ppo_training_step_matches_cpu_oracle(dev, kind):
     assert ts.env_steps == 3 * tr.env_step_per_training_step
 
 
+@pytest.mark.parametrize("kind", ["pendulum", "ensemble"])
+def test_ppo_training_epoch_graph_equals_eager(dev, kind):
+    """PPO.training_epoch through the captured hipGraph (the reference compiles the epoch scan into one XLA computation,
+    ppo/ppo.py:235-247) == the same epoch issued eagerly, bit for bit: parameters, moments, step count, env state, statistics, the
+    last collected batch, the last permutation, the RNG words and the epoch's metrics."""
+    from mbpo.optimizers.policy_optimizers.ppo.ppo import PPO
+    from mbpo.systems.brax_wrapper import BraxWrapper
+    out = {}
+    for use_graph in (False, True):
+        system, sp, osystem, X, U = _make_system(dev, kind)
+        tb, tbs = _true_buffer(dev, X, U, 256)
+        env = BraxWrapper(system, sp, tbs, tb)
+        tr = PPO(environment=env, num_timesteps=5 * 16 * 8 * 4, use_graph=use_graph, **PPO_KW)
+        assert tr.num_training_steps_per_epoch == 5
+        ts = tr.init_training_state(5)
+        es = env.reset([101 + i for i in range(PPO_KW["num_envs"])])
+        metrics = None
+        for key in (19, 31):                   # the second epoch re-uses the captured graph (same addresses)
+            ts, es, metrics = tr.training_epoch(ts, es, key)
+        torch.cuda.synchronize()
+        assert (tr._graph is not None) == use_graph
+        assert ts.env_steps == 10 * tr.env_step_per_training_step
+        u = tr.updater
+        out[use_graph] = dict(params=u.params.clone(), m=u.adam_m.clone(), v=u.adam_v.clone(), count=u.step_count.clone(),
+                              obs=es.obs.clone(), steps=es.info["steps"].clone(), done=es.done.clone(), stats=tr._stats_vec.clone(),
+                              data=tr._data.clone(), perm=tr._perm.clone(), rng=tr._rng.clone(), metrics=metrics)
+        tr.close()
+    for name, eager in out[False].items():
+        if name == "metrics":
+            assert eager == out[True][name]
+        else:
+            assert torch.equal(eager, out[True][name]), name
+    assert float(out[True]["count"]) == 10 * 8
+
+
 def test_philox_permutation_bit_exact(dev):
     from mbpo import ops
     for n, seed, off in ((1, 3, 0), (64, 5, 7), (1000, 2 ** 40 + 3, (1024 << 32) + 9), (16384, 11, 1 << 33)):
