@@ -354,7 +354,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # rehearsal only (one-GPU box): MBPO_BENCH_SHARE_GPU=1 puts every rank on cuda:0, MBPO_BENCH_BACKEND=gloo replaces RCCL
     share_gpu = os.environ.get("MBPO_BENCH_SHARE_GPU") == "1"
-    backend = os.environ.get("MBPO_BENCH_BACKEND", "nccl")
+    # (RCCL refuses two ranks on one device — "Duplicate GPU detected" — so the shared-GPU rehearsal defaults to gloo)
+    backend = os.environ.get("MBPO_BENCH_BACKEND", "gloo" if share_gpu else "nccl")
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -466,6 +467,19 @@ def main():
             trainer, ts, env_state, buffer_state, graph, dt = measure()
 
     log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
+    # the contract's timed region is K steps (tens of ms); the same graph over >= 500 replays, device time — EVERY rank replays
+    # (the captured step holds the gradient exchange), the slowest rank's figure is reported
+    steady_ms, n_steady = None, max(500, args.steps)
+    if graph is not None:
+        if pg is not None:
+            import torch.distributed as dist
+            dist.barrier()
+        steady_ms = _events_ms(graph.replay, n_steady)
+        if pg is not None:
+            t = torch.tensor([steady_ms], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            steady_ms = float(t)
+        log(f"steady state over {n_steady} replays: {steady_ms:.4f} ms/step")
     finite = bool(torch.isfinite(trainer.updater.params).all())
     # which device every rank sits on, and — if the peer exchange was declined — why (for whoever reads an 8-GPU run's line)
     from mbpo.parallel import P2PExchange
@@ -542,13 +556,10 @@ def main():
                                "frac_of_fp32_mfma_peak": N_ENVS * S_STEPS * flop_per_transition / t_roll / 1e12 / FP32_MFMA_PEAK_TFLOPS},
         }
         log("kernel timings done")
-        if graph is not None:
-            # the contract's timed region is K steps (tens of ms); the same graph over >= 500 replays, device time
-            n_steady = max(500, args.steps)
-            out["steady_ms_per_step"] = _events_ms(graph.replay, n_steady)
+        if steady_ms is not None:
+            out["steady_ms_per_step"] = steady_ms
             out["steady_replays"] = n_steady
-            out["steady_transitions_per_s"] = world * N_ENVS * S_STEPS / (out["steady_ms_per_step"] * 1e-3)
-            log(f"steady state over {n_steady} replays: {out['steady_ms_per_step']:.4f} ms/step")
+            out["steady_transitions_per_s"] = world * N_ENVS * S_STEPS / (steady_ms * 1e-3)
         if world == 1 and pg is None and not args.no_extras:
             del graph
             trainer.close()

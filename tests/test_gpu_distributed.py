@@ -352,3 +352,30 @@ def test_sac_trainer_two_ranks_rank_keys_and_guarded_capture(tmp_path, fail_rank
     port = 41500 + (os.getpid() % 2000) + (11 if fail_rank >= 0 else 0) + (7 if fail_rank >= 100 else 0)
     mp.spawn(_trainer_dp_worker, args=(world, port, str(tmp_path), fail_rank), nprocs=world, join=True)
     assert all((tmp_path / f"dp_ok{r}").exists() for r in range(world))
+
+
+@pytest.mark.timeout(420)
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as ONE command — no outer torch.distributed.run — starts its two ranks itself
+    (the parent never touches the GPU), relays rank 0's single JSON line and exits 0.  Rehearsed with both ranks on the box's one
+    GPU (MBPO_BENCH_SHARE_GPU=1: gloo process group — RCCL refuses two ranks on one device — peer-memory gradient exchange)."""
+    import json
+    import subprocess
+    env = dict(os.environ, MBPO_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                                   # exactly one line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["pg_world_size"] == 2 and out["params_finite"]
+    assert out["config"]["rank_device_ids"] == [0, 0]
+    assert out["config"]["grad_exchange"].startswith("peer-memory") or out["config"]["p2p_decline_reason"]
+    assert out["value"] > 0 and "steady_ms_per_step" in out
+    # a rank that fails makes the whole command fail (here: more ranks than GPUs without the rehearsal switch)
+    env.pop("MBPO_BENCH_SHARE_GPU")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr
