@@ -63,6 +63,11 @@ const char *mbpo_last_error(void);
  * Convention used by the trainers: offset = (call-site id << 32), rng_dev = {epoch key, training-step index}.
  * mbpo_rng_advance: rng_dev[1] += inc (one tiny launch, graph-capturable). */
 int mbpo_rng_advance(uint64_t *rng_dev, uint64_t inc, void *stream);
+/* out[i] = standard normal of element (elem_base + i) of `stream` (1 = policy noise ... 10 = iCEM; csrc/common.hpp) under
+ * (seed + rng_dev[0], offset + rng_dev[1]) — exactly the number a fused kernel draws for that element.  For host-side horizon
+ * loops around a user-defined System (BPTT: the noise of jr.normal in act(), bptt_optimizer.py:305-325). */
+int mbpo_philox_normal_fill(uint64_t seed, uint64_t offset, const uint64_t *rng_dev, uint32_t stream, uint64_t elem_base, int64_t n,
+                            float *out, void *stream_);
 
 /* ---- R2: ensemble MLP forward -------------------------------------------------------------
  * replaces: the (new) learned Dynamics.next_state evaluated under vmap —
@@ -411,6 +416,22 @@ int mbpo_critic_grads(const float *critic_params, int32_t x_dim, int32_t critic_
                       int32_t activation, const float *transitions, int32_t row_len, const float *lambda_values,
                       const int32_t *idx, int64_t batch, const float *state_mean, const float *state_std, float *grads,
                       float *metrics, float *workspace, void *stream);
+
+/* ---- B1/B3 around a USER-DEFINED System: vector-Jacobian product of one or two 64-wide MLPs ------------------------
+ * replaces: the reverse-mode pieces of value_and_grad(vmap(actor_loss)) (bptt_optimizer.py:361-372) that are NOT the user's
+ *           System.step when the horizon loop of rollout_policy (utils/optimizer_utils.py:62-116) has to run on the host:
+ *           the actor MLP (weights only: act(stop_gradient(obs)), :85-86) and the twin target critics on the next state
+ *           (input only: bptt_optimizer.py:342-343).  MLP semantics: utils/network_utils.py:5-17.
+ * For every net k < n_nets (1 or 2; shared input):  y_k = MLP_k((x - norm_mean) / norm_std)   [norm_* NULL: y_k = MLP_k(x)]
+ *   dx[k][j][:] = d <dy[k][j], y_k[j]> / d x[j]        (optional, [n_nets][n][dims[0]], with respect to the RAW x)
+ *   dw[k][:]    = sum_j d <dy[k][j], y_k[j]> / d params_k   (optional, [n_nets][params per net]; needs net_stride == params per net)
+ *   y[k][j][:]  = the recomputed outputs (optional, [n_nets][n][dims[n_layers]])
+ * dy: [n_nets][n][dims[n_layers]].  Hidden layers 64 wide, input / output width <= 32.  workspace (only for dw)
+ * >= mbpo_mlp_vjp_workspace_floats(mlp, n) floats.  Fixed-order reductions: bit-reproducible.
+ */
+int64_t mbpo_mlp_vjp_workspace_floats(const mbpo_mlp_desc *mlp, int64_t n);
+int mbpo_mlp_vjp(const mbpo_mlp_desc *mlp, const float *x, int64_t n, const float *norm_mean, const float *norm_std,
+                 const float *dy, float *y, float *dx, float *dw, float *workspace, void *stream);
 
 /* ---- generic optimizer step: [optax.apply_if_finite(] optax.adamw(lr, wd) [)] + optional Polyak target ----------------
  * replaces: actor_optimizer.update/apply_updates (bptt_optimizer.py:218-225, 374-378), critic_optimizer + soft_update

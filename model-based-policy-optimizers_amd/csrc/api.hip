@@ -55,3 +55,26 @@ extern "C" int mbpo_rng_advance(uint64_t *rng_dev, uint64_t inc, void *stream) {
   MBPO_CHECK_LAUNCH("rng_advance");
   return MBPO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- standard-normal fill
+// out[i] = philox_normal(seed + rng_dev[0], offset + rng_dev[1], stream, elem_base + i): the draws a fused kernel makes in
+// registers, as a tensor — for host-side loops that walk a horizon step by step with a user's code between the kernels (BPTT
+// through a user-defined System) and must consume the SAME numbers as the fused kernel (k_bptt_actor: element (traj*H + t)*u + d).
+__global__ void __launch_bounds__(256) k_philox_normal_fill(unsigned long long seed, unsigned long long offset, const unsigned long long *rng_dev,
+                                                            unsigned int stream, unsigned long long elem_base, long long n, float *out) {
+  const RngKey k = rng_resolve(seed, offset, rng_dev);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i] = philox_normal(k.seed, k.offset, stream, elem_base + (unsigned long long)i);
+}
+
+extern "C" int mbpo_philox_normal_fill(uint64_t seed, uint64_t offset, const uint64_t *rng_dev, uint32_t stream, uint64_t elem_base,
+                                       int64_t n, float *out, void *stream_) {
+  MBPO_REQUIRE(out && n > 0, MBPO_ERR_ARG, "philox_normal_fill: null out / n <= 0");
+  MBPO_REQUIRE(stream >= 1 && stream <= 10, MBPO_ERR_ARG, "philox_normal_fill: unknown stream id %u", stream);
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_philox_normal_fill, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream_,
+                     (unsigned long long)seed, (unsigned long long)offset, (const unsigned long long *)rng_dev, stream,
+                     (unsigned long long)elem_base, (long long)n, out);
+  MBPO_CHECK_LAUNCH("philox_normal_fill");
+  return MBPO_OK;
+}

@@ -236,6 +236,12 @@ def _bind_optional(lib: C.CDLL) -> None:
         fn.argtypes = [i32, i32, vp, i64]
     lib.mbpo_policy_act.restype = C.c_int
     lib.mbpo_policy_act.argtypes = [C.POINTER(MlpDesc), vp, i64, vp, vp, i32, f32, vp, u64, u64, vp, u64, vp, vp, vp, vp, vp]
+    lib.mbpo_philox_normal_fill.restype = C.c_int
+    lib.mbpo_philox_normal_fill.argtypes = [C.c_uint64, C.c_uint64, vp, C.c_uint32, C.c_uint64, i64, vp, vp]
+    lib.mbpo_mlp_vjp_workspace_floats.restype = C.c_int64
+    lib.mbpo_mlp_vjp_workspace_floats.argtypes = [C.POINTER(MlpDesc), i64]
+    lib.mbpo_mlp_vjp.restype = C.c_int
+    lib.mbpo_mlp_vjp.argtypes = [C.POINTER(MlpDesc), vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mbpo_episode_step.restype = C.c_int
     lib.mbpo_episode_step.argtypes = [C.POINTER(EpisodeStepDesc), vp]
     lib.mbpo_running_stats_workspace_floats.restype = C.c_int64

@@ -57,6 +57,61 @@ def ensemble_mlp_forward(params: torch.Tensor, spec: MlpSpec, x: torch.Tensor, s
     return y
 
 
+def mlp_vjp(params: torch.Tensor, spec: MlpSpec, x: torch.Tensor, dy: torch.Tensor, norm_mean=None, norm_std=None,
+            want_dx: bool = True, want_dw: bool = True, want_y: bool = False, workspace: Optional[torch.Tensor] = None):
+    """mbpo_mlp_vjp: for the spec's 1 or 2 nets on the shared input x [n, in] with upstream gradients dy [n_nets, n, out]:
+    (dx [n_nets, n, in] | None, dw [n_nets * n_params] | None, y [n_nets, n, out] | None)."""
+    lib = load()
+    _req(x, "x"); _req(dy, "dy")
+    din, dout = spec.dims[0], spec.dims[-1]
+    n = x.shape[0]
+    if x.dim() != 2 or x.shape[1] != din:
+        raise ValueError(f"x must be [n,{din}], got {tuple(x.shape)}")
+    if tuple(dy.shape) != (spec.n_nets, n, dout):
+        raise ValueError(f"dy must be [{spec.n_nets},{n},{dout}], got {tuple(dy.shape)}")
+    d = spec.desc(params)
+    dx = torch.empty((spec.n_nets, n, din), device=x.device, dtype=torch.float32) if want_dx else None
+    dw = torch.empty(spec.n_nets * spec.n_params, device=x.device, dtype=torch.float32) if want_dw else None
+    y = torch.empty((spec.n_nets, n, dout), device=x.device, dtype=torch.float32) if want_y else None
+    if want_dw:
+        need = int(lib.mbpo_mlp_vjp_workspace_floats(C.byref(d), n))
+        if need < 0:
+            check(need, "mbpo_mlp_vjp_workspace_floats")
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(max(need, 1), device=x.device, dtype=torch.float32)
+    check(lib.mbpo_mlp_vjp(C.byref(d), x.data_ptr(), n, ptr(norm_mean), ptr(norm_std), dy.data_ptr(), ptr(y), ptr(dx), ptr(dw),
+                           ptr(workspace) if want_dw else None, current_stream_ptr()), "mbpo_mlp_vjp")
+    return dx, dw, y
+
+
+class HipMlp(torch.autograd.Function):
+    """y [n_nets, n, out] = MLP_k((x - mean) / std): forward in mbpo_ensemble_mlp_forward, backward in mbpo_mlp_vjp — the node that
+    puts the HIP networks into a torch autograd graph whose other nodes are a USER-DEFINED System.step (BPTT through a model
+    that exists only as the user's torch code; utils/optimizer_utils.py:62-116, bptt_optimizer.py:327-378).  `params` gets a
+    gradient when it requires one, `x` likewise (mean / std are constants of the graph, as the reference's normaliser state is)."""
+
+    @staticmethod
+    def forward(ctx, params, x, spec, norm_mean, norm_std):
+        xn = x if norm_mean is None else ((x - norm_mean) / norm_std).contiguous()
+        ctx.spec, ctx.norm = spec, (norm_mean, norm_std)
+        ctx.save_for_backward(params, x)
+        return ensemble_mlp_forward(params, spec, xn.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        params, x = ctx.saved_tensors
+        need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_w or need_x):
+            return None, None, None, None, None
+        dx, dw, _ = mlp_vjp(params, ctx.spec, x.contiguous(), dy.contiguous(), ctx.norm[0], ctx.norm[1], want_dx=need_x, want_dw=need_w)
+        gx = dx.sum(0) if need_x else None               # the nets share the input: their input gradients add up
+        gw = None
+        if need_w:
+            gw = torch.zeros_like(params)
+            gw[:dw.numel()] = dw
+        return gw, gx, None, None, None
+
+
 # ------------------------------------------------------------------------------------------------ hidden-width padding
 # The MFMA kernels are built for hidden layers of ONE width per launch (64 or 128; the rollout also 256).  The reference accepts
 # any sizes (experiments/train_inverted_pendulum/exp_ppo.py: policy (32,)*4 beside critic (256,)*5).  Narrower or unequal hidden
@@ -829,6 +884,119 @@ class BpttActorGrad:
             self.workspace = torch.zeros(int(nws), device=self.device, dtype=torch.float32)
         d.workspace = self.workspace.data_ptr()
         check(self.lib.mbpo_bptt_actor_grads(C.byref(d), current_stream_ptr()), "mbpo_bptt_actor_grads")
+        return self.grads
+
+
+def philox_normal(n: int, seed: int, offset: int = 0, stream: int = 1, rng_dev: Optional[torch.Tensor] = None, elem_base: int = 0,
+                  device=None) -> torch.Tensor:
+    """mbpo_philox_normal_fill: n standard normals of `stream` (1 = policy noise) — the numbers the fused kernels draw."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = torch.empty(int(n), device=dev, dtype=torch.float32)
+    check(load().mbpo_philox_normal_fill(int(seed) & ((1 << 64) - 1), int(offset) & ((1 << 64) - 1), rng_ptr(rng_dev), int(stream),
+                                         int(elem_base), int(n), out.data_ptr(), current_stream_ptr()), "mbpo_philox_normal_fill")
+    return out
+
+
+class LambdaReturnFn(torch.autograd.Function):
+    """lambda_return (utils/optimizer_utils.py:119-152) on [n, H] tensors as an autograd node: forward and backward are the HIP scan
+    (mbpo_lambda_return_scan).  R_t = r_t + g(1-l) V_t + g l R_{t+1}, R_H = V_{H-1} is linear in (r, V): with
+    G_t = sum_{s<=t} (g l)^{t-s} dL/dR_s  (the same recurrence run forward in time = the scan on the time-reversed upstream
+    gradient with zero bootstrap):  dL/dr_t = G_t,  dL/dV_t = g(1-l) G_t  (t < H-1),  dL/dV_{H-1} = g G_{H-1}."""
+
+    @staticmethod
+    def forward(ctx, reward, next_values, discount, lambda_):
+        ctx.cfg = (float(discount), float(lambda_))
+        return lambda_return_scan(reward.contiguous(), next_values.contiguous(), discount, lambda_)
+
+    @staticmethod
+    def backward(ctx, g):
+        discount, lambda_ = ctx.cfg
+        G = lambda_return_scan(g.flip(1).contiguous(), torch.zeros_like(g), discount, lambda_).flip(1)
+        dv = discount * (1.0 - lambda_) * G
+        dv[:, -1] = discount * G[:, -1]
+        return G, dv, None, None
+
+
+class BpttActorGradGeneric:
+    """BpttActorGrad's contract (grads [P], transitions [n*H, 2x+u+2], lambda_values [n*H], metrics) for a USER-DEFINED System —
+    value_and_grad(vmap(actor_loss)) of bptt_optimizer.py:327-372 with rollout_policy (utils/optimizer_utils.py:62-116) walked on
+    the host: per horizon step  HipMlp (actor on stop_gradient(obs), HIP) -> squash -> the user's batched, torch-differentiable
+    System.step -> next step;  then HipMlp (twin target critics on the next states, HIP), LambdaReturnFn (HIP scans), the loss of
+    :346-353, and one backward through the graph: torch autograd differentiates the user's step, mbpo_mlp_vjp the networks.
+    Same Philox noise (stream POLICY_NOISE, element (traj*H + t)*u + d) and the same A > 1 log-prob form as the fused kernel.
+    Not hipGraph-captured (user code runs between the kernels)."""
+
+    def __init__(self, *, x_dim: int, u_dim: int, horizon: int, actor_dims: Sequence[int], critic_dims: Sequence[int], n: int,
+                 device, actor_activation: str = "swish", critic_activation: str = "swish", init_stddev: float = 1.0,
+                 discount: float = 0.99, lambda_: float = 0.97, ent_coef: float = 0.005, seed: int = 0):
+        self.x_dim, self.u_dim, self.horizon, self.n = x_dim, u_dim, horizon, n
+        self.device = torch.device(device)
+        self.actor_spec = MlpSpec(list(actor_dims), actor_activation, 1)
+        self.critic_spec = MlpSpec(list(critic_dims), critic_activation, 2)
+        self.P, self.C = self.actor_spec.n_params, self.critic_spec.n_params
+        self.init_stddev, self.discount, self.lambda_, self.ent_coef = float(init_stddev), float(discount), float(lambda_), float(ent_coef)
+        f = lambda *s: torch.zeros(*s, device=self.device, dtype=torch.float32)
+        self.row_len = 2 * x_dim + u_dim + 2
+        self.transitions, self.lambda_values = f(n * horizon, self.row_len), f(n * horizon)
+        self.grads, self.metrics = f(self.P), f(2)
+
+        class _D:       # the fields the optimizer sets on BpttActorGrad.desc
+            seed = seed
+        self.desc = _D()
+
+    def __call__(self, *, actor_params, target_critic_params, init_states, state_mean, state_std, reward_mean_std, system,
+                 system_params, act_noise=None, offset: int = 0, rng_dev=None):
+        import math
+        n, H, X, U = self.n, self.horizon, self.x_dim, self.u_dim
+        if tuple(init_states.shape) != (n, X):
+            raise ValueError(f"init_states must be [{n},{X}]")
+        if act_noise is None:
+            act_noise = philox_normal(n * H * U, self.desc.seed, offset, 1, rng_dev, device=self.device)
+        noise = act_noise.reshape(n, H, U)
+        p = actor_params.detach().clone().requires_grad_(True)
+        tcp = target_critic_params.detach()
+        s_mean, s_std = state_mean.detach().contiguous(), state_std.detach().contiguous()
+        inv_sp = math.log(math.exp(self.init_stddev) - 1.0) if self.init_stddev < 20.0 else self.init_stddev
+
+        def actor(obs):           # Actor.__call__ (bptt_optimizer.py:131-142) on the state normaliser's view of obs
+            out = HipMlp.apply(p, obs, self.actor_spec, s_mean, s_std)[0]
+            mu, raw = out[:, :U], out[:, U:]
+            return mu, torch.clamp(torch.nn.functional.softplus(raw + inv_sp), 1e-6, 1e2)
+
+        obs, sp = init_states.detach(), system_params
+        o_l, a_l, r_l, n_l = [], [], [], []
+        for t in range(H):        # rollout_policy (optimizer_utils.py:79-101): policy(stop_gradient(obs)), then System.step
+            mu, sig = actor(obs.detach())
+            a = torch.clamp(torch.tanh(mu + noise[:, t] * sig), -0.999, 0.999)          # act (:313-317)
+            st = system.step(obs, a, sp)
+            nxt = st.x_next.reshape(n, X).to(torch.float32)
+            r = torch.as_tensor(st.reward, device=self.device, dtype=torch.float32).reshape(-1).expand(n)
+            o_l.append(obs); a_l.append(a); r_l.append(r); n_l.append(nxt)
+            obs, sp = nxt, st.system_params
+        observation, action = torch.stack(o_l, 1), torch.stack(a_l, 1)                 # [n, H, .]
+        reward, next_observation = torch.stack(r_l, 1), torch.stack(n_l, 1)
+        reward_n = (reward - reward_mean_std[0]) / reward_mean_std[1]                  # :340-341
+        v = HipMlp.apply(tcp, next_observation.reshape(n * H, X), self.critic_spec, s_mean, s_std)   # :338-339, 342
+        bootstrap = torch.minimum(v[0, :, 0], v[1, :, 0]).reshape(n, H)                # :343
+        lam = LambdaReturnFn.apply(reward_n, bootstrap, self.discount, self.lambda_)   # :344
+        disc = torch.cat([torch.ones(1, device=self.device), torch.full((H - 1,), self.discount, device=self.device)]).cumprod(0)   # :346-348
+        mu, sig = actor(observation.reshape(n * H, X))                                 # get_log_prob (:144-152): obs NOT stop-gradiented
+        a_flat = action.reshape(n * H, U)
+        a_c = torch.clamp(a_flat, -1 + 1e-8, 1 - 1e-8)
+        u_raw = 0.5 * torch.log((1 + a_c) / (1 - a_c))
+        log_l = (-0.5 * ((u_raw - mu) / sig) ** 2 - torch.log(sig) - 0.5 * math.log(2 * math.pi)).sum(-1) - torch.log(1 - a_flat ** 2).sum(-1)
+        entropy_loss = -log_l.reshape(n, H).mean(dim=1)                                # :351
+        loss = (-(lam * disc).mean(dim=1) + entropy_loss * self.ent_coef).mean()       # :352, vmap + mean (:364-366)
+        loss.backward()
+        self.grads.copy_(p.grad)
+        with torch.no_grad():
+            self.metrics[0] = loss.detach()
+            self.metrics[1] = entropy_loss.detach().mean()
+            R = n * H
+            self.transitions.copy_(torch.cat([observation.reshape(R, X), a_flat, reward.reshape(R, 1), torch.ones(R, 1, device=self.device),
+                                              next_observation.reshape(R, X)], dim=1))
+            self.lambda_values.copy_(lam.detach().reshape(R))
+        self.system_params_out = sp
         return self.grads
 
 

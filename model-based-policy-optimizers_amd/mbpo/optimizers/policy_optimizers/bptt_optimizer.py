@@ -246,6 +246,10 @@ class BPTTOptimizer(BaseOptimizer):
                                              n=n, device=dev, actor_activation=policy_activation,
                                              critic_activation=critic_activation, init_stddev=self.init_stddev, discount=discount,
                                              lambda_=lambda_, ent_coef=loss_ent_coefficient)
+        self._actor_grad_generic = ops.BpttActorGradGeneric(
+            x_dim=X, u_dim=U, horizon=H, actor_dims=self.actor_dims, critic_dims=self.critic_dims, n=n, device=dev,
+            actor_activation=policy_activation, critic_activation=critic_activation, init_stddev=self.init_stddev, discount=discount,
+            lambda_=lambda_, ent_coef=loss_ent_coefficient)        # the same contract for a user-defined System (non-fused)
         self._critic_grad = ops.CriticGrad(x_dim=X, critic_dims=self.critic_dims, batch=self.critic_batch, device=dev,
                                            activation=critic_activation)
         self.P, self.C2 = self.actor_spec.n_params, 2 * self.critic_spec.n_params
@@ -325,9 +329,10 @@ class BPTTOptimizer(BaseOptimizer):
     def _system_kwargs(self, system_params):
         spec = self.system.rollout_spec(system_params, self.device)
         if spec["system_kind"] == _hip.SYS_GENERIC:
-            raise _hip.MbpoHipError("BPTT differentiates THROUGH the model inside one kernel (csrc/bptt.hip): the system must exist as "
-                                    "device code (PendulumSystem, EnsembleSystem in 'mean' mode); a user-defined torch System cannot be "
-                                    "back-propagated through on this path (INTEGRATION.md)")
+            # a user-defined System (the reference's plug-in seam, base_systems.py:40-52): rollout_policy's scan
+            # (utils/optimizer_utils.py:62-116) is walked on the host — ops.BpttActorGradGeneric: the networks' forward and VJP in HIP
+            # (mbpo_ensemble_mlp_forward / mbpo_mlp_vjp), lambda-return in HIP, the user's step differentiated by torch autograd
+            return spec, dict(system=self.system, system_params=system_params)
         if spec["system_kind"] == _hip.SYS_ENSEMBLE and spec.get("ens_mode", _hip.ENS_MEAN) != _hip.ENS_MEAN:
             raise _hip.MbpoHipError("BPTT needs a differentiable model: EnsembleSystem mode must be 'mean'")
         if spec.get("ens_sample_noise", False):
@@ -348,7 +353,7 @@ class BPTTOptimizer(BaseOptimizer):
         # actor: value_and_grad(vmap(actor_loss).mean)   (:361-372)
         self._reward_ms[0:1].copy_(w.reward_norm.vec[1:2])
         self._reward_ms[1:2].copy_(w.reward_norm.vec[3:4])
-        ag = self._actor_grad
+        ag = self._actor_grad_generic if w.generic else self._actor_grad
         ag.desc.seed = act_seed
         ag(actor_params=w.actor_params, target_critic_params=w.target_critic_params, init_states=self._init_obs,
            state_mean=w.state_norm.mean, state_std=w.state_norm.std, reward_mean_std=self._reward_ms, offset=0,
@@ -442,7 +447,7 @@ class BPTTOptimizer(BaseOptimizer):
         # per step cost more host time than GPU time at the reference's sizes (n = 50, H = 20).  Library collectives are
         # not captured (a failed capture is not recoverable); evaluation runs eagerly between replays.
         graph = None
-        can_capture = self.use_graph and self._all_reduce is None and self.train_steps >= 3
+        can_capture = self.use_graph and self._all_reduce is None and self.train_steps >= 3 and not w.generic   # user code between the kernels
         n_rows = self._actor_grad.transitions.shape[0]
         for i in range(self.train_steps):
             sampling_key, state_key = K.split(state_key, 2)
@@ -493,6 +498,7 @@ class _Work:
         self.state_norm = st.state_normalizer_state.clone()
         self.reward_norm = st.reward_normalizer_state.clone()
         self.rollout_spec, self.sys_kw = opt._system_kwargs(st.system_params)
+        self.generic = self.rollout_spec["system_kind"] == _hip.SYS_GENERIC
         self.step_summary = torch.zeros(4, device=opt.device, dtype=torch.float32)
 
     def snapshot(self, opt: BPTTOptimizer, key: int) -> BPTTState:

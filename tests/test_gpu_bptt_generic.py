@@ -1,0 +1,180 @@
+"""GPU: BPTT through a USER-DEFINED System (reference: utils/optimizer_utils.py:62-116, bptt_optimizer.py:327-372).
+
+The reference differentiates rollout_policy through ANY System.step.  Here a System that exists only as the user's batched torch
+code is back-propagated through on a non-fused path: the networks' forward and vector-Jacobian products run in HIP
+(mbpo_ensemble_mlp_forward / mbpo_mlp_vjp), the lambda-return in the HIP scan, the user's step under torch autograd.
+Checked: (1) mbpo_mlp_vjp against torch autograd of the oracle MLP; (2) the generic actor gradient against the oracle AND against
+the fused kernel on the same physics (Pendulum re-expressed as a user System) with the existing tolerances; (3) whole
+BPTTOptimizer.train steps against oracle.bptt.CpuBpttLoop."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bptt as obptt, nets as onets, systems as osys
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("X,NO,L,nets,n,norm", [(3, 2, 3, 1, 40, True),      # BPTT actor at u = 1, ragged last tile
+                                                 (3, 1, 3, 2, 16, True),      # twin critics
+                                                 (17, 12, 3, 1, 33, False),   # config-5 actor shape (x = 17, u = 6): the WIDE instantiation
+                                                 (17, 1, 3, 2, 64, True),     # config-5 twin critics
+                                                 (4, 2, 1, 1, 5000, True),    # one hidden layer; more tiles than workgroups' first pass
+                                                 (8, 4, 2, 2, 100, False)])
+def test_mlp_vjp_matches_autograd(dev, X, NO, L, nets, n, norm):
+    from mbpo import ops
+    g = torch.Generator().manual_seed(X * 100 + NO)
+    dims = [X] + [64] * L + [NO]
+    P = onets.n_params(dims)
+    params = torch.cat([onets.init_mlp_flat(dims, g) + 0.05 * torch.randn(P, generator=g) for _ in range(nets)])
+    x = torch.randn(n, X, generator=g)
+    dy = torch.randn(nets, n, NO, generator=g)
+    mean, std = (torch.randn(X, generator=g) * 0.3, torch.rand(X, generator=g) + 0.5) if norm else (None, None)
+    p64, x64 = params.double().requires_grad_(True), x.double().requires_grad_(True)
+    xn = x64 if not norm else (x64 - mean.double()) / std.double()
+    ys = [onets.mlp_forward(p64[k * P:(k + 1) * P], dims, xn) for k in range(nets)]
+    loss = sum((ys[k] * dy[k].double()).sum() for k in range(nets))
+    loss.backward()
+    # per-net input gradients for the dx check
+    dx_ref = []
+    for k in range(nets):
+        xk = x.double().requires_grad_(True)
+        xkn = xk if not norm else (xk - mean.double()) / std.double()
+        (onets.mlp_forward(params.double()[k * P:(k + 1) * P], dims, xkn) * dy[k].double()).sum().backward()
+        dx_ref.append(xk.grad)
+    spec = ops.MlpSpec(dims, "swish", nets)
+    to = lambda t: None if t is None else t.to(dev)
+    dx, dw, y = ops.mlp_vjp(to(params), spec, to(x), to(dy), to(mean), to(std), want_dx=True, want_dw=True, want_y=True)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.cpu().double(), torch.stack([t.detach() for t in ys]), atol=2e-5, rtol=2e-5)
+    torch.testing.assert_close(dx.cpu().double(), torch.stack(dx_ref), atol=2e-5, rtol=2e-4)
+    scale = float(p64.grad.abs().max())
+    torch.testing.assert_close(dw.cpu().double(), p64.grad, atol=2e-6 * max(scale, 1.0), rtol=2e-4)
+    # dw alone / dx alone give the same numbers (the unused chains idle)
+    _, dw2, _ = ops.mlp_vjp(to(params), spec, to(x), to(dy), to(mean), to(std), want_dx=False, want_dw=True)
+    dx2, _, _ = ops.mlp_vjp(to(params), spec, to(x), to(dy), to(mean), to(std), want_dx=True, want_dw=False)
+    assert torch.equal(dw2, dw) and torch.equal(dx2, dx)
+
+
+def test_mlp_vjp_refuses_what_it_cannot_run(dev):
+    from mbpo import _hip, ops
+    x, dy = torch.zeros(4, 3, device=dev), torch.zeros(1, 4, 2, device=dev)
+    with pytest.raises(_hip.MbpoHipError):          # 128-wide hidden layers
+        ops.mlp_vjp(torch.zeros(onets.n_params([3, 128, 2]), device=dev), ops.MlpSpec([3, 128, 2]), x, dy)
+    with pytest.raises(_hip.MbpoHipError):          # no hidden layer
+        ops.mlp_vjp(torch.zeros(onets.n_params([3, 2]), device=dev), ops.MlpSpec([3, 2]), x, dy)
+    with pytest.raises(ValueError):                 # dy of the wrong shape
+        ops.mlp_vjp(torch.zeros(onets.n_params([3, 64, 2]), device=dev), ops.MlpSpec([3, 64, 2]), x, dy[:, :3])
+
+
+def test_philox_normal_fill_is_the_kernels_stream(dev):
+    from mbpo import ops
+    from oracle import philox
+    seed, off = 2 ** 40 + 17, (5 << 32) + 3
+    got = ops.philox_normal(1000, seed, off, stream=philox.STREAM_POLICY_NOISE, elem_base=7).cpu().numpy()
+    ref = philox.philox_normal(seed, off, philox.STREAM_POLICY_NOISE, np.arange(7, 1007, dtype=np.uint64))
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-6)
+    rng = ops.make_rng(dev, seed=100, counter=9)
+    got = ops.philox_normal(64, 5, 1 << 32, stream=philox.STREAM_POLICY_NOISE, rng_dev=rng).cpu().numpy()
+    np.testing.assert_allclose(got, philox.philox_normal(105, (1 << 32) + 9, philox.STREAM_POLICY_NOISE, np.arange(64, dtype=np.uint64)),
+                               rtol=2e-6, atol=2e-6)
+
+
+def _user_pendulum_system():
+    from test_gpu_generic_system import _user_pendulum
+    return _user_pendulum()()
+
+
+@pytest.mark.parametrize("H,n", [(10, 20), (20, 16)])
+def test_generic_actor_gradient_matches_oracle_and_fused_kernel(dev, H, n):
+    """Pendulum re-expressed as a user torch System: the non-fused BPTT actor gradient within the fused kernel's tolerances of the
+    oracle (tests/test_gpu_bptt.py), and the fused kernel itself on the same inputs."""
+    from mbpo import ops
+    from test_gpu_bptt import _run_hip, _setup
+    X, U = 3, 1
+    cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, tsys, extra = _setup(X, U, H, n, "pendulum", 0, 0)
+    g_ref, loss_ref, aux = obptt.actor_grads(cfg, tsys, ap, cp, x0, noise, s_mean, s_std, r_ms[0], r_ms[1])
+    d = lambda t: t.double()
+    g64, loss64, aux64 = obptt.actor_grads(cfg, obptt.TorchPendulumSystem(), d(ap), d(cp), d(x0), d(noise), d(s_mean), d(s_std), d(r_ms[0]), d(r_ms[1]))
+    user = _user_pendulum_system()
+    op = ops.BpttActorGradGeneric(x_dim=X, u_dim=U, horizon=H, actor_dims=cfg.actor_dims, critic_dims=cfg.critic_dims, n=n, device=dev,
+                                  init_stddev=cfg.init_stddev, discount=cfg.discount, lambda_=cfg.lambda_, ent_coef=cfg.ent_coef)
+    op(actor_params=ap.to(dev), target_critic_params=cp.to(dev), init_states=x0.to(dev), state_mean=s_mean.to(dev), state_std=s_std.to(dev),
+       reward_mean_std=r_ms.to(dev), system=user, system_params=user.init_params(0), act_noise=noise.to(dev))
+    torch.cuda.synchronize()
+    assert user.calls == H and not user.fused
+    rows = op.transitions.cpu().reshape(n, H, -1)
+    torch.testing.assert_close(rows[..., :X], aux["observation"], atol=2e-4, rtol=2e-4)
+    torch.testing.assert_close(rows[..., X:X + U], aux["action"], atol=2e-4, rtol=2e-4)
+    torch.testing.assert_close(rows[..., X + U], aux["reward"], atol=5e-4, rtol=5e-4)
+    assert torch.all(rows[..., X + U + 1] == 1.0)
+    torch.testing.assert_close(rows[..., X + U + 2:], aux["next_observation"], atol=2e-4, rtol=2e-4)
+    torch.testing.assert_close(op.lambda_values.cpu().reshape(n, H), aux["lambda_values"], atol=5e-4, rtol=5e-4)
+    m = op.metrics.cpu().tolist()
+    np.testing.assert_allclose(m[0], loss64, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(m[1], float(aux64["entropy_loss"]), rtol=1e-4, atol=2e-5)
+    g = op.grads.cpu()
+    torch.testing.assert_close(g, g_ref, atol=5e-6, rtol=2e-3)
+    torch.testing.assert_close(g.double(), g64, atol=5e-6, rtol=1e-3)
+    fused = _run_hip(dev, cfg, ap, cp, x0, noise, s_mean, s_std, r_ms, "pendulum", extra, n)
+    torch.testing.assert_close(g, fused.grads.cpu(), atol=5e-6, rtol=2e-3)
+    torch.testing.assert_close(op.transitions, fused.transitions, atol=2e-4, rtol=2e-4)
+
+
+def test_lambda_return_fn_gradient(dev):
+    """The autograd node around the HIP scan against the differentiable oracle recurrence."""
+    from mbpo import ops
+    g = torch.Generator().manual_seed(2)
+    n, H = 37, 12
+    r, v, w = torch.randn(n, H, generator=g), torch.randn(n, H, generator=g), torch.randn(n, H, generator=g)
+    r64, v64 = r.double().requires_grad_(True), v.double().requires_grad_(True)
+    (obptt.lambda_return_t(r64, v64, 0.97, 0.9) * w.double()).sum().backward()
+    rd, vd = r.to(dev).requires_grad_(True), v.to(dev).requires_grad_(True)
+    out = ops.LambdaReturnFn.apply(rd, vd, 0.97, 0.9)
+    (out * w.to(dev)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu().double(), obptt.lambda_return_t(r.double(), v.double(), 0.97, 0.9), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(rd.grad.cpu().double(), r64.grad, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(vd.grad.cpu().double(), v64.grad, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("kc", [1, 2])
+def test_bptt_optimizer_trains_through_a_user_defined_system(dev, kc):
+    """BPTTOptimizer.train with the user System: 1 and 3 whole train steps (sampling, actor update through the user's step, critic
+    updates, normalisers, buffer insert) against oracle.bptt.CpuBpttLoop on the same Philox streams — the tolerances of the fused
+    path's test (tests/test_gpu_host_api.py::test_bptt_train_steps_match_cpu_oracle); nothing is hipGraph-captured."""
+    from mbpo.optimizers import BPTTOptimizer
+    from test_gpu_host_api import _bptt_pendulum_setup
+    _, _, sbs = _bptt_pendulum_setup(dev, buffer_rows=16)
+    n, H = 24, 6
+
+    def run(steps):
+        user = _user_pendulum_system()
+        opt = BPTTOptimizer(action_dim=1, obs_dim=3, horizon=H, num_samples_per_gradient_update=n, train_steps=steps, init_stddev=1.5,
+                            critic_updates_per_policy_update=kc, sampling_buffer_size=4096)
+        opt.set_system(user)
+        st = opt.init(key=11, true_buffer_state=sbs)
+        out = opt.train(bptt_state=st)
+        assert user.calls == steps * H
+        return opt, st, out
+
+    opt, st0, out1 = run(1)
+    cfg = obptt.BpttConfig(x_dim=3, u_dim=1, actor_dims=opt.actor_dims, critic_dims=opt.critic_dims, horizon=H, init_stddev=1.5)
+    loop = obptt.CpuBpttLoop(cfg, obptt.TorchPendulumSystem(), st0.actor_params.cpu(), st0.critic_params.cpu(), sbs.data.cpu(), n, kc,
+                             opt._last_seeds, buffer_size=4096)
+    r = loop.step()
+    s1, o1 = out1.bptt_summary, out1.optimizer_state
+    assert abs(float(s1.actor_loss[0]) - r["actor_loss"]) <= 2e-5 * max(1.0, abs(r["actor_loss"]))
+    assert abs(float(s1.critic_loss[0]) - r["critic_loss"]) <= 1e-4 * max(1.0, abs(r["critic_loss"]))
+    assert abs(float(s1.actor_grad_norm[0]) - r["actor_grad_norm"]) <= 2e-3 * r["actor_grad_norm"]
+    rel = lambda a, b: float((a.cpu() - b).norm() / b.norm())
+    assert rel(o1.actor_params, loop.ap) < 2e-4 and rel(o1.critic_params, loop.cp) < 2e-4
+    torch.testing.assert_close(o1.state_normalizer_state.mean.cpu(), loop.s_mean, atol=1e-5, rtol=1e-4)
+    opt, st0, out3 = run(3)
+    for _ in range(2):
+        r = loop.step()
+    o3 = out3.optimizer_state
+    assert rel(o3.actor_params, loop.ap) < 2e-3 and rel(o3.critic_params, loop.cp) < 2e-3
+    assert float(o3.state_normalizer_state.size) == loop.s_size == 3 * n * H
+    assert float(o3.actor_opt_state.count) == 3 and float(o3.critic_opt_state.count) == 3 * kc
