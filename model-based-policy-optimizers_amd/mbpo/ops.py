@@ -940,9 +940,8 @@ class BpttActorGradGeneric:
         self.transitions, self.lambda_values = f(n * horizon, self.row_len), f(n * horizon)
         self.grads, self.metrics = f(self.P), f(2)
 
-        class _D:       # the fields the optimizer sets on BpttActorGrad.desc
-            seed = seed
-        self.desc = _D()
+        import types
+        self.desc = types.SimpleNamespace(seed=seed)       # the field the optimizer sets on BpttActorGrad.desc
 
     def __call__(self, *, actor_params, target_critic_params, init_states, state_mean, state_std, reward_mean_std, system,
                  system_params, act_noise=None, offset: int = 0, rng_dev=None):
