@@ -488,6 +488,15 @@ int mbpo_icem_update(const float *rows, int32_t row_len, int32_t reward_col, int
                      int32_t horizon, int32_t u_dim, const float *candidates, int32_t n_elites, int32_t n_prev, float alpha,
                      int32_t use_max, float *mean, float *std, float *best_value, float *best_sequence, float *prev_elites,
                      float *values, int32_t *workspace, void *stream);
+/* The same with the reference's constraint term (icem_optimizer.py:99,157-166): particle_cost[c * n_particles + p] = the user's
+ * cost_fn on the trajectory of candidate c, particle p (evaluated by the host between the rollout and this launch — a Python
+ * callable cannot run in a kernel); objective[c] = reward[c] - lambda_constraint * relu(cost[c]), cost[c] = mean (cost_use_max:
+ * max, `use_pessimism`) over the particles.  particle_cost NULL: mbpo_icem_update. */
+int mbpo_icem_update_constrained(const float *rows, int32_t row_len, int32_t reward_col, int32_t n_candidates, int32_t n_particles,
+                                 int32_t horizon, int32_t u_dim, const float *candidates, int32_t n_elites, int32_t n_prev, float alpha,
+                                 int32_t use_max, const float *particle_cost, float lambda_constraint, int32_t cost_use_max, float *mean,
+                                 float *std, float *best_value, float *best_sequence, float *prev_elites, float *values,
+                                 int32_t *workspace, void *stream);
 
 /* ---- one-shot all-reduce over xGMI peer memory (multi-GPU SAC gradient exchange) ------------------------
  * replaces: the live form of the reference's jax.lax.pmean(grad) (sac/utils.py:29-33) for vectors small enough that a

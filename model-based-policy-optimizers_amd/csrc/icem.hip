@@ -104,7 +104,7 @@ extern "C" int mbpo_icem_sample(const float *mean, const float *std, const float
 
 // ---- objective + elite update ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_icem_values(const float *rows, int row_len, int reward_col, int NC, int P, int H, int use_max,
-                                                      float *values) {
+                                                      float *values, const float *particle_cost, float lambda_c, int cost_use_max) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= NC) return;
   const long long N = (long long)NC * P;
@@ -115,7 +115,19 @@ __global__ void __launch_bounds__(256) k_icem_values(const float *rows, int row_
     const float m = acc / (float)H;                                   // jnp.mean(transitions.reward, axis=-1)
     agg = (p == 0) ? m : (use_max ? fmaxf(agg, m) : agg + m);
   }
-  values[c] = use_max ? agg : agg / (float)P;                          // summarize_raw_samples: mean (or max under optimism)
+  float value = use_max ? agg : agg / (float)P;                        // summarize_raw_samples: mean (or max under optimism)
+  if (particle_cost) {
+    // constraint (:161-166): cost = summarize_cost_samples(vmap(cost_fn)(observation, action)) over the particles — mean, or max
+    // under pessimism; objective = reward - lambda_constraint * relu(cost).  The per-particle costs come from the user's callable.
+    float cagg = 0.f;
+    for (int p = 0; p < P; ++p) {
+      const float cp = particle_cost[(long long)c * P + p];
+      cagg = (p == 0) ? cp : (cost_use_max ? fmaxf(cagg, cp) : cagg + cp);
+    }
+    const float cost = cost_use_max ? cagg : cagg / (float)P;
+    value = value - lambda_c * fmaxf(cost, 0.f);
+  }
+  values[c] = value;
 }
 
 struct IcemUpdateArgs {
@@ -179,10 +191,11 @@ __global__ void __launch_bounds__(1024) k_icem_update(IcemUpdateArgs A) {
   if (tid == 0 && take) A.best_value[0] = best_elite;
 }
 
-extern "C" int mbpo_icem_update(const float *rows, int32_t row_len, int32_t reward_col, int32_t n_candidates, int32_t n_particles,
-                                int32_t horizon, int32_t u_dim, const float *candidates, int32_t n_elites, int32_t n_prev, float alpha,
-                                int32_t use_max, float *mean, float *std, float *best_value, float *best_sequence, float *prev_elites,
-                                float *values, int32_t *workspace, void *stream) {
+extern "C" int mbpo_icem_update_constrained(const float *rows, int32_t row_len, int32_t reward_col, int32_t n_candidates, int32_t n_particles,
+                                            int32_t horizon, int32_t u_dim, const float *candidates, int32_t n_elites, int32_t n_prev,
+                                            float alpha, int32_t use_max, const float *particle_cost, float lambda_constraint,
+                                            int32_t cost_use_max, float *mean, float *std, float *best_value, float *best_sequence,
+                                            float *prev_elites, float *values, int32_t *workspace, void *stream) {
   MBPO_REQUIRE(rows && candidates && mean && std && best_value && best_sequence && values && workspace, MBPO_ERR_ARG, "icem_update: null pointer");
   MBPO_REQUIRE(n_candidates > 0 && n_particles > 0 && horizon > 0 && u_dim > 0, MBPO_ERR_ARG, "icem_update: bad sizes");
   MBPO_REQUIRE(n_elites > 0 && n_elites <= n_candidates && n_prev >= 0 && n_prev <= n_elites, MBPO_ERR_ARG, "icem_update: bad elite counts");
@@ -190,10 +203,18 @@ extern "C" int mbpo_icem_update(const float *rows, int32_t row_len, int32_t rewa
   MBPO_REQUIRE(reward_col >= 0 && reward_col < row_len, MBPO_ERR_ARG, "icem_update: bad reward column");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_icem_values, dim3((n_candidates + 255) / 256), dim3(256), 0, st, rows, row_len, reward_col, n_candidates, n_particles,
-                     horizon, use_max, values);
+                     horizon, use_max, values, particle_cost, lambda_constraint, cost_use_max);
   IcemUpdateArgs A{values, candidates, n_candidates, horizon, u_dim, n_elites, n_prev, alpha, mean, std, best_value, best_sequence,
                    prev_elites, workspace};
   hipLaunchKernelGGL(k_icem_update, dim3(1), dim3(1024), 0, st, A);
   MBPO_CHECK_LAUNCH("icem_update");
   return MBPO_OK;
+}
+
+extern "C" int mbpo_icem_update(const float *rows, int32_t row_len, int32_t reward_col, int32_t n_candidates, int32_t n_particles,
+                                int32_t horizon, int32_t u_dim, const float *candidates, int32_t n_elites, int32_t n_prev, float alpha,
+                                int32_t use_max, float *mean, float *std, float *best_value, float *best_sequence, float *prev_elites,
+                                float *values, int32_t *workspace, void *stream) {
+  return mbpo_icem_update_constrained(rows, row_len, reward_col, n_candidates, n_particles, horizon, u_dim, candidates, n_elites, n_prev, alpha,
+                                      use_max, nullptr, 0.f, 0, mean, std, best_value, best_sequence, prev_elites, values, workspace, stream);
 }

@@ -255,6 +255,9 @@ def _bind_optional(lib: C.CDLL) -> None:
     lib.mbpo_icem_sample.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, u64, u64, vp, vp, vp, vp]
     lib.mbpo_icem_update.restype = C.c_int
     lib.mbpo_icem_update.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mbpo_icem_update_constrained.restype = C.c_int
+    lib.mbpo_icem_update_constrained.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, f32, i32, vp, f32, i32, vp, vp, vp, vp, vp, vp,
+                                                 vp, vp]
     # one-shot peer-memory all-reduce (csrc/p2p.hip)
     lib.mbpo_p2p_region_bytes.restype = C.c_int64
     lib.mbpo_p2p_region_bytes.argtypes = [i32, i64]

@@ -5,8 +5,11 @@ One `optimize` = num_steps iterations of
     mbpo_model_rollout open-loop rollouts of every candidate x particle through System.step               (rollout_actions)
     mbpo_icem_update   objective, elites, soft mean/std update, best-so-far, elites carried over              (:193-232)
 with all optimizer state in flat device vectors; the host only sequences launches.  Keys are integers (mbpo.utils.keys);
-device noise is Philox(seed = split key, offset = iteration).  A user `cost_fn` (a Python callable over trajectories) cannot run
-inside the kernels and is not supported; optimism / pessimism switches are (use_optimism -> max over particles).
+device noise is Philox(seed = split key, offset = iteration).  A user `cost_fn` (icem_optimizer.py:99,161-166: a callable over one
+trajectory, `cost_fn(observation [H, x], action [H, u]) -> scalar`) cannot run inside the kernels: it is evaluated between the
+rollout launch and the update launch, vmapped over all (candidate, particle) trajectories with torch.func.vmap on the device rows
+(the reference vmaps it too), and enters the objective inside mbpo_icem_update_constrained: reward - lambda_constraint * relu(cost),
+cost summarised over particles by mean (use_pessimism: max).  use_optimism -> max over particles of the reward.
 """
 from __future__ import annotations
 
@@ -63,8 +66,7 @@ class iCemTO(BaseOptimizer, Generic[DynamicsParams, RewardParams]):
     def __init__(self, horizon: int, action_dim: int, key: int = K.PRNGKey(0), opt_params: iCemParams = iCemParams(), cost_fn=None,
                  use_optimism: bool = False, use_pessimism: bool = False, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        if cost_fn is not None:
-            raise NotImplementedError("a Python cost_fn cannot run inside the fused rollout; only the reward objective is built")
+        self.cost_fn = cost_fn       # evaluated on the host side of the seam, between two launches (see the module docstring)
         self.lib = _hip.load()
         self.horizon, self.action_dim = int(horizon), int(action_dim)
         self.opt_params, self.key = opt_params, key
@@ -132,10 +134,21 @@ class iCemTO(BaseOptimizer, Generic[DynamicsParams, RewardParams]):
             b["steps"].zero_(); b["done"].zero_()
             ops.model_rollout(x_dim=X, u_dim=U, actions=b["actions"], obs=b["obs"], first_obs=b["first"], steps=b["steps"], done=b["done"],
                               n_steps=H, episode_length=2 ** 30, seed=particles_key, offset=it, out=b["rows"], **spec)
-            _hip.check(lib.mbpo_icem_update(b["rows"].data_ptr(), b["rows"].shape[1], X + U, b["NC"], p.num_particles, H, U, b["cand"].data_ptr(),
-                                            p.num_elites, self.num_prev, float(p.alpha), int(self.use_optimism), b["mean"].data_ptr(),
-                                            b["std"].data_ptr(), b["best_value"].data_ptr(), b["best_seq"].data_ptr(), b["prev"].data_ptr(),
-                                            b["values"].data_ptr(), b["rank"].data_ptr(), st), "mbpo_icem_update")
+            cost_ptr = None
+            if self.cost_fn is not None:
+                rows3 = b["rows"].reshape(H, b["N"], -1)
+                obs_t = rows3[:, :, :X].transpose(0, 1)                    # [N, H, x]: transitions.observation per (candidate, particle)
+                act_t = rows3[:, :, X:X + U].transpose(0, 1)               # [N, H, u]
+                cost = torch.func.vmap(self.cost_fn)(obs_t, act_t)         # :162  vmap(self.cost_fn)(observation, action)
+                cost = torch.as_tensor(cost, device=dev, dtype=torch.float32).reshape(-1).contiguous()
+                assert cost.numel() == b["N"], "cost_fn must return one scalar per trajectory"       # :163
+                b["cost"] = cost
+                cost_ptr = cost.data_ptr()
+            _hip.check(lib.mbpo_icem_update_constrained(
+                b["rows"].data_ptr(), b["rows"].shape[1], X + U, b["NC"], p.num_particles, H, U, b["cand"].data_ptr(), p.num_elites,
+                self.num_prev, float(p.alpha), int(self.use_optimism), cost_ptr, float(p.lambda_constraint), int(self.use_pessimism),
+                b["mean"].data_ptr(), b["std"].data_ptr(), b["best_value"].data_ptr(), b["best_seq"].data_ptr(), b["prev"].data_ptr(),
+                b["values"].data_ptr(), b["rank"].data_ptr(), st), "mbpo_icem_update_constrained")
         return opt_state.replace(key=key, best_sequence=b["best_seq"].clone(), best_reward=b["best_value"][0].clone())
 
     def act(self, obs: torch.Tensor, opt_state: iCemOptimizerState, evaluate: bool = True) -> Tuple[torch.Tensor, iCemOptimizerState]:

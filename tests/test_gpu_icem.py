@@ -144,3 +144,84 @@ def test_icem_mpc_solves_pendulum(dev):
         x, total = nxt.x_next, total + float(nxt.reward)
     print("icem MPC return:", total)
     assert total >= -400
+
+
+def test_icem_constraint_term_values(dev):
+    """mbpo_icem_update_constrained (icem_optimizer.py:157-166): objective = summarize(mean_t reward) - lambda * relu(summarize_cost(cost_p)),
+    summarize_cost = mean over particles, or max under pessimism; a NULL cost vector gives mbpo_icem_update's values."""
+    rng = np.random.default_rng(4)
+    X, U, H, NC, P = 3, 1, 6, 40, 3
+    D = 2 * X + U + 3
+    N = NC * P
+    rows = rng.standard_normal((H * N, D)).astype(np.float32)
+    cand = rng.standard_normal((NC, H, U)).astype(np.float32)
+    cost = rng.standard_normal(N).astype(np.float32)
+    from mbpo import _hip
+    lib = _hip.load()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rew = rows[:, X + U].reshape(H, NC, P).mean(axis=0, dtype=np.float64)
+    drows, dcand, dcost = t(rows), t(cand), t(cost)          # (kept alive: a temporary's block would be handed to the next allocation)
+    for use_max in (0, 1):
+        for cost_max in (0, 1):
+            reward = rew.max(axis=1) if use_max else rew.mean(axis=1)
+            c = cost.reshape(NC, P).astype(np.float64)
+            c = c.max(axis=1) if cost_max else c.mean(axis=1)
+            want = reward - 7.5 * np.maximum(c, 0.0)
+            dvals, drank = torch.zeros(NC, device=dev), torch.zeros(NC, device=dev, dtype=torch.int32)
+            mean, std = torch.zeros(H, U, device=dev), torch.ones(H, U, device=dev)
+            bv, bs, prev = torch.full((1,), -np.inf, device=dev), torch.zeros(H, U, device=dev), torch.zeros(2, H, U, device=dev)
+            _hip.check(lib.mbpo_icem_update_constrained(drows.data_ptr(), D, X + U, NC, P, H, U, dcand.data_ptr(), 5, 2, 0.1, use_max,
+                                                        dcost.data_ptr(), 7.5, cost_max, mean.data_ptr(), std.data_ptr(), bv.data_ptr(),
+                                                        bs.data_ptr(), prev.data_ptr(), dvals.data_ptr(), drank.data_ptr(), None),
+                       "mbpo_icem_update_constrained")
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(dvals.cpu().numpy(), want, atol=2e-5, rtol=2e-5)
+            assert float(bv) == float(dvals.max())
+
+
+def test_icem_cost_fn_steers_the_plan(dev):
+    """iCemTO(cost_fn=...) (icem_optimizer.py:99,161-166): a torch cost over one trajectory, vmapped over candidates x particles.
+    With the constraint "never push with u < -0.2" the best sequence obeys it; without it the same keys produce a plan that does
+    not — and the constrained optimum matches the numpy loop that applies the same penalty to the oracle's objective."""
+    from mbpo.optimizers import iCemParams, iCemTO
+    from mbpo.systems import PendulumSystem
+    from mbpo.utils import keys as K
+    params = iCemParams(num_particles=2, num_samples=150, num_elites=15, num_steps=4, exponent=1.0, alpha=0.1, init_std=0.6, lambda_constraint=50.0)
+    H = 10
+    system = PendulumSystem()
+    x0 = torch.tensor([-0.8, 0.6, 0.5], device=dev)
+
+    def cost_fn(observation, action):          # one trajectory: [H, 3], [H, 1] -> scalar; positive where the constraint is violated
+        return torch.clamp(-0.2 - action, min=0.0).sum()
+
+    def run(cf):
+        opt = iCemTO(horizon=H, action_dim=1, opt_params=params, key=5, cost_fn=cf)
+        opt.set_system(system)
+        st = opt.init(7)
+        return opt.optimize(x0, st), st
+
+    free, _ = run(None)
+    con, st = run(cost_fn)
+    assert float(free.best_sequence.min()) < -0.3                # the unconstrained plan does push hard (u = -1 from this state)
+    assert float(con.best_sequence.min()) >= -0.2 - 1e-6         # the constrained one does not
+    # numpy loop with the same keys and the same penalty
+    osystem = osys.PendulumSystem()
+
+    def step(x, u):
+        xn, r = osystem.step(torch.from_numpy(x), torch.from_numpy(u))
+        return xn.numpy(), r.numpy()
+
+    mean = np.zeros((H, 1)); std = np.full((H, 1), params.init_std)
+    best_v, best_s = -np.inf, mean.copy()
+    nprev = max(int(params.elite_set_fraction * params.num_elites), 1)
+    prev = np.zeros((nprev, H, 1))
+    carry = K.split(st.key, 2)[0]
+    for it in range(params.num_steps):
+        sampling_key, _pk = K.split(carry, 2)
+        carry = K.split(sampling_key, 2)[0]
+        cand = oicem.sample_candidates(mean, std, prev, -1.0, 1.0, params.num_samples, H, 1, params.exponent, sampling_key, it)
+        vals = oicem.objective(step, x0.cpu().double().numpy(), cand, params.num_particles)
+        vals = vals - params.lambda_constraint * np.maximum(np.clip(-0.2 - cand[:, :, 0], 0.0, None).sum(axis=1), 0.0)
+        mean, std, best_v, best_s, prev = oicem.update(vals, cand, mean, std, best_v, best_s, params.num_elites, nprev, params.alpha)
+    assert abs(float(con.best_reward) - best_v) <= 2e-3 * max(1.0, abs(best_v))
+    np.testing.assert_allclose(con.best_sequence.cpu().numpy(), best_s, atol=5e-3)
