@@ -481,6 +481,16 @@ extern "C" int mbpo_debug_set_rollout_stamps(void *buf) {
 // (Dealing the members 2,2,2,2,4 waves to level the MFMA load per SIMD was tried: the second runner instantiation brought
 // 26 spills back and the kernel got slower, 82 -> 92 us.)
 #define RO64_WAVES 12
+// The thread id, re-derived where it is needed: wave id (an SGPR since the top of the kernel) * 64 + the lane's position from
+// v_mbcnt.  Holding threadIdx.x itself across the step loop made hipcc park it in scratch (one of 168 VGPRs too many): 8 bytes
+// per lane stored at the top of every launch — 1.6 MB of the 2.59 MB the PMC counters saw this kernel write for 0.98 MB of rows
+// (profiles/r02_pmc_traffic.json).  volatile: not hoisted out of the loops, so nothing has to stay live for it.
+__device__ __forceinline__ int ro_tid_now(int wave) {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return (wave << 6) | l;
+}
+
 template <bool WIDE>
 __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs64 AA) {
   extern __shared__ __align__(16) float smem[];
@@ -526,7 +536,7 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const long long env0 = tile * 16;
     {
-      const int tid = opaque(tid_);
+      const int tid = ro_tid_now(wave);
       for (int idx = tid; idx < 16 * X; idx += nthreads) {
         const int r = idx & 15, c = idx >> 4;
         const long long env = env0 + r;
@@ -548,7 +558,7 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
 
 #pragma nounroll
     for (int s = 0; s < A.n_steps; ++s) {
-      const int tid = opaque(tid_), lane = tid & 63;
+      const int tid = ro_tid_now(wave), lane = tid & 63;
       float *s_row = s_rows + (s & 1) * 16 * D4;
       float *steps_cur = s_steps + (s & 1) * 16, *steps_nxt = s_steps + ((s + 1) & 1) * 16;
       WSet<HT, 4> Rp;
@@ -747,7 +757,7 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
     __syncthreads();
     // ---- write back env state ----
     {
-      const int tid = opaque(tid_);
+      const int tid = ro_tid_now(wave);
       const float *steps_fin = s_steps + (A.n_steps & 1) * 16;
       for (int idx = tid; idx < 16 * X; idx += nthreads) {
         const int r = idx & 15, c = idx >> 4;
