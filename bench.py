@@ -506,15 +506,16 @@ def main():
         try:
             sys.path.insert(0, str(ROOT / "scripts"))
             from make_pmc_traffic import source_sha16
-            pmc = json.loads((ROOT / "profiles" / "r02_pmc_traffic.json").read_text())
+            pmc_path = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]        # the newest round's collection
+            pmc = json.loads(pmc_path.read_text())
             cand = {n: v for n, v in pmc["kernels"].items() if n.startswith("k_sac_fwd_bwd<64")}
             k = max(cand.values(), key=lambda v: v["dispatches"])     # the variant this workload launches
             if pmc.get("source_sha16") != source_sha16():
-                traffic_note = ("profiles/r02_pmc_traffic.json was collected on other kernel sources (hash mismatch): refused; "
+                traffic_note = (f"profiles/{pmc_path.name} was collected on other kernel sources (hash mismatch): refused; "
                                 "re-run scripts/collect_pmc.sh + scripts/make_pmc_traffic.py")
             else:
                 traffic = int((k["fetch_kb"] + k["write_kb"]) * 1024)
-                traffic_note = ("FETCH_SIZE + WRITE_SIZE per launch from profiles/r02_pmc_traffic.json (rocprofv3 --pmc, separate passes; "
+                traffic_note = (f"FETCH_SIZE + WRITE_SIZE per launch from profiles/{pmc_path.name} (rocprofv3 --pmc, separate passes; "
                                 "source hash checked); 1.65 MB written = the 16 per-tile gradient slabs the fixed-order cross-tile "
                                 "reduction reads back, 1.1 MB read = weights once per workgroup (48 workgroups, 8 L2s) + the tile rows")
         except Exception as e:      # noqa: BLE001

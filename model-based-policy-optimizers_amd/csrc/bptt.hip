@@ -834,7 +834,7 @@ static int critic_plan(int x_dim, int critic_layers, const int *critic_dims, lon
   *ld_x = ((x_dim + 3) & ~3) + 4;
   *ld_h = 68;
   *lds = sizeof(float) * (16ull * *ld_x + 128 + 128 + 16 + 32 + (size_t)(4 * *LH + 4) * 16 * *ld_h);
-  long long tiles = (batch + 15) / 16, cap = 2LL * bptt_num_cus();
+  long long tiles = (batch + 15) / 16, cap = 1LL * bptt_num_cus();   // one 1024-thread workgroup fills a CU: one slab per CU (see ppo.hip)
   *n_slabs = (int)(tiles < cap ? tiles : cap);
   *total = (long long)*n_slabs * 2 * cr->n_params + ((*n_slabs + 3) & ~3);
   return MBPO_OK;

@@ -147,7 +147,7 @@ static int vjp_plan(const mbpo_mlp_desc *mlp, long long n, VjpPlan *pl, bool nee
   pl->ld_h = 68;
   pl->ld_y = ((md.dims[md.n_layers] + 3) & ~3) + 4;
   pl->lds = sizeof(float) * (3ull * 16 * pl->ld_x + 4ull * 16 * pl->ld_y + (size_t)(4 * pl->LH + 4) * 16 * pl->ld_h);
-  const long long tiles = (n + 15) / 16, cap = 2LL * vjp_num_cus();
+  const long long tiles = (n + 15) / 16, cap = 1LL * vjp_num_cus();   // one 1024-thread workgroup fills a CU: one slab per CU
   pl->n_slabs = (int)(tiles < cap ? tiles : cap);
   pl->total = (long long)pl->n_slabs * md.n_nets * pl->net.n_params;
   return MBPO_OK;

@@ -439,7 +439,10 @@ static int ppo_plan(const mbpo_ppo_desc *d, PpoPlan *pl, bool need_ptrs) {
   pl->lds_fb = sizeof(float) * (16ull * up4(d->row_len) + 16ull * pl->ld_x + (size_t)pl->LH * 4 * 16 * pl->ld_h + 4ull * 16 * pl->ld_h +
                                 4ull * 16 * pl->ld_y + 64);
   long long tiles = (pl->M + 15) / 16;
-  long long cap = 2LL * ppo_num_cus();
+  // one workgroup — one gradient slab — per CU: a workgroup's registers fill a CU (1024 threads x 128 VGPRs, or 512 x 256), so a
+  // second one per CU only waited its turn, and k_ppo_reduce summed twice the slabs (512 x 17 k floats = 35 MB per minibatch at
+  // C3's T = 40: 22 us of a 158 us minibatch_step, rocprofv3 round 3).  Tiles per CU, and so the fwd/bwd time, are unchanged.
+  long long cap = 1LL * ppo_num_cus();
   pl->n_slabs = (int)(tiles < cap ? tiles : cap);
   long long o = 0;
   auto take = [&](long long n) { long long at = o; o += (n + 3) & ~3LL; return at; };

@@ -7,6 +7,6 @@ mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$R/gpurun_out/pmc_$(echo $c | tr A-Z a-z)
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph > $R/gpurun_out/pmc_$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras --no-graph > $R/gpurun_out/pmc_$c.log 2>&1
   echo "$c done: $(find $d -name '*counter_collection.csv' | head -1)"
 done

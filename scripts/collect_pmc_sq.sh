@@ -8,5 +8,5 @@ mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 d=$R/gpurun_out/pmc_sq
 rm -rf $d
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $d -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph > $R/gpurun_out/pmc_sq.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $d -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras --no-graph > $R/gpurun_out/pmc_sq.log 2>&1
 echo "SQ pass done: $(find $d -name '*counter_collection.csv' | head -1)"

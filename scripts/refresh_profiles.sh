@@ -1,8 +1,8 @@
 #!/bin/bash
 # Copy what scripts/collect_profiles.sh + collect_pmc.sh + collect_pmc_sq.sh + the stamp scripts left under gpurun_out/ into
-# profiles/ under a round tag (default r02).  Run in the dev container after the gpurun call has merged gpurun_out/.
+# profiles/ under a round tag (default r03).  Run in the dev container after the gpurun call has merged gpurun_out/.
 set -e
-T=${1:-r02}
+T=${1:-r03}
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd $R
 python scripts/make_pmc_traffic.py gpurun_out/pmc_fetch_size gpurun_out/pmc_write_size profiles/${T}_pmc_traffic.json > /dev/null
