@@ -154,8 +154,21 @@ __global__ void __launch_bounds__(1024) k_moments_fused(const float *x, long lon
 }
 
 // ------------------------------------------------------------------------------------------------ loss fwd/bwd
+// hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp; as sac.hip and rollout.hip): the loss section runs on a few
+// lanes while the other waves of the workgroup wait at its barrier, so its instruction count is tile latency.  libm's
+// expf / log1pf / logf / tanhf are 30-60 instructions each.
+__device__ __forceinline__ float pp_fexp(float x) { return __builtin_amdgcn_exp2f(1.44269504088896340736f * x); }
+__device__ __forceinline__ float pp_flog(float x) { return 0.69314718055994530942f * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float pp_fsoftplus(float x) { return fmaxf(x, 0.0f) + pp_flog(1.0f + pp_fexp(-fabsf(x))); }
+__device__ __forceinline__ float pp_ftanh(float x) {
+  const float e = pp_fexp(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
+  return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+// SP = 2 at H = 64 (512 threads, held to 128 VGPRs by the waves-per-SIMD request): TWO workgroups share a CU, so a tile's chain of
+// dependent layer steps overlaps with another tile's — the launch is a latency chain per tile (MFMA pipes ~17 % busy with one
+// 1024-thread workgroup per CU), not a throughput problem.  The host picks it when there are more tiles than CUs.
 template <int H, int SP, bool WIDE>   // 4 chains x SP waves; WIDE: chain_run.hpp fast_shape
-__global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
+__global__ void __launch_bounds__(256 * SP, (H == 64 && SP == 2) ? 4 : 1) k_ppo_fwd_bwd(PpoArgs A) {
   extern __shared__ __align__(16) float smem[];
   constexpr int HT = H / 16;
   const int tid_ = threadIdx.x, nthreads = 256 * SP;
@@ -173,6 +186,9 @@ __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
   float *s_y = s_pp + 4 * TT;                // [2][16][ld_y]  logits | value
   float *s_dy = s_y + 2 * 16 * ld_y;         // [2][16][ld_y]
   float *s_scal = s_dy + 2 * 16 * ld_y;      // [4][16]
+  float *s_eps = s_scal + 64;                // [16][U]  entropy-sample noise, drawn in the tile-load section
+  float *s_lpt = s_eps + ((16 * U + 3) & ~3);   // [16][U] per-dimension log-prob terms  | then [16][U] entropy terms
+  float *s_ent = s_lpt + ((16 * U + 3) & ~3);
   float *zp = s_store, *hp = s_store + LH * TT, *zv = s_store + 2 * LH * TT, *hv = s_store + 3 * LH * TT;
   float *y_pi = s_y, *y_v = s_y + 16 * ld_y;
   const int PL = A.pi.n_layers, VL = A.v.n_layers;
@@ -208,6 +224,19 @@ __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
         if (A.norm_mean) o = (o - A.norm_mean[c]) / A.norm_std[c];
         s_x[r * ld_x + c] = o;
       }
+      // the entropy sample's noise depends on (seed, offset, element) only: drawn HERE, once, by the last threads of the workgroup
+      // while the tile is in flight (Philox + Box-Muller is ~250 instructions; it used to be drawn twice per element inside the
+      // loss section, on the 16 lanes every other wave waits for)
+      for (int idx = nthreads - 1 - tid; idx < 16 * U; idx += nthreads) {
+        const int r = idx / U, d = idx - r * U;
+        const long long i = r0 + r;
+        float e = 0.f;
+        if (i < M) {
+          const long long nidx = i * U + d;
+          e = A.ent_noise ? A.ent_noise[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_ENTROPY, (unsigned long long)nidx);
+        }
+        s_eps[idx] = e;
+      }
     }
     __syncthreads();
     // ---- forward: policy logits (:80) and value baseline (:82), both stored for the backward
@@ -217,7 +246,23 @@ __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
     else
       chain_idle_run(Lmax);
     if (chain < 2) chain_dgrad_prefetch<HT, SP, WIDE>(R, sh, nparams, sub, lane);
-    // ---- per-sample loss terms and output gradients
+    // ---- per-sample loss terms and output gradients.  Stage 1: one lane per (row, action dim) forms that dimension's log-prob
+    //      and entropy terms; stage 2 (after a barrier of its own: the stage-1 lanes may sit in other waves): one lane per row sums them
+    //      in dimension order, forms rho and the clipped surrogate's weight and writes the value gradient; stage 3: one lane per
+    //      (row, dim) again writes the logits' gradients.  Same arithmetic as the one-lane-per-row loop it replaces.
+    for (int idx = tid; idx < 16 * U; idx += nthreads) {
+      const int r = idx / U, d = idx - r * U;
+      const float *row = s_row + r * D;
+      const float loc = y_pi[r * ld_y + d], raw = y_pi[r * ld_y + U + d];
+      const float sg = pp_fsoftplus(raw) + 0.001f;
+      const float z = row[2 * X + U + 3 + d];                      // raw_action
+      const float q = (z - loc) / sg;
+      const float lsg = pp_flog(sg);
+      s_lpt[idx] = -0.5f * q * q - lsg - LOG_SQRT_2PI - 2.0f * (LOG_2 - z - pp_fsoftplus(-2.0f * z));   // log_prob (:91-92)
+      const float zf = loc + sg * s_eps[idx];
+      s_ent[idx] = 0.5f + LOG_SQRT_2PI + lsg + 2.0f * (LOG_2 - zf - pp_fsoftplus(-2.0f * zf));          // entropy (:117)
+    }
+    __syncthreads();
     if (tid < 16) {
       const int r = tid;
       const long long i = r0 + r;
@@ -228,27 +273,16 @@ __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
       const float vs = ok ? A.vs[i] : 0.f;
       float lp_t = 0.f, ent = 0.f;
       for (int d = 0; d < U; ++d) {
-        const float loc = y_pi[r * ld_y + d], raw = y_pi[r * ld_y + U + d];
-        const float sg = softplus_f(raw) + 0.001f;
-        const float z = row[2 * X + U + 3 + d];                    // raw_action
-        const float q = (z - loc) / sg;
-        lp_t += -0.5f * q * q - logf(sg) - LOG_SQRT_2PI - 2.0f * (LOG_2 - z - softplus_f(-2.0f * z));   // log_prob (:91-92)
-        float eps = 0.f;
-        if (ok) {
-          const long long nidx = i * U + d;
-          eps = A.ent_noise ? A.ent_noise[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_ENTROPY, (unsigned long long)nidx);
-        }
-        const float zf = loc + sg * eps;
-        ent += 0.5f + LOG_SQRT_2PI + logf(sg) + 2.0f * (LOG_2 - zf - softplus_f(-2.0f * zf));           // entropy (:117)
+        lp_t += s_lpt[r * U + d];
+        ent += s_ent[r * U + d];
       }
-      const float rho = expf(lp_t - lp_b);                                                                // :103
+      const float rho = pp_fexp(lp_t - lp_b);                                                             // :103
       const float lo = 1.f - A.clip_eps, hi = 1.f + A.clip_eps;
       const float s1 = rho * adv, s2 = fminf(fmaxf(rho, lo), hi) * adv;
       // d min(s1,s2)/d rho: inside the clip range s1 == s2 (tie, both branches carry adv); outside only s1 can carry it
       const bool inside = (rho >= lo) && (rho <= hi);
       const float w = inside ? 1.f : (s1 < s2 ? 1.f : 0.f);
-      const float g_lp = ok ? -invM * rho * adv * w : 0.f;          // d policy_loss / d lp_t
-      const float g_ent = ok ? -A.entropy_cost * invM : 0.f;        // d entropy_loss / d entropy_i
+      s_scal[48 + r] = ok ? -invM * rho * adv * w : 0.f;            // g_lp = d policy_loss / d lp_t
       const float v = y_v[r * ld_y];
       if (ok) {
         loss_pol += -fminf(s1, s2);
@@ -256,23 +290,25 @@ __global__ void __launch_bounds__(256 * SP) k_ppo_fwd_bwd(PpoArgs A) {
         loss_ent += ent;
       }
       s_dy[(16 + r) * ld_y] = ok ? -(vs - v) * invM : 0.f;          // d (0.5*mean((vs-V)^2)) / dV   (:112-114)
-      for (int d = 0; d < U; ++d) {
-        const float loc = y_pi[r * ld_y + d], raw = y_pi[r * ld_y + U + d];
-        const float sg = softplus_f(raw) + 0.001f;
-        const float z = row[2 * X + U + 3 + d];
-        const float q = (z - loc) / sg;
-        float eps = 0.f;
-        if (ok) {
-          const long long nidx = i * U + d;
-          eps = A.ent_noise ? A.ent_noise[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_ENTROPY, (unsigned long long)nidx);
-        }
-        const float th = tanhf(loc + sg * eps);
-        // lp_t: d/dloc = q/sg, d/dsigma = (q*q - 1)/sg ; entropy: d/dloc = -2 tanh(zf), d/dsigma = 1/sg - 2 tanh(zf) eps
-        const float g_loc = g_lp * (q / sg) + g_ent * (-2.f * th);
-        const float g_sig = g_lp * ((q * q - 1.f) / sg) + g_ent * (1.f / sg - 2.f * th * eps);
-        s_dy[r * ld_y + d] = g_loc;
-        s_dy[r * ld_y + U + d] = g_sig * sigmoid_f(raw);
-      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 16 * U; idx += nthreads) {
+      const int r = idx / U, d = idx - r * U;
+      const bool ok = r0 + r < M;
+      const float *row = s_row + r * D;
+      const float g_lp = s_scal[48 + r];
+      const float g_ent = ok ? -A.entropy_cost * invM : 0.f;        // d entropy_loss / d entropy_i
+      const float loc = y_pi[r * ld_y + d], raw = y_pi[r * ld_y + U + d];
+      const float sg = pp_fsoftplus(raw) + 0.001f;
+      const float z = row[2 * X + U + 3 + d];
+      const float q = (z - loc) / sg;
+      const float eps = s_eps[idx];
+      const float th = pp_ftanh(loc + sg * eps);
+      // lp_t: d/dloc = q/sg, d/dsigma = (q*q - 1)/sg ; entropy: d/dloc = -2 tanh(zf), d/dsigma = 1/sg - 2 tanh(zf) eps
+      const float g_loc = g_lp * (q / sg) + g_ent * (-2.f * th);
+      const float g_sig = g_lp * ((q * q - 1.f) / sg) + g_ent * (1.f / sg - 2.f * th * eps);
+      s_dy[r * ld_y + d] = g_loc;
+      s_dy[r * ld_y + U + d] = g_sig * fast_sigmoid(raw);
     }
     __syncthreads();
     // ---- backward: chains 0/1 push delta down (policy / value), chains 2/3 accumulate dW/db into this WG's slab
@@ -316,6 +352,8 @@ struct PpoReduceArgs {
 };
 
 __global__ void __launch_bounds__(256) k_ppo_reduce(PpoReduceArgs A) {
+  // (16 waves per workgroup instead of 4 — four times the loads in flight per CU — changed nothing at 512 slabs: 23.5 vs 22.7 us for
+  //  35 MB.  The sum reads 256-byte pieces 68 KB apart: it is bound by that access pattern, not by latency.)
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
   const float gsum = slab_sum_wg64(A.slabs, A.NPV, A.n_slabs, i, i < A.NPV);
   if (threadIdx.x < 64 && i < A.NPV) A.grads[i] = gsum;
@@ -373,6 +411,7 @@ __global__ void __launch_bounds__(256) k_ppo_apply(PpoApplyArgs A) {
 struct PpoPlan {
   MlpDev pi, v;
   int P, V, NPV, H, LH, n_slabs;
+  int sp2;            // H == 64, one-tile network ends, more tiles than CUs: the two-workgroups-per-CU launch (k_ppo_fwd_bwd<64, 2>)
   long long M;
   int ld_x, ld_h, ld_y;
   size_t lds_values, lds_fb;
@@ -437,12 +476,17 @@ static int ppo_plan(const mbpo_ppo_desc *d, PpoPlan *pl, bool need_ptrs) {
   pl->ld_y = up4(2 * d->u_dim) + 4;
   pl->lds_values = sizeof(float) * (16ull * pl->ld_x + 2ull * 16 * pl->ld_h + 16ull * pl->ld_y);
   pl->lds_fb = sizeof(float) * (16ull * up4(d->row_len) + 16ull * pl->ld_x + (size_t)pl->LH * 4 * 16 * pl->ld_h + 4ull * 16 * pl->ld_h +
-                                4ull * 16 * pl->ld_y + 64);
+                                4ull * 16 * pl->ld_y + 64 + 3ull * ((16 * d->u_dim + 3) & ~3));
   long long tiles = (pl->M + 15) / 16;
-  // one workgroup — one gradient slab — per CU: a workgroup's registers fill a CU (1024 threads x 128 VGPRs, or 512 x 256), so a
-  // second one per CU only waited its turn, and k_ppo_reduce summed twice the slabs (512 x 17 k floats = 35 MB per minibatch at
-  // C3's T = 40: 22 us of a 158 us minibatch_step, rocprofv3 round 3).  Tiles per CU, and so the fwd/bwd time, are unchanged.
-  long long cap = 1LL * ppo_num_cus();
+  // one gradient slab per RESIDENT workgroup: a 1024-thread (or 512 x 256-VGPR) workgroup fills a CU's registers, so more of them
+  // per CU only waited their turn while k_ppo_reduce summed twice the slabs (512 x 17 k floats = 35 MB per minibatch at C3's
+  // T = 40: 22 us of a 158 us minibatch_step, rocprofv3 round 3).  The 512-thread / 128-VGPR launch (sp2) holds two per CU.
+  {
+    const NetShape sp_ = NetShape{d->x_dim, d->policy_layers, 2 * d->u_dim, 0}, sv_ = NetShape{d->x_dim, d->value_layers, 1, 0};
+    static const int sp2_env = getenv("MBPO_PPO_SP2") ? atoi(getenv("MBPO_PPO_SP2")) : -1;
+    pl->sp2 = (Hp == 64 && !net_is_wide(sp_) && !net_is_wide(sv_) && tiles > ppo_num_cus() && sp2_env != 0) ? 1 : 0;
+  }
+  long long cap = (pl->sp2 ? 2LL : 1LL) * ppo_num_cus();
   pl->n_slabs = (int)(tiles < cap ? tiles : cap);
   long long o = 0;
   auto take = [&](long long n) { long long at = o; o += (n + 3) & ~3LL; return at; };
@@ -518,7 +562,11 @@ extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
     const bool wide = net_is_wide(A.sh_pi) || net_is_wide(A.sh_v);
     rc = wide ? mbpo_ensure_lds<k_ppo_fwd_bwd<64, 4, true>>(pl.lds_fb, "ppo_grads") : mbpo_ensure_lds<k_ppo_fwd_bwd<64, 4, false>>(pl.lds_fb, "ppo_grads");
     if (rc != MBPO_OK) return rc;
-    if (wide) hipLaunchKernelGGL((k_ppo_fwd_bwd<64, 4, true>), dim3(pl.n_slabs), dim3(1024), pl.lds_fb, st, A);
+    if (pl.sp2) {
+      rc = mbpo_ensure_lds<k_ppo_fwd_bwd<64, 2, false>>(pl.lds_fb, "ppo_grads");
+      if (rc != MBPO_OK) return rc;
+      hipLaunchKernelGGL((k_ppo_fwd_bwd<64, 2, false>), dim3(pl.n_slabs), dim3(512), pl.lds_fb, st, A);
+    } else if (wide) hipLaunchKernelGGL((k_ppo_fwd_bwd<64, 4, true>), dim3(pl.n_slabs), dim3(1024), pl.lds_fb, st, A);
     else hipLaunchKernelGGL((k_ppo_fwd_bwd<64, 4, false>), dim3(pl.n_slabs), dim3(1024), pl.lds_fb, st, A);
   } else {
     rc = mbpo_ensure_lds<k_ppo_fwd_bwd<128, 2, false>>(pl.lds_fb, "ppo_grads");
