@@ -241,3 +241,36 @@ __device__ __forceinline__ float slab_sum_wg64(const float *slab, long long stri
   __syncthreads();
   return q == 0 ? ((s_q[0][p] + s_q[1][p]) + s_q[2][p]) + s_q[3][p] : 0.f;
 }
+
+// First stage of a two-stage sum of MANY long slabs: workgroup (g, c) adds slabs 16 g .. 16 g + 15 over the column block
+// [1024 c, 1024 c + 1024) — sixteen 4-KB runs, each contiguous — and leaves the result IN slab 16 g (it alone reads those columns
+// of those slabs).  The second stage is the ordinary strided sum over slabs 0, 16, 32, ... (slab_sum_wg64 with stride 16 * stride).
+// Fixed order ((s0 + .. + s15) + (s16 + ..) + ..): deterministic.  256 threads; thread t owns columns c0 + t + 256 k, k < 4.
+__device__ __forceinline__ void slab_group16_sum(float *slab, long long stride, int n, long long n_cols) {
+  const int g = blockIdx.y;
+  const long long c0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+  const int t0 = g * 16, t1 = (t0 + 16 < n) ? t0 + 16 : n;
+  bool ok[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ok[k] = c0 + 256 * k < n_cols;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int t = t0;
+  for (; t + 8 <= t1; t += 8) {
+    float v[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[u][k] = ok[k] ? slab[(long long)(t + u) * stride + c0 + 256 * k] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += v[u][k];
+  }
+  for (; t < t1; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += ok[k] ? slab[(long long)t * stride + c0 + 256 * k] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (ok[k]) slab[(long long)t0 * stride + c0 + 256 * k] = acc[k];
+}
+

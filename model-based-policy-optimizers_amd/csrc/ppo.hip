@@ -345,40 +345,62 @@ __global__ void __launch_bounds__(256 * SP, (H == 64 && SP == 2) ? 4 : 1) k_ppo_
 
 struct PpoReduceArgs {
   const float *slabs, *extras;
-  int n_slabs, NPV;
+  int n_slabs, NPV, slab_step;
   long long M;
   float entropy_cost;
   float *grads, *metrics, *metrics_accum, *step_count;
 };
 
+// stage 1 of the two-stage slab sum (many slabs): groups of 16 slabs, 4-KB contiguous runs (common.hpp slab_group16_sum)
+__global__ void __launch_bounds__(256) k_ppo_reduce_groups(float *slabs, int NPV, int n_slabs) { slab_group16_sum(slabs, NPV, n_slabs, NPV); }
+
 __global__ void __launch_bounds__(256) k_ppo_reduce(PpoReduceArgs A) {
-  // (16 waves per workgroup instead of 4 — four times the loads in flight per CU — changed nothing at 512 slabs: 23.5 vs 22.7 us for
-  //  35 MB.  The sum reads 256-byte pieces 68 KB apart: it is bound by that access pattern, not by latency.)
+  // (A.slab_step = 16 after k_ppo_reduce_groups: the group sums sit in slabs 0, 16, 32, ...)
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-  const float gsum = slab_sum_wg64(A.slabs, A.NPV, A.n_slabs, i, i < A.NPV);
+  const float gsum = slab_sum_wg64(A.slabs, (long long)A.NPV * A.slab_step, (A.n_slabs + A.slab_step - 1) / A.slab_step, i, i < A.NPV);
   if (threadIdx.x < 64 && i < A.NPV) A.grads[i] = gsum;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    // (what this thread read-modify-writes is requested before its slab sums: behind them, one after the other — with a load of
-    //  what it had just stored among them — these round trips were the tail of the launch, as in k_sac_reduce_apply)
-    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    if (A.metrics_accum) {
+  if (blockIdx.x == 0) {
+    // The loss partials (three per slab) are summed by the whole workgroup: thread t takes slabs t, t + 256, ..., then a fixed tree
+    // over the 256 partial sums in LDS.  ONE thread walking 3 x n_slabs values (its loads in dependent batches of 16) was the
+    // launch: 21.6 us at 512 slabs with the gradient sum itself done in 3 (rocprofv3, round 3).
+    __shared__ float s_e[3][256];
+    const int t = threadIdx.x;
+    float e[3] = {0.f, 0.f, 0.f};
+    for (int sl = t; sl < A.n_slabs; sl += 256) {
 #pragma unroll
-      for (int k = 0; k < 5; ++k) acc[k] = A.metrics_accum[k];
+      for (int k = 0; k < 3; ++k) e[k] += A.extras[(long long)sl * 4 + k];
     }
-    const float count = A.step_count[0];
-    const float a = slab_sum<16>(A.extras, 4, A.n_slabs, 0), b = slab_sum<16>(A.extras, 4, A.n_slabs, 1),
-                c = slab_sum<16>(A.extras, 4, A.n_slabs, 2);
-    const float invM = 1.0f / (float)A.M;
-    const float pl = a * invM, vl = b * invM, el = A.entropy_cost * -(c * invM);
-    const float m[4] = {pl + vl + el, pl, vl, el};   // m[0]: total_loss
 #pragma unroll
-    for (int k = 0; k < 4; ++k) A.metrics[k] = m[k];
-    if (A.metrics_accum) {
+    for (int k = 0; k < 3; ++k) s_e[k][t] = e[k];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (t < w) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) A.metrics_accum[k] = acc[k] + m[k];
-      A.metrics_accum[4] = acc[4] + 1.0f;
+        for (int k = 0; k < 3; ++k) s_e[k][t] += s_e[k][t + w];
+      }
+      __syncthreads();
     }
-    A.step_count[0] = count + 1.0f;
+    if (t == 0) {
+      // (what this thread read-modify-writes is requested together)
+      float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      if (A.metrics_accum) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[k] = A.metrics_accum[k];
+      }
+      const float count = A.step_count[0];
+      const float a = s_e[0][0], b = s_e[1][0], c = s_e[2][0];
+      const float invM = 1.0f / (float)A.M;
+      const float pl = a * invM, vl = b * invM, el = A.entropy_cost * -(c * invM);
+      const float m[4] = {pl + vl + el, pl, vl, el};   // m[0]: total_loss
+#pragma unroll
+      for (int k = 0; k < 4; ++k) A.metrics[k] = m[k];
+      if (A.metrics_accum) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) A.metrics_accum[k] = acc[k] + m[k];
+        A.metrics_accum[4] = acc[4] + 1.0f;
+      }
+      A.step_count[0] = count + 1.0f;
+    }
   }
 }
 
@@ -577,6 +599,14 @@ extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
   PpoReduceArgs R;
   R.slabs = A.slabs; R.extras = A.extras; R.n_slabs = pl.n_slabs; R.NPV = pl.NPV; R.M = pl.M; R.entropy_cost = d->entropy_cost;
   R.grads = d->grads; R.metrics = d->metrics; R.metrics_accum = d->metrics_accum; R.step_count = d->step_count;
+  // The one-stage sum reads 256-byte pieces 68 KB apart: 22.7 us for the 35 MB of 512 slabs (C3, T = 40), unchanged by 4x the loads
+  // in flight or by 1-KB pieces.  With many slabs: first groups of 16 over 4-KB contiguous runs, in place, then the 32 group sums.
+  R.slab_step = 1;
+  if (pl.n_slabs >= 64) {
+    hipLaunchKernelGGL(k_ppo_reduce_groups, dim3((pl.NPV + 1023) / 1024, (pl.n_slabs + 15) / 16), dim3(256), 0, st, A.slabs, pl.NPV,
+                       pl.n_slabs);
+    R.slab_step = 16;
+  }
   hipLaunchKernelGGL(k_ppo_reduce, dim3((pl.NPV + 63) / 64), dim3(256), 0, st, R);
   MBPO_CHECK_LAUNCH("ppo_grads");
   return MBPO_OK;
