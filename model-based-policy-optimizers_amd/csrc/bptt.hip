@@ -119,6 +119,17 @@ __device__ __forceinline__ float reward_grad_comp(const BpttArgs &A, const float
   return c < X ? g * (-2.f * qp[c] * (xu[c] - tp[c])) : g * (-2.f * rp[c - X] * xu[c]);
 }
 
+// hardware transcendentals for the elementwise sections (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp, as in sac.hip / ppo.hip): at
+// u = 6 a section is 96 elements on two of the eight waves — its libm calls (expf, log1pf, logf x3, tanhf: 30-60 instructions
+// each) were the section's whole time while the other waves waited at its barrier.
+__device__ __forceinline__ float bp_fexp(float x) { return __builtin_amdgcn_exp2f(1.44269504088896340736f * x); }
+__device__ __forceinline__ float bp_flog(float x) { return 0.69314718055994530942f * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float bp_fsoftplus(float x) { return fmaxf(x, 0.0f) + bp_flog(1.0f + bp_fexp(-fabsf(x))); }
+__device__ __forceinline__ float bp_ftanh(float x) {
+  const float e = bp_fexp(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
+  return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
 template <int H, bool WIDE>
 __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
   extern __shared__ __align__(16) float smem[];
@@ -324,14 +335,14 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
             const int r = idx / U, d = idx - r * U;
             const long long i = row0 + r;
             const float mu = s_y[r * ld_y + d];
-            const float sg = fminf(fmaxf(softplus_f(s_y[r * ld_y + U + d] + A.c0), 1e-6f), 1e2f);
+            const float sg = fminf(fmaxf(bp_fsoftplus(s_y[r * ld_y + U + d] + A.c0), 1e-6f), 1e2f);
             float eps = 0.f;
             if (i < A.n) {
               const long long nidx = (i * HZ + t) * U + d;
               eps = A.act_noise ? A.act_noise[nidx] : philox_normal(rng_seed, rng_off, MBPO_STREAM_POLICY_NOISE, (unsigned long long)nidx);
               A.w_eps[nidx] = eps;
             }
-            const float a = fminf(fmaxf(tanhf(mu + eps * sg), -0.999f), 0.999f);   // squash_action (:313-317)
+            const float a = fminf(fmaxf(bp_ftanh(mu + eps * sg), -0.999f), 0.999f);   // squash_action (:313-317)
             s_xu[r * ld_xu + X + d] = a;
             if (i < A.n) A.w_as[(i * HZ + t) * U + d] = a;
           }
@@ -489,17 +500,17 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
             const int r = idx / U, d = idx - r * U;
             const bool ok = row0 + r < A.n;
             const float mu = s_y[r * ld_y + d], sraw = s_y[r * ld_y + U + d] + A.c0;
-            const float sp = softplus_f(sraw);
+            const float sp = bp_fsoftplus(sraw);
             const bool sin_ = (sp > 1e-6f) && (sp < 1e2f);
             const float sg = fminf(fmaxf(sp, 1e-6f), 1e2f);
-            const float dsig = sin_ ? sigmoid_f(sraw) : 0.f;
+            const float dsig = sin_ ? fast_sigmoid(sraw) : 0.f;
             const float a = s_a[r * U + d], eps = s_eps[r * U + d];
-            const float th = tanhf(mu + eps * sg);
+            const float th = bp_ftanh(mu + eps * sg);
             const float dadw = (th > -0.999f && th < 0.999f) ? (1.f - th * th) : 0.f;
             const float om = 1.f - a * a;
-            const float u = 0.5f * logf((1.f + a) / (1.f - a));            // atanh(a)   (:111-120)
+            const float u = 0.5f * bp_flog((1.f + a) * __builtin_amdgcn_rcpf(1.f - a));            // atanh(a)   (:111-120)
             const float q = (u - mu) / sg;
-            const float lp = -0.5f * q * q - logf(sg) - LOG_SQRT_2PI_B - logf(om);
+            const float lp = -0.5f * q * q - bp_flog(sg) - LOG_SQRT_2PI_B - bp_flog(om);
             const float dlp_da = (-q / sg) / om + 2.f * a / om;
             const float Ga = s_dxu[r * ld_xu + X + d] + reward_grad_comp(A, s_xu + r * ld_xu, ok ? s_gR[t] / r_std : 0.f, X + d) + w_lp * dlp_da;
             const float l_mu = w_lp * (q / sg), l_sr = w_lp * ((q * q - 1.f) / sg) * dsig;
