@@ -362,6 +362,9 @@ typedef struct mbpo_ppo_desc {
 int64_t mbpo_ppo_workspace_floats(const mbpo_ppo_desc *d);
 int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream);
 int mbpo_ppo_apply(const mbpo_ppo_desc *d, void *stream);
+/* mbpo_ppo_grads + mbpo_ppo_apply with no seam for a collective between them (a single rank): the launch that sums the gradient
+ * also applies AdamW to it — the same bits, one launch less per minibatch_step (ppo/ppo.py:142-156). */
+int mbpo_ppo_step(const mbpo_ppo_desc *d, void *stream);
 
 /* ---- B1-B5: BPTT actor gradient (bptt_optimizer.py:327-378) -----------------------------------------
  * replaces: value_and_grad(vmap(actor_loss)) of BPTTOptimizer._train_step, i.e. rollout_policy with stop_grads=True

@@ -30,6 +30,8 @@ struct PpoArgs {
   float *baseline, *boot, *trunc, *term, *rew, *vs, *adv, *mom, *slabs, *extras;
   int n_slabs;
   int ld_x, ld_h, ld_y, LH;
+  float *step_count_rw;      // optax's count: bumped by block 0 of the FIRST launch of a minibatch_step (k_ppo_values), so that every
+                             // later launch of the step — the reduce launch that also applies AdamW, or k_ppo_apply — reads the final value
 };
 
 // ------------------------------------------------------------------------------------------------ values pre-pass
@@ -45,6 +47,7 @@ __global__ void __launch_bounds__(256) k_ppo_values(PpoArgs A) {
   float *s_pp = s_x + 16 * A.ld_x;           // 2 hidden tiles
   float *s_y = s_pp + 2 * 16 * A.ld_h;       // [16][ld_y]
   const long long n_tiles = (rows + 15) >> 4;
+  if (blockIdx.x == 0 && tid_ == 0) A.step_count_rw[0] = A.step_count_rw[0] + 1.0f;     // (nothing in this launch reads it)
 #pragma nounroll
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int tid = opaque(tid_), lane = tid & 63;
@@ -348,7 +351,11 @@ struct PpoReduceArgs {
   int n_slabs, NPV, slab_step;
   long long M;
   float entropy_cost;
-  float *grads, *metrics, *metrics_accum, *step_count;
+  float *grads, *metrics, *metrics_accum;
+  const float *step_count;   // already this step's count (k_ppo_values bumped it)
+  // fused optimizer step (mbpo_ppo_step: no all-reduce sits between the gradient and AdamW): params != nullptr
+  float *params, *adam_m, *adam_v;
+  float lr, wd, grad_scale;
 };
 
 // stage 1 of the two-stage slab sum (many slabs): groups of 16 slabs, 4-KB contiguous runs (common.hpp slab_group16_sum)
@@ -358,7 +365,24 @@ __global__ void __launch_bounds__(256) k_ppo_reduce(PpoReduceArgs A) {
   // (A.slab_step = 16 after k_ppo_reduce_groups: the group sums sit in slabs 0, 16, 32, ...)
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
   const float gsum = slab_sum_wg64(A.slabs, (long long)A.NPV * A.slab_step, (A.n_slabs + A.slab_step - 1) / A.slab_step, i, i < A.NPV);
-  if (threadIdx.x < 64 && i < A.NPV) A.grads[i] = gsum;
+  if (threadIdx.x < 64 && i < A.NPV) {
+    A.grads[i] = gsum;
+    if (A.params) {
+      // k_ppo_apply's arithmetic on the element this thread has just summed: one launch less per minibatch_step, the same bits
+      const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+      const float count = A.step_count[0];
+      const float g = gsum * A.grad_scale;
+      const float mu = b1 * A.adam_m[i] + 0.1f * g;
+      const float nu = b2 * A.adam_v[i] + 0.001f * (g * g);
+      A.adam_m[i] = mu;
+      A.adam_v[i] = nu;
+      const float mu_hat = mu / (1.f - powf(b1, count));
+      const float nu_hat = nu / (1.f - powf(b2, count));
+      const float p = A.params[i];
+      const float upd = mu_hat / (sqrtf(nu_hat) + eps) + A.wd * p;
+      A.params[i] = p + (-A.lr) * upd;
+    }
+  }
   if (blockIdx.x == 0) {
     // The loss partials (three per slab) are summed by the whole workgroup: thread t takes slabs t, t + 256, ..., then a fixed tree
     // over the 256 partial sums in LDS.  ONE thread walking 3 x n_slabs values (its loads in dependent batches of 16) was the
@@ -387,7 +411,6 @@ __global__ void __launch_bounds__(256) k_ppo_reduce(PpoReduceArgs A) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) acc[k] = A.metrics_accum[k];
       }
-      const float count = A.step_count[0];
       const float a = s_e[0][0], b = s_e[1][0], c = s_e[2][0];
       const float invM = 1.0f / (float)A.M;
       const float pl = a * invM, vl = b * invM, el = A.entropy_cost * -(c * invM);
@@ -399,7 +422,6 @@ __global__ void __launch_bounds__(256) k_ppo_reduce(PpoReduceArgs A) {
         for (int k = 0; k < 4; ++k) A.metrics_accum[k] = acc[k] + m[k];
         A.metrics_accum[4] = acc[4] + 1.0f;
       }
-      A.step_count[0] = count + 1.0f;
     }
   }
 }
@@ -529,7 +551,7 @@ extern "C" int64_t mbpo_ppo_workspace_floats(const mbpo_ppo_desc *d) {
   return pl.total;
 }
 
-extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
+static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply) {
   PpoPlan pl;
   int rc = ppo_plan(d, &pl, true);
   if (rc != MBPO_OK) return rc;
@@ -542,6 +564,7 @@ extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
   A.sh_v = NetShape{pl.v.dims[0], pl.v.n_layers, pl.v.dims[pl.v.n_layers], pl.v.act};
   A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.T = d->unroll_length; A.D = d->row_len;
   A.data = d->data; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std; A.ent_noise = d->entropy_noise;
+  A.step_count_rw = d->step_count;
   A.seed = d->seed; A.offset = d->offset; A.rng_dev = (const unsigned long long *)d->rng_dev;
   A.entropy_cost = d->entropy_cost; A.discounting = d->discounting; A.reward_scaling = d->reward_scaling;
   A.gae_lambda = d->gae_lambda; A.clip_eps = d->clipping_epsilon; A.normalize_advantage = d->normalize_advantage;
@@ -599,6 +622,8 @@ extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
   PpoReduceArgs R;
   R.slabs = A.slabs; R.extras = A.extras; R.n_slabs = pl.n_slabs; R.NPV = pl.NPV; R.M = pl.M; R.entropy_cost = d->entropy_cost;
   R.grads = d->grads; R.metrics = d->metrics; R.metrics_accum = d->metrics_accum; R.step_count = d->step_count;
+  R.params = fuse_apply ? d->params : nullptr; R.adam_m = d->adam_m; R.adam_v = d->adam_v;
+  R.lr = d->lr; R.wd = d->wd; R.grad_scale = d->grad_scale;
   // The one-stage sum reads 256-byte pieces 68 KB apart: 22.7 us for the 35 MB of 512 slabs (C3, T = 40), unchanged by 4x the loads
   // in flight or by 1-KB pieces.  With many slabs: first groups of 16 over 4-KB contiguous runs, in place, then the 32 group sums.
   R.slab_step = 1;
@@ -611,6 +636,12 @@ extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) {
   MBPO_CHECK_LAUNCH("ppo_grads");
   return MBPO_OK;
 }
+
+extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) { return ppo_grads_impl(d, stream, false); }
+
+// One minibatch_step without a seam for a collective: the reduce launch applies AdamW to the elements it has just summed
+// (k_ppo_apply's arithmetic, bit for bit) — six launches instead of seven.
+extern "C" int mbpo_ppo_step(const mbpo_ppo_desc *d, void *stream) { return ppo_grads_impl(d, stream, true); }
 
 extern "C" int mbpo_ppo_apply(const mbpo_ppo_desc *d, void *stream) {
   PpoPlan pl;

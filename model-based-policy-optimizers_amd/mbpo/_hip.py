@@ -221,7 +221,7 @@ def _bind_optional(lib: C.CDLL) -> None:
     if fn is not None:
         fn.restype = C.c_int
         fn.argtypes = [C.POINTER(SacDesc), vp, u64, vp]
-    for name in ("mbpo_ppo_grads", "mbpo_ppo_apply"):
+    for name in ("mbpo_ppo_grads", "mbpo_ppo_apply", "mbpo_ppo_step"):
         fn = getattr(lib, name, None)
         if fn is not None:
             fn.restype = C.c_int

@@ -755,6 +755,7 @@ class PpoUpdater:
         self.params, self.adam_m, self.adam_v, self.grads = f(self.NPV), f(self.NPV), f(self.NPV), f(self.NPV)
         self.step_count, self.metrics, self.metrics_accum = f(1), f(4), f(5)
         self.all_reduce, self.world_size = all_reduce, world_size
+        self.fused_step = os.environ.get("MBPO_PPO_FUSED_STEP", "1") != "0"     # mbpo_ppo_step (single rank) vs grads + apply
         d = _hip.PpoDesc()
         d.x_dim, d.u_dim = x_dim, u_dim
         d.policy_layers, d.value_layers = len(policy_dims) - 1, len(value_dims) - 1
@@ -809,6 +810,9 @@ class PpoUpdater:
             d.seed = seed
         d.rng_dev = rng_ptr(rng_dev)
         st = current_stream_ptr()
+        if self.all_reduce is None and self.fused_step:
+            check(self.lib.mbpo_ppo_step(C.byref(d), st), "mbpo_ppo_step")      # the reduce launch applies AdamW: one launch less
+            return
         check(self.lib.mbpo_ppo_grads(C.byref(d), st), "mbpo_ppo_grads")
         if self.all_reduce is not None:
             self.all_reduce(self.grads)

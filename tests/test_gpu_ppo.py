@@ -123,3 +123,35 @@ def test_ppo_step_against_committed_golden(dev):
     torch.cuda.synchronize()
     torch.testing.assert_close(up.grads.cpu().double(), torch.from_numpy(gold["grads"]), atol=2e-6, rtol=3e-4)
     np.testing.assert_allclose(up.metrics.cpu().numpy(), gold["losses"], rtol=2e-5, atol=1e-5)
+
+
+def test_ppo_fused_step_equals_grads_plus_apply(dev):
+    """mbpo_ppo_step (the reduce launch applies AdamW to what it has just summed) against mbpo_ppo_grads + mbpo_ppo_apply on the same
+    state and minibatches: four chained steps, BIT-identical parameters, moments, count, gradients and metrics — for the few-slab
+    (one-stage sum) and the many-slab (two-stage sum, two workgroups per CU) shapes."""
+    from mbpo import ops
+    X, U = 4, 1
+    for B, T in ((32, 5), (512, 40)):
+        g = torch.Generator().manual_seed(B)
+        pd, vd = [X, 64, 64, 2 * U], [X, 64, 64, 1]
+        ups = []
+        for fused in (True, False):
+            up = ops.PpoUpdater(x_dim=X, u_dim=U, policy_dims=pd, value_dims=vd, batch_size=B, unroll_length=T, device=dev, lr=1e-3, wd=1e-4)
+            up.fused_step = fused
+            ups.append(up)
+        init = torch.randn(ups[0].NPV, generator=g) * 0.1
+        for up in ups:
+            up.load_state(init.to(dev))
+        D = 2 * X + 2 * U + 4
+        for it in range(4):
+            data = torch.randn(B, T, D, generator=g)
+            data[..., X + U + 1] = 1.0                                   # discount
+            data[..., D - 1] = (torch.rand(B, T, generator=g) < 0.05).float()
+            data = data.to(dev)
+            for up in ups:
+                up.minibatch_step(data, offset=it << 32, seed=9)
+        torch.cuda.synchronize()
+        a, b = ups
+        assert float(a.step_count) == float(b.step_count) == 4
+        for name in ("params", "adam_m", "adam_v", "grads", "metrics"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (B, T, name)
