@@ -30,6 +30,7 @@ struct PpoArgs {
   float *baseline, *boot, *trunc, *term, *rew, *vs, *adv, *mom, *slabs, *extras;
   int n_slabs;
   int ld_x, ld_h, ld_y, LH;
+  int mom_inline;            // 1: k_ppo_fwd_bwd forms the advantage moments itself (no k_moments_fused launch)
   float *step_count_rw;      // optax's count: bumped by block 0 of the FIRST launch of a minibatch_step (k_ppo_values), so that every
                              // later launch of the step — the reduce launch that also applies AdamW, or k_ppo_apply — reads the final value
 };
@@ -197,8 +198,63 @@ __global__ void __launch_bounds__(256 * SP, (H == 64 && SP == 2) ? 4 : 1) k_ppo_
   const int PL = A.pi.n_layers, VL = A.v.n_layers;
   const int Lmax = PL > VL ? PL : VL;
   const float invM = 1.0f / (float)M;
-  const float adv_mean = A.normalize_advantage ? A.mom[0] : 0.f;
-  const float adv_istd = A.normalize_advantage ? 1.0f / (A.mom[1] + 1e-8f) : 1.f;          // losses.py:101-102
+  // Advantage moments over the WHOLE minibatch (losses.py:101-102), formed here by every workgroup for itself when the minibatch is
+  // small enough (mom_inline): k_moments_fused's arithmetic in k_moments_fused's order — its 1024 threads are VIRTUAL here, thread t
+  // of a 512-thread workgroup playing t and t + 512 — so the numbers are bit for bit the separate launch's, which this removes
+  // (one launch of seven per minibatch_step; at T = 5 the step is launch-bound).  M floats from L2 per workgroup.
+  float adv_mean = 0.f, adv_istd = 1.f;
+  if (A.normalize_advantage && !A.mom_inline) {
+    adv_mean = A.mom[0];
+    adv_istd = 1.0f / (A.mom[1] + 1e-8f);
+  } else if (A.normalize_advantage) {
+    __shared__ float s_mw[16];
+    __shared__ float s_mm[2];
+    constexpr int VT = 1024 / (256 * SP);            // virtual threads per thread: 1 or 2
+    float acc[VT];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      acc[v] = 0.f;
+#pragma unroll 4
+      for (long long i = tid_ + v * nthreads; i < M; i += 1024) acc[v] += A.adv[i];
+      acc[v] = ppo_wave_sum(acc[v]);
+      if ((tid_ & 63) == 0) s_mw[(tid_ >> 6) + v * (nthreads >> 6)] = acc[v];
+    }
+    __syncthreads();
+    if (tid_ == 0) {
+      float a = 0.f;
+      for (int k = 0; k < 16; ++k) a += s_mw[k];
+      s_mm[0] = a / (float)M;
+    }
+    __syncthreads();
+    const float mean = s_mm[0];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      acc[v] = 0.f;
+#pragma unroll 4
+      for (long long i = tid_ + v * nthreads; i < M; i += 1024) {
+        const float dd = A.adv[i] - mean;
+        acc[v] += dd * dd;
+      }
+      acc[v] = ppo_wave_sum(acc[v]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < VT; ++v)
+      if ((tid_ & 63) == 0) s_mw[(tid_ >> 6) + v * (nthreads >> 6)] = acc[v];
+    __syncthreads();
+    if (tid_ == 0) {
+      float a = 0.f;
+      for (int k = 0; k < 16; ++k) a += s_mw[k];
+      s_mm[1] = sqrtf(a / (float)M);                 // population std (jnp.std)
+      if (blockIdx.x == 0) {
+        A.mom[0] = mean;
+        A.mom[1] = s_mm[1];
+      }
+    }
+    __syncthreads();
+    adv_mean = mean;
+    adv_istd = 1.0f / (s_mm[1] + 1e-8f);
+  }
   const RngKey rk_ = rng_resolve(A.seed, A.offset, A.rng_dev);
   const unsigned long long rng_off = rk_.offset, rng_seed = rk_.seed;
   float *slab = A.slabs + (long long)blockIdx.x * (A.pi.n_params + A.v.n_params);
@@ -565,6 +621,12 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
   A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.T = d->unroll_length; A.D = d->row_len;
   A.data = d->data; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std; A.ent_noise = d->entropy_noise;
   A.step_count_rw = d->step_count;
+  {
+    // every workgroup re-reads the M advantages twice: worth a launch only while that is a few KB — C3 at T = 5 (M = 2560): 12.39 ->
+    // 12.19 ms per training step; at T = 40 (M = 20480, 512 workgroups) it COST 1.8 ms (28.0 -> 29.8).  MBPO_PPO_MOM_INLINE=0 disables.
+    static const int mi_env = getenv("MBPO_PPO_MOM_INLINE") ? atoi(getenv("MBPO_PPO_MOM_INLINE")) : -1;
+    A.mom_inline = (d->normalize_advantage && pl.H == 64 && pl.M <= 4096 && mi_env != 0) ? 1 : 0;
+  }
   A.seed = d->seed; A.offset = d->offset; A.rng_dev = (const unsigned long long *)d->rng_dev;
   A.entropy_cost = d->entropy_cost; A.discounting = d->discounting; A.reward_scaling = d->reward_scaling;
   A.gae_lambda = d->gae_lambda; A.clip_eps = d->clipping_epsilon; A.normalize_advantage = d->normalize_advantage;
@@ -594,7 +656,9 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
     float *part = ws + pl.off_part;
     long long blocks = (pl.M + 255) / 256;
     int g = (int)(blocks < PPO_MOM_WGS ? blocks : PPO_MOM_WGS);
-    if (pl.M <= PPO_MOM_FUSED_MAX) hipLaunchKernelGGL(k_moments_fused, dim3(1), dim3(1024), 0, st, (const float *)A.adv, pl.M, A.mom);
+    if (A.mom_inline) {
+      // (formed inside k_ppo_fwd_bwd)
+    } else if (pl.M <= PPO_MOM_FUSED_MAX) hipLaunchKernelGGL(k_moments_fused, dim3(1), dim3(1024), 0, st, (const float *)A.adv, pl.M, A.mom);
     else {
     hipLaunchKernelGGL(k_moments_partial<0>, dim3(g), dim3(256), 0, st, (const float *)A.adv, pl.M, (const float *)A.mom, part);
     hipLaunchKernelGGL(k_moments_final<0>, dim3(1), dim3(64), 0, st, (const float *)part, g, pl.M, A.mom);
