@@ -332,9 +332,9 @@ def main():
     for key in range(first_key, first_key + n_keys):
         t0 = time.time()
         evals, r = run_sac(key, flip) if mode == "sac" else run_ppo(key, flip, steps)
-        ok = bool(evals[-1] >= -400 and abs(r) <= 0.1)
+        ok = bool(evals[-1] >= -400 and abs(r) <= 0.1)          # (NaN compares False: a diverged run fails)
         print(json.dumps({"algo": mode, "flip": flip, "key": key, "steps": (steps if mode == "ppo" else 20_000), "final": evals[-1],
-                          "best": max(evals), "r200": abs(r), "pass": ok, "seconds": round(time.time() - t0), "curve": [round(e) for e in evals]}),
+                          "best": max(evals), "r200": abs(r), "pass": ok, "seconds": round(time.time() - t0), "curve": [round(e) if e == e else None for e in evals]}),
               flush=True)
 
 
