@@ -484,12 +484,20 @@ def main():
     # which device every rank sits on, and — if the peer exchange was declined — why (for whoever reads an 8-GPU run's line)
     from mbpo.parallel import P2PExchange
     dev_ids, p2p_reasons = [torch.cuda.current_device()], [P2PExchange.last_decline_reason]
+    replicas_identical = None
     if pg is not None:
         import torch.distributed as dist
         gathered = [None] * dist.get_world_size(pg)
         dist.all_gather_object(gathered, (torch.cuda.current_device(), os.getpid(), P2PExchange.last_decline_reason), group=pg)
         dev_ids = [g_[0] for g_ in gathered]
         p2p_reasons = [g_[2] for g_ in gathered]
+        # data parallelism keeps the replicas bit-identical (every rank adds the same gradients in the same order): a checksum of
+        # the parameter words per rank says whether the exchange really delivered the same sums everywhere
+        sums = [None] * dist.get_world_size(pg)
+        dist.all_gather_object(sums, int(trainer.updater.params.view(torch.int32).to(torch.int64).sum()), group=pg)
+        replicas_identical = len(set(sums)) == 1
+        if not replicas_identical:
+            log(f"WARNING: parameter checksums differ across ranks: {sums}")
     if rank == 0:
         P = mlp_macs([X_DIM, *HIDDEN, 2 * U_DIM])
         Q = mlp_macs([X_DIM + U_DIM, *HIDDEN, 1])
@@ -543,6 +551,7 @@ def main():
                        "pg_backend": (None if pg is None else __import__("torch.distributed").distributed.get_backend(pg)),
                        "pg_world_size": (None if pg is None else __import__("torch.distributed").distributed.get_world_size(pg)),
                        "rank_device_ids": dev_ids,
+                       "replicas_identical": replicas_identical,
                        "p2p_decline_reason": (None if getattr(trainer, "p2p", None) is not None or pg is None else p2p_reasons)},
             "sac_updates_per_s": GRAD_UPDATES * args.steps / dt,
             "sac_update_samples_per_s": world * BATCH * GRAD_UPDATES * args.steps / dt,

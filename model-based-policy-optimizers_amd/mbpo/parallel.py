@@ -257,6 +257,14 @@ class P2PExchange:
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
 
+        # one exchange first, then an agreement: if it failed on ANY rank nobody enters the timed loop (a rank that has given up
+        # would leave its peers in one bounded wait of 20-30 s per repetition)
+        guarded_exchange()
+        torch.cuda.synchronize()
+        flag = torch.tensor([1 if local_ok[0] and self._safe_status() == 0 else 0], device=self.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.dp.group)
+        if int(flag) != 1:
+            return False
         t_p2p = timed(guarded_exchange)
         t_lib = timed(lambda: dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.dp.group))
         self.timing_ms = (t_p2p, t_lib)
