@@ -1,0 +1,259 @@
+// layered.hip — Dense layers as whole-minibatch fp32-MFMA GEMM launches (see layered.hpp).
+#include "layered.hpp"
+
+namespace {
+constexpr int BK = 64;
+// LDS layouts, chosen by which index is contiguous in global memory so that both the global loads and the LDS stores of a tile are
+// unit-stride across lanes:  k contiguous -> [row][k] with row stride LDK (68 % 32 == 4: the 16 rows x 4 k a wave's operand read
+// touches fall in 32 distinct banks, twice);  row/column contiguous -> [k][row] with stride tile + 16 (% 32 == 16: same property).
+constexpr int LDK = BK + 4;
+
+// One launch = one Dense layer over the whole minibatch.  Output tile per workgroup 32T x 32T (2 x 2 waves, T x T MFMA blocks each):
+// T = 2 when that still gives the chip enough workgroups, else T = 1 — fp32 MFMA is 256 FLOP/cycle/CU, so a 256 x 256 x 256 layer on
+// sixteen 64 x 64 tiles is 8 k cycles on 16 CUs; on sixty-four 32 x 32 tiles 2 k cycles on 64.  K walks through LDS in chunks of 64;
+// the NEXT chunk's global loads are issued (into registers) before the current chunk's MFMAs.
+template <int MODE, int T>
+__global__ void __launch_bounds__(256) k_layered_gemm(GemmArgs G) {
+  constexpr int BM = 32 * T, LDT = BM + 16, PER_T = BM * BK / 256;
+  constexpr int TILE_F = (BK * LDT > BM * LDK) ? BK * LDT : BM * LDK;
+  __shared__ float sA[TILE_F], sB[TILE_F];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int zb = blockIdx.z / G.n_split, sp = blockIdx.z - zb * G.n_split;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BM;
+  const float *A = G.A + (long long)zb * G.zA, *B = G.B + (long long)zb * G.zB;
+  const int k_begin = sp * G.k_chunk;
+  const int k_end = (k_begin + G.k_chunk < G.K) ? k_begin + G.k_chunk : G.K;
+  const bool a_kfast = G.sak == 1, b_kfast = G.sbk == 1 && G.sbn != 1;
+  // element e = tid + 256 i of an operand tile: (fast index, slow index) = (e % 64, e / 64) when k is the fast one, (e % BM, e / BM) else
+  float ra[PER_T], rb[PER_T];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int e = tid + 256 * i;
+      {
+        const int r = a_kfast ? e / BK : e % BM, k = a_kfast ? e % BK : e / BM;
+        const int gm = m0 + r, gk = k0 + k;
+        float v = 0.f;
+        if (gm < G.M && gk < k_end) v = (G.ones_row && gm == G.M - 1) ? 1.0f : A[(long long)gm * G.sam + (long long)gk * G.sak];
+        ra[i] = v;
+      }
+      {
+        const int c = b_kfast ? e / BK : e % BM, k = b_kfast ? e % BK : e / BM;
+        const int gn = n0 + c, gk = k0 + k;
+        rb[i] = (gn < G.N && gk < k_end) ? B[(long long)gk * G.sbk + (long long)gn * G.sbn] : 0.f;
+      }
+    }
+  };
+  f32x4 acc[T][T];
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wm = (wave >> 1) * 16 * T, wn = (wave & 1) * 16 * T;
+  const int lr = lane & 15, lg = lane >> 4;
+  // operand read addresses: element (row, k) of A at row * a_rs + k * a_ks, element (k, col) of B at col * b_cs + k * b_ks
+  const int a_rs = a_kfast ? LDK : 1, a_ks = a_kfast ? 1 : LDT, b_cs = b_kfast ? LDK : 1, b_ks = b_kfast ? 1 : LDT;
+  const int a_off = (wm + lr) * a_rs + lg * a_ks, b_off = (wn + lr) * b_cs + lg * b_ks;
+  fetch(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      const int e = tid + 256 * i;
+      sA[a_kfast ? (e / BK) * LDK + e % BK : (e / BM) * LDT + e % BM] = ra[i];
+      sB[b_kfast ? (e / BK) * LDK + e % BK : (e / BM) * LDT + e % BM] = rb[i];
+    }
+    __syncthreads();
+    if (k0 + BK < k_end) fetch(k0 + BK);        // in flight during this chunk's MFMAs
+#pragma unroll 4
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      float a[T], b[T];
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        a[i] = sA[a_off + 16 * i * a_rs + 4 * ks * a_ks];
+        b[i] = sB[b_off + 16 * i * b_cs + 4 * ks * b_ks];
+      }
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // lane holds D[row = 4 * (lane >> 4) + r][col = lane & 15] of each 16 x 16 block
+  float *C = G.C ? G.C + (G.n_split > 1 ? (long long)blockIdx.z * G.zSplit : (long long)zb * G.zC) : nullptr;
+  float *C2 = G.C2 ? G.C2 + (long long)zb * G.zC : nullptr;
+  const float *bias = (MODE == 0 && G.bias) ? G.bias + (long long)zb * G.zBias : nullptr;
+  const float *Zp = (MODE == 1 && G.Zprev) ? G.Zprev + (long long)zb * G.zZ : nullptr;
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      const int gn = n0 + wn + 16 * j + lr;
+      if (gn >= G.N) continue;
+      const float bv = bias ? bias[gn] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gm = m0 + wm + 16 * i + 4 * lg + r;
+        if (gm >= G.M) continue;
+        float v = acc[i][j][r];
+        if (MODE == 0) {
+          v += bv;
+          if (C) C[(long long)gm * G.ldc + gn] = v;
+          if (C2) C2[(long long)gm * G.ldc + gn] = G.act >= 0 ? act_apply(v, G.act) : v;
+        } else if (MODE == 1) {
+          if (Zp) v *= act_grad(Zp[(long long)gm * G.ldz + gn], G.act);
+          C[(long long)gm * G.ldc + gn] = v;
+        } else {
+          C[(long long)gm * G.ldc + gn] = v;
+        }
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_layered_split_sum(const float *part, long long stride, int n_split, float *out, long long out_stride,
+                                                           long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int z = blockIdx.y;
+  out[(long long)z * out_stride + i] = slab_sum<8>(part + (long long)z * n_split * stride, stride, n_split, i);
+}
+}  // namespace
+
+int layered_gemm(int mode, const GemmArgs &G, hipStream_t st) {
+  MBPO_REQUIRE(G.A && G.B && (G.C || (mode == 0 && G.C2)), MBPO_ERR_ARG, "layered_gemm: null operand");
+  MBPO_REQUIRE(G.M > 0 && G.N > 0 && G.K > 0 && G.nz >= 1 && G.n_split >= 1, MBPO_ERR_ARG, "layered_gemm: bad shape %d x %d x %d", G.M, G.N, G.K);
+  MBPO_REQUIRE(G.n_split == 1 || (G.k_chunk > 0 && G.k_chunk % BK == 0), MBPO_ERR_ARG, "layered_gemm: k_chunk must be a multiple of %d", BK);
+  GemmArgs H = G;
+  if (H.n_split == 1) H.k_chunk = H.K;
+  const long long wg64 = (long long)((G.N + 63) / 64) * ((G.M + 63) / 64) * G.nz * G.n_split;
+  const int T = wg64 >= 128 ? 2 : 1;
+  const int bm = 32 * T;
+  const dim3 grid((unsigned)((G.N + bm - 1) / bm), (unsigned)((G.M + bm - 1) / bm), (unsigned)(G.nz * G.n_split));
+#define LG(MODE_, T_) hipLaunchKernelGGL((k_layered_gemm<MODE_, T_>), grid, dim3(256), 0, st, H)
+  if (T == 2) {
+    if (mode == 0) LG(0, 2); else if (mode == 1) LG(1, 2); else LG(2, 2);
+  } else {
+    if (mode == 0) LG(0, 1); else if (mode == 1) LG(1, 1); else LG(2, 1);
+  }
+#undef LG
+  MBPO_CHECK_LAUNCH("layered_gemm");
+  return MBPO_OK;
+}
+
+int layered_split_sum(const float *part, long long stride, int n_split, int nz, float *out, long long out_stride, long long n, hipStream_t st) {
+  hipLaunchKernelGGL(k_layered_split_sum, dim3((unsigned)((n + 255) / 256), (unsigned)nz), dim3(256), 0, st, part, stride, n_split, out,
+                     out_stride, n);
+  MBPO_CHECK_LAUNCH("layered_split_sum");
+  return MBPO_OK;
+}
+
+LayeredNet layered_net(const MlpDev &m, const float *params, long long net_stride, int nz) {
+  LayeredNet n;
+  n.params = params; n.net_stride = net_stride; n.nz = nz; n.L = m.n_layers; n.act = m.act;
+  for (int l = 0; l <= m.n_layers; ++l) n.dims[l] = m.dims[l];
+  for (int l = 0; l < m.n_layers; ++l) { n.w_off[l] = m.w_off[l]; n.b_off[l] = m.b_off[l]; }
+  return n;
+}
+
+int layered_max_hidden(const LayeredNet &n) {
+  int h = 1;
+  for (int l = 0; l <= n.L; ++l) h = n.dims[l] > h ? n.dims[l] : h;
+  return h;
+}
+
+// weight gradients reduce over the minibatch rows: beyond 1024 rows the range is split over workgroups (a 256 x 256 weight is only
+// 16 output tiles) and the partials are added in a fixed order
+static void split_of(int rows, int *n_split, int *k_chunk) {
+  int s = (rows + 1023) / 1024;
+  if (s > 32) s = 32;
+  if (s < 1) s = 1;
+  int c = (rows + s - 1) / s;
+  c = (c + BK - 1) / BK * BK;
+  *n_split = (rows + c - 1) / c;
+  *k_chunk = c;
+}
+
+long long layered_part_floats(const LayeredNet &n, int rows) {
+  int s, c;
+  split_of(rows, &s, &c);
+  if (s == 1) return 0;
+  long long mx = 0;
+  for (int l = 0; l < n.L; ++l) {
+    const long long v = (long long)(n.dims[l] + 1) * n.dims[l + 1];
+    mx = v > mx ? v : mx;
+  }
+  return mx * s * n.nz;
+}
+
+int layered_forward(const LayeredNet &n, const float *x, long long zx, int rows, float *const *Z, float *const *H, float *y, hipStream_t st) {
+  const float *in = x;
+  long long zin = zx;
+  for (int l = 0; l < n.L; ++l) {
+    const int K = n.dims[l], N = n.dims[l + 1];
+    const bool last = l == n.L - 1;
+    GemmArgs G = {};
+    G.A = in; G.sam = K; G.sak = 1; G.zA = zin;
+    G.B = n.params + n.w_off[l]; G.sbk = N; G.sbn = 1; G.zB = n.net_stride;
+    G.bias = n.params + n.b_off[l]; G.zBias = n.net_stride;
+    G.M = rows; G.N = N; G.K = K; G.nz = n.nz; G.n_split = 1;
+    G.ldc = N; G.zC = (long long)rows * N;
+    if (last) {
+      G.C = y; G.C2 = nullptr; G.act = -1;
+    } else {
+      G.C = Z ? Z[l + 1] : nullptr; G.C2 = H[l + 1]; G.act = n.act;
+    }
+    int rc = layered_gemm(0, G, st);
+    if (rc != MBPO_OK) return rc;
+    if (!last) { in = H[l + 1]; zin = (long long)rows * N; }
+  }
+  return MBPO_OK;
+}
+
+int layered_backward(const LayeredNet &n, const float *x, long long zx, int rows, float *const *Z, float *const *H, const float *dy,
+                     float *dw, long long dw_stride, float *dx, float *tmp0, float *tmp1, float *part, hipStream_t st) {
+  const float *dz = dy;      // [nz][rows][dims[l+1]]
+  float *pp[2] = {tmp0, tmp1};
+  int flip = 0;
+  int n_split, k_chunk;
+  split_of(rows, &n_split, &k_chunk);
+  for (int l = n.L - 1; l >= 0; --l) {
+    const int K = n.dims[l], N = n.dims[l + 1];
+    if (dw) {
+      const float *in = l == 0 ? x : H[l];
+      const long long zin = l == 0 ? zx : (long long)rows * K;
+      // [dW; db](k, n) = sum_rows [in, 1](row, k) * dz(row, n): the GEMM's m = k (K + 1 rows, the last all ones), its k = minibatch rows
+      GemmArgs G = {};
+      G.A = in; G.sam = 1; G.sak = K; G.zA = zin; G.ones_row = 1;
+      G.B = dz; G.sbk = N; G.sbn = 1; G.zB = (long long)rows * N;
+      G.M = K + 1; G.N = N; G.K = rows; G.nz = n.nz;
+      G.ldc = N;
+      if (n_split == 1) {
+        G.n_split = 1; G.C = dw + n.w_off[l]; G.zC = dw_stride;
+      } else {
+        G.n_split = n_split; G.k_chunk = k_chunk; G.C = part; G.zSplit = (long long)(K + 1) * N;
+      }
+      int rc = layered_gemm(2, G, st);
+      if (rc != MBPO_OK) return rc;
+      if (n_split > 1) {
+        rc = layered_split_sum(part, (long long)(K + 1) * N, n_split, n.nz, dw + n.w_off[l], dw_stride, (long long)(K + 1) * N, st);
+        if (rc != MBPO_OK) return rc;
+      }
+    }
+    if (l == 0 && !dx) break;
+    // d in(row, k) = sum_n dz(row, n) * W(k, n), times act'(Z[l]) for a hidden layer's input
+    GemmArgs G = {};
+    G.A = dz; G.sam = N; G.sak = 1; G.zA = (long long)rows * N;
+    G.B = n.params + n.w_off[l]; G.sbk = 1; G.sbn = N; G.zB = n.net_stride;
+    G.M = rows; G.N = K; G.K = N; G.nz = n.nz; G.n_split = 1;
+    G.ldc = K; G.zC = (long long)rows * K;
+    if (l == 0) {
+      G.C = dx; G.Zprev = nullptr; G.act = -1;
+    } else {
+      G.C = pp[flip]; G.Zprev = Z[l]; G.ldz = K; G.zZ = (long long)rows * K; G.act = n.act;
+    }
+    int rc = layered_gemm(1, G, st);
+    if (rc != MBPO_OK) return rc;
+    if (l > 0) { dz = pp[flip]; flip ^= 1; }
+  }
+  return MBPO_OK;
+}

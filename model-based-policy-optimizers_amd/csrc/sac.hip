@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "chain_run.hpp"
 #include "p2p.hpp"
+#include "sac_layered.hpp"
 #include <string.h>
 #include <stdlib.h>
 int mbpo_p2p_make_dev(const mbpo_p2p_desc *d, P2pDev *P);
@@ -980,7 +981,10 @@ struct SacPlan {
   size_t lds;
   int ld_x, ld_xu, ld_h, ld_y;
   // workspace offsets (floats)
-  long long off_slab_pi, off_slab_q, off_slab_ex, off_ss, off_seq, off_undo, total;
+  long long off_slab_pi, off_slab_q, off_slab_ex, off_ss, off_seq, off_undo, off_layered, total;
+  // hidden layers outside the fused kernel's range (one width in {64,128} that fits a tile's LDS): the forward/backward half runs
+  // layer by layer (sac_layered.hip) and leaves ONE tile of slabs; everything behind it is shared
+  bool layered;
 };
 
 static int same_hidden(const int *dims, int n_layers) {
@@ -1001,8 +1005,8 @@ static int sac_plan(const mbpo_sac_desc *d, SacPlan *pl, bool need_ptrs) {
   MBPO_REQUIRE(d->q_dims[0] == d->x_dim + d->u_dim && d->q_dims[d->q_layers] == 1, MBPO_ERR_ARG,
                "sac: critic must map [x_dim+u_dim] -> [1]");
   const int Hp = same_hidden(d->policy_dims, d->policy_layers), Hq = same_hidden(d->q_dims, d->q_layers);
-  MBPO_REQUIRE(Hp == Hq && (Hp == 64 || Hp == 128), MBPO_ERR_UNSUPPORTED,
-               "sac: policy and critic hidden layers must share one width in {64,128} (got %d, %d)", Hp, Hq);
+  static const int layered_env = getenv("MBPO_SAC_LAYERED") ? atoi(getenv("MBPO_SAC_LAYERED")) : 0;    // 1: force the layered path (tests)
+  pl->layered = layered_env != 0 || !(Hp == Hq && (Hp == 64 || Hp == 128));
   mbpo_mlp_desc md;
   md.net_stride = 0;
   // policy
@@ -1033,6 +1037,7 @@ static int sac_plan(const mbpo_sac_desc *d, SacPlan *pl, bool need_ptrs) {
   pl->LH = lhp > lhq ? lhp : lhq;
   pl->n_tiles = (d->batch_size + 15) / 16;
   pl->n_red = (pl->NP + 255) / 256;
+  pl->off_layered = 0;
   auto up4 = [](int v) { return (v + 3) & ~3; };
   pl->ld_x = up4(d->x_dim) + 4;
   pl->ld_xu = up4(d->x_dim + d->u_dim) + 4;
@@ -1042,9 +1047,8 @@ static int sac_plan(const mbpo_sac_desc *d, SacPlan *pl, bool need_ptrs) {
   size_t f = 16ull * up4(d->row_len) + 2ull * 16 * pl->ld_x + 2ull * 16 * pl->ld_xu + 4ull * 16 * pl->ld_h +
              (size_t)pl->LH * 4 * 16 * pl->ld_h + 5ull * 16 * pl->ld_y + 2ull * 16 * pl->ld_xu + 6ull * up4(16 * U) + 64 + 4;
   pl->lds = f * sizeof(float);
-  MBPO_REQUIRE(pl->lds <= 160 * 1024, MBPO_ERR_UNSUPPORTED,
-               "sac: a 16-sample tile of these networks needs %zu B of LDS (> 160 KiB): %d hidden layers of width %d do not fit; "
-               "use fewer / narrower hidden layers (INTEGRATION.md, 'Network shapes')", pl->lds, pl->LH, Hp);
+  if (!pl->layered && pl->lds > 160 * 1024) pl->layered = true;      // more stored activations than a tile's LDS holds
+  if (pl->layered) pl->n_tiles = 1;
   pl->off_slab_pi = 0;
   pl->off_slab_q = pl->off_slab_pi + (long long)pl->n_tiles * pl->P;
   pl->off_slab_ex = pl->off_slab_q + (long long)pl->n_tiles * 2 * pl->Q;
@@ -1053,6 +1057,10 @@ static int sac_plan(const mbpo_sac_desc *d, SacPlan *pl, bool need_ptrs) {
                                                                        // then slot word + undo count, accum, 2 bias corrections (zero at start)
   pl->off_undo = pl->off_seq + 16;                                     // undo log of the speculative optimizer step
   pl->total = pl->off_undo + 3LL * pl->NP + 2LL * pl->Q;
+  if (pl->layered) {
+    pl->off_layered = (pl->total + 3) & ~3LL;
+    pl->total = pl->off_layered + sac_layered_floats(d, pl->pi, pl->q);
+  }
   if (need_ptrs) {
     MBPO_REQUIRE(d->params && d->target_q && d->adam_m && d->adam_v && d->step_count && d->grads && d->workspace && d->metrics,
                  MBPO_ERR_ARG, "sac: null state pointer");
@@ -1215,7 +1223,7 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
     A.thin = (want && split && jvp && pl.H == 64 && A.sh_pi.K_in <= THIN_KMAX && A.sh_q.K_in <= THIN_KMAX && A.sh_pi.N_out <= THIN_NMAX &&
               A.sh_q.N_out <= THIN_NMAX && A.sh_pi.L >= 3 && A.sh_q.L >= 3) ? 1 : 0;
   }
-  sac_chain_table(pl, d->row_len, &A, split, jvp);
+  if (!pl.layered) sac_chain_table(pl, d->row_len, &A, split, jvp);
   A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.D = d->row_len;
   A.batch = d->batch; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std;
   A.log_alpha = d->params + pl.NP - 1;
@@ -1242,7 +1250,13 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
   A.slab_pi = d->workspace + pl.off_slab_pi; A.slab_q = d->workspace + pl.off_slab_q; A.slab_ex = d->workspace + pl.off_slab_ex;
   A.ld_x = pl.ld_x; A.ld_xu = pl.ld_xu; A.ld_h = pl.ld_h; A.ld_y = pl.ld_y; A.LH = pl.LH;
   hipStream_t st = (hipStream_t)stream;
-  if (phase_mask & 1) {
+  if (pl.layered) {
+    if (phase_mask & 1) {
+      const SacLayeredBegin bg = {d->step_count, A.opt.seq, A.opt.slot_word, A.p2p_epoch, A.p2p_blocks};
+      rc = sac_layered_fwd_bwd(d, pl.pi, pl.q, pl.qt, d->workspace + pl.off_layered, A.slab_pi, A.slab_q, A.slab_ex, bg, st);
+      if (rc != MBPO_OK) return rc;
+    }
+  } else if (phase_mask & 1) {
     if (pl.H == 64) {
       if (net_is_wide(A.sh_pi) || net_is_wide(A.sh_q)) {
         rc = mbpo_ensure_lds<k_sac_fwd_bwd<64, SP64, true>>(pl.lds, "sac_grads");
@@ -1282,7 +1296,13 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
   R.n_tiles = pl.n_tiles; R.P = pl.P; R.Q2 = 2 * pl.Q; R.B = d->batch_size;
   R.grads = d->grads; R.metrics = d->metrics; R.metrics_accum = d->metrics_accum; R.ss_part = d->workspace + pl.off_ss; R.step_count = d->step_count;
   R.seq = A.opt.seq;
-  if (apply_in_reduce) {
+  if (apply_in_reduce && pl.layered) {
+    // no speculative step on the layered path (two launches out of ~50 is nothing to win): the reduction, then the clipped
+    // optimizer step — what mbpo_sac_step is defined to equal bit for bit
+    if (xd) hipLaunchKernelGGL(k_sac_reduce_exchange, dim3(pl.n_red), dim3(256), 0, st, R, X);
+    else hipLaunchKernelGGL(k_sac_reduce, dim3(pl.n_red), dim3(256), 0, st, R);
+    hipLaunchKernelGGL(k_sac_apply, dim3(pl.n_red), dim3(256), 0, st, A.opt);
+  } else if (apply_in_reduce) {
     if (xd) hipLaunchKernelGGL(k_sac_reduce_apply<true>, dim3(pl.n_red), dim3(256), 0, st, R, A.opt, X);
     else hipLaunchKernelGGL(k_sac_reduce_apply<false>, dim3(pl.n_red), dim3(256), 0, st, R, A.opt, X);
   } else if (xd && exchange_in_reduce) hipLaunchKernelGGL(k_sac_reduce_exchange, dim3(pl.n_red), dim3(256), 0, st, R, X);

@@ -121,6 +121,9 @@ class HipMlp(torch.autograd.Function):
 # 0 / (0 + eps) + wd * 0).  The padding is a fixed point of training: the padded network IS the logical one, bit for bit in
 # exact arithmetic (the k-ordered fp32 sums gain only +0.0 terms).
 KERNEL_WIDTHS = (64, 128)
+# Above that the SAC update runs layer by layer (csrc/layered.hip: one GEMM launch per Dense layer, any hidden sizes, no padding);
+# a POLICY also runs inside the rollout / act kernels, which take one hidden width in {64, 128, 256}.
+ROLLOUT_WIDTHS = (64, 128, 256)
 
 
 def common_width(*hidden_size_lists, supported=KERNEL_WIDTHS, what: str = "networks") -> int:
@@ -133,9 +136,10 @@ def common_width(*hidden_size_lists, supported=KERNEL_WIDTHS, what: str = "netwo
                             "INTEGRATION.md, 'Network shapes')")
 
 
-def padded_dims(dims: Sequence[int], width: int) -> list:
+def padded_dims(dims: Sequence[int], width: Optional[int]) -> list:
+    """`width` None: the network keeps its logical hidden sizes (the layered path takes any)."""
     d = [int(v) for v in dims]
-    return [d[0]] + [width] * (len(d) - 2) + [d[-1]]
+    return d if width is None else [d[0]] + [width] * (len(d) - 2) + [d[-1]]
 
 
 def embed_mlp_params(flat: torch.Tensor, dims: Sequence[int], width: int, n_nets: int = 1) -> torch.Tensor:

@@ -178,12 +178,21 @@ class SAC:
         self.policy_dims_logical = [self.x_dim, *policy_hidden_layer_sizes, 2 * self.u_dim]
         self.q_dims_logical = [self.x_dim + self.u_dim, *critic_hidden_layer_sizes, 1]
         dyn_hidden = list(getattr(getattr(self.env.system, "dynamics", None), "dims", [])[1:-1]) if self.env.system.fused else []
-        self.kernel_width = ops.common_width(policy_hidden_layer_sizes, critic_hidden_layer_sizes, dyn_hidden, what="SAC")
+        widest = max([int(h) for h in (*policy_hidden_layer_sizes, *critic_hidden_layer_sizes, *dyn_hidden)], default=0)
+        if widest <= ops.KERNEL_WIDTHS[-1]:
+            self.kernel_width = ops.common_width(policy_hidden_layer_sizes, critic_hidden_layer_sizes, dyn_hidden, what="SAC")
+            self.q_width = self.kernel_width
+        else:
+            # wider than the fused update kernel takes (sac.py:84-88 accepts any tuple): mbpo_sac_step then runs its forward/backward
+            # half layer by layer (csrc/sac_layered.hip) — the critics keep their logical sizes; the policy, which also runs inside
+            # the rollout / act kernels, is padded to one of their widths
+            self.kernel_width = ops.common_width(policy_hidden_layer_sizes, dyn_hidden, supported=ops.ROLLOUT_WIDTHS, what="SAC policy")
+            self.q_width = None
         if dyn_hidden and any(h != self.kernel_width for h in dyn_hidden):
-            raise _hip.MbpoHipError(f"SAC: the learned ensemble's hidden width {dyn_hidden} must equal the policy/critic kernel width "
+            raise _hip.MbpoHipError(f"SAC: the learned ensemble's hidden width {dyn_hidden} must equal the policy's kernel width "
                                     f"{self.kernel_width} inside the fused rollout (build the EnsembleDynamics with that width)")
         self.policy_dims = ops.padded_dims(self.policy_dims_logical, self.kernel_width)
-        self.q_dims = ops.padded_dims(self.q_dims_logical, self.kernel_width)
+        self.q_dims = ops.padded_dims(self.q_dims_logical, self.q_width)
         self.policy_spec = ops.MlpSpec(self.policy_dims, policy_activation, 1)
         # data-parallel ranks (the live form of _PMAP_AXIS_NAME, sac.py:188-189): one process per GPU
         self.process_group = process_group
@@ -258,7 +267,7 @@ class SAC:
         gq = torch.Generator().manual_seed(key_q % (2 ** 63))
         # lecun-uniform at the LOGICAL fan-ins, then embedded into the (possibly wider) kernel shape
         pol = ops.embed_mlp_params(lecun_uniform_flat(self.policy_dims_logical, gp), self.policy_dims_logical, self.kernel_width)
-        q = torch.cat([ops.embed_mlp_params(lecun_uniform_flat(self.q_dims_logical, gq), self.q_dims_logical, self.kernel_width)
+        q = torch.cat([ops.embed_mlp_params(lecun_uniform_flat(self.q_dims_logical, gq), self.q_dims_logical, self.q_width)
                        for _ in range(2)])
         params = torch.cat([pol, q, torch.tensor([self.init_log_alpha], dtype=torch.float32)]).to(self.device)
         self.dp.broadcast(params, src=0)     # identical replicas: rank 0's initialisation everywhere

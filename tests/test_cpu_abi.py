@@ -69,9 +69,12 @@ def test_size_queries_and_validation_without_a_device(lib):
     assert lib.mbpo_sac_workspace_floats(C.byref(d)) < 0
     assert b"row_len" in lib.mbpo_last_error()
     d.row_len = 12
-    d.policy_dims[1] = 96                                          # unsupported hidden width
+    d.policy_dims[1] = 96                                          # not a fused-kernel width: the layered path (one tile of slabs + its buffers)
+    n96 = lib.mbpo_sac_workspace_floats(C.byref(d))
+    assert n96 > 0
+    d.policy_dims[4] = 3                                           # a policy must end in 2 * u_dim outputs
     assert lib.mbpo_sac_workspace_floats(C.byref(d)) < 0
-    assert b"hidden" in lib.mbpo_last_error()
+    assert b"policy" in lib.mbpo_last_error()
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -14,9 +14,10 @@ from oracle import sac as osac
 pytestmark = pytest.mark.gpu
 
 
-def _make(X, U, hidden, B, seed, normalize, trunc_p=0.2, **cfgkw):
+def _make(X, U, hidden, B, seed, normalize, trunc_p=0.2, q_hidden=None, **cfgkw):
     g = torch.Generator().manual_seed(seed)
-    cfg = osac.SacConfig(x_dim=X, u_dim=U, policy_dims=[X, *hidden, 2 * U], q_dims=[X + U, *hidden, 1], **cfgkw)
+    cfg = osac.SacConfig(x_dim=X, u_dim=U, policy_dims=[X, *hidden, 2 * U], q_dims=[X + U, *(hidden if q_hidden is None else q_hidden), 1],
+                         **cfgkw)
     st = osac.init_state(cfg, g, init_log_alpha=-0.3)
     st.params = st.params + 0.03 * torch.randn(st.params.shape, generator=g)      # non-zero biases
     st.target_q = st.params[cfg.P:cfg.P + 2 * cfg.Q] + 0.02 * torch.randn(2 * cfg.Q, generator=g)
@@ -77,6 +78,72 @@ def test_sac_gradients_and_step(dev, X, U, hidden, B, normalize):
     torch.testing.assert_close(up.adam_m.cpu(), st_new.adam_m, atol=1e-9, rtol=1e-5)
     torch.testing.assert_close(up.adam_v.cpu(), st_new.adam_v, atol=1e-12, rtol=1e-5)
     assert float(up.step_count.cpu()) == 1.0
+
+
+@pytest.mark.parametrize("X,U,hidden,q_hidden,B,normalize", [
+    (3, 1, (256, 256, 256), (256, 256, 256), 256, True),     # wider than the fused kernels take
+    (4, 2, (48, 80), (200, 72, 40), 100, True),              # unequal hidden layers, ragged batch, different depths
+    (17, 6, (96,), (300,), 3000, False),                     # one hidden layer; 3000 rows: weight gradients split over the rows
+    (4, 1, (256,) * 5, (256,) * 5, 64, True),                # the depth experiments/train_inverted_pendulum/exp_ppo.py gives its critic
+])
+def test_sac_layered_path_any_widths(dev, X, U, hidden, q_hidden, B, normalize):
+    """Shapes outside the fused kernel's range (sac.py:84-88 accepts any tuple): the forward/backward half runs layer by layer
+    (csrc/sac_layered.hip, one fp32-MFMA GEMM launch per Dense layer), everything behind it is the fused path's code.  Same
+    tolerances as test_sac_gradients_and_step."""
+    cfg, st, batch, noise, nm, ns = _make(X, U, hidden, B, 5, normalize, q_hidden=q_hidden, discounting=0.99, reward_scaling=1.5,
+                                           lr_policy=3e-4, lr_q=3e-4, lr_alpha=3e-4, wd_q=1e-3)
+    to64 = lambda t: None if t is None else t.double()
+    g_ref64, (cl64, ac64, al64) = osac.grads(cfg, st.params.double(), st.target_q.double(), batch.double(),
+                                             *[n.double() for n in noise], to64(nm), to64(ns))
+    d = lambda t: None if t is None else t.to(dev)
+    outs = []
+    for two_launch in (False, True):        # mbpo_sac_grads + mbpo_sac_apply, and mbpo_sac_step (defined to equal them bit for bit)
+        up = _updater(dev, cfg, B, two_launch=two_launch)
+        up.load_state(st.params.to(dev), st.target_q.to(dev))
+        up.sgd_step(batch.to(dev), d(nm), d(ns), *[n.to(dev) for n in noise])
+        up.finalize()
+        torch.cuda.synchronize()
+        outs.append((up.grads.cpu().clone(), up.params.cpu().clone(), up.target_q.cpu().clone(), up.metrics.cpu().clone()))
+        assert float(up.step_count.cpu()) == 1.0
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    g = outs[0][0]
+    P, Q = cfg.P, cfg.Q
+    for name, sl in (("policy", slice(0, P)), ("critic", slice(P, P + 2 * Q)), ("alpha", slice(P + 2 * Q, None))):
+        scale = float(g_ref64[sl].abs().max())
+        torch.testing.assert_close(g[sl].double(), g_ref64[sl], atol=2e-6 + 2e-6 * scale, rtol=2e-4,
+                                   msg=lambda m: f"{name} grad vs fp64 oracle: {m}")
+    st_new, met, _ = osac.sgd_step(cfg, st, batch, *noise, nm, ns, grad_override=g)
+    np.testing.assert_allclose(outs[0][3].tolist()[:3], [cl64, ac64, al64], rtol=5e-5, atol=2e-6)
+    np.testing.assert_allclose(outs[0][3].tolist()[3], met["alpha"], rtol=1e-6)
+    torch.testing.assert_close(outs[0][1], st_new.params, atol=1e-7, rtol=1e-6)
+    torch.testing.assert_close(outs[0][2], st_new.target_q, atol=1e-7, rtol=1e-6)
+
+
+def test_sac_layered_path_equals_fused_path_on_a_padded_network(dev):
+    """The same logical 60-wide networks twice: zero-padded to 64 through the fused kernel (what the trainer does, ops.py 'hidden-width
+    padding') and unpadded through the layered path (60 is not a kernel width).  Gradients of the logical entries agree."""
+    from mbpo import ops
+    X, U, B = 4, 1, 96
+    cfg, st, batch, noise, nm, ns = _make(X, U, (60, 60, 60), B, 8, True, discounting=0.95)
+    cfg_pad = osac.SacConfig(x_dim=X, u_dim=U, policy_dims=ops.padded_dims(cfg.policy_dims, 64), q_dims=ops.padded_dims(cfg.q_dims, 64),
+                             discounting=0.95)
+    P, Q = cfg.P, cfg.Q
+    pol = ops.embed_mlp_params(st.params[:P], cfg.policy_dims, 64)
+    q = ops.embed_mlp_params(st.params[P:P + 2 * Q], cfg.q_dims, 64, n_nets=2)
+    tq = ops.embed_mlp_params(st.target_q, cfg.q_dims, 64, n_nets=2)
+    up_l, up_f = _updater(dev, cfg, B), _updater(dev, cfg_pad, B)
+    up_l.load_state(st.params.to(dev), st.target_q.to(dev))
+    up_f.load_state(torch.cat([pol, q, st.params[-1:]]).to(dev), tq.to(dev))
+    for up in (up_l, up_f):
+        up.sgd_step(batch.to(dev), nm.to(dev), ns.to(dev), *[n.to(dev) for n in noise])
+        up.finalize()
+    torch.cuda.synchronize()
+    gf = up_f.grads.cpu()
+    g_fused = torch.cat([ops.extract_mlp_params(gf[:cfg_pad.P], cfg.policy_dims, 64),
+                         ops.extract_mlp_params(gf[cfg_pad.P:cfg_pad.P + 2 * cfg_pad.Q], cfg.q_dims, 64, n_nets=2), gf[-1:]])
+    torch.testing.assert_close(up_l.grads.cpu(), g_fused, atol=1e-6, rtol=1e-4)
+    torch.testing.assert_close(up_l.metrics.cpu(), up_f.metrics.cpu(), atol=1e-6, rtol=2e-5)
 
 
 @pytest.mark.parametrize("X,U,hidden,B", [
@@ -179,10 +246,14 @@ def test_sac_philox_noise_path(dev):
 
 def test_sac_bad_args(dev):
     from mbpo import ops, _hip
-    with pytest.raises(_hip.MbpoHipError):
-        ops.SacUpdater(x_dim=3, u_dim=1, policy_dims=[3, 64, 32, 2], q_dims=[4, 64, 32, 1], batch_size=32, device=dev)
-    with pytest.raises(_hip.MbpoHipError):
-        ops.SacUpdater(x_dim=3, u_dim=1, policy_dims=[3, 256, 256, 2], q_dims=[4, 256, 256, 1], batch_size=32, device=dev)
+    with pytest.raises(_hip.MbpoHipError):      # the policy must end in 2u outputs
+        ops.SacUpdater(x_dim=3, u_dim=1, policy_dims=[3, 64, 64, 3], q_dims=[4, 64, 64, 1], batch_size=32, device=dev)
+    with pytest.raises(_hip.MbpoHipError):      # a critic takes x + u inputs
+        ops.SacUpdater(x_dim=3, u_dim=1, policy_dims=[3, 64, 64, 2], q_dims=[3, 64, 64, 1], batch_size=32, device=dev)
+    with pytest.raises(_hip.MbpoHipError):      # at least one hidden layer
+        ops.SacUpdater(x_dim=3, u_dim=1, policy_dims=[3, 2], q_dims=[4, 1], batch_size=32, device=dev)
+    # unequal or wide hidden layers are NOT errors: they take the layered path (test_sac_layered_path_any_widths)
+    ops.SacUpdater(x_dim=3, u_dim=1, policy_dims=[3, 64, 32, 2], q_dims=[4, 256, 256, 1], batch_size=32, device=dev)
 
 
 @pytest.mark.parametrize("max_norm,mode", [(0.05, "finalize_each"), (0.05, "deferred"), (1e5, "deferred"), (0.4, "deferred")])
@@ -377,8 +448,9 @@ def test_sac_padded_widths_match_the_logical_networks(dev, ph, qh):
 
 
 def test_sac_trainer_accepts_reference_experiment_shapes(dev):
-    """exp.py / exp_ppo.py-like shapes through the trainers: policy (32,)*4 with critic (128,)*3 trains; a 256-wide critic is
-    refused with a message that names the cap (INTEGRATION.md "Network shapes")."""
+    """exp.py / exp_ppo.py-like shapes through the trainers: policy (32,)*4 with critic (48,)*3 trains on the fused kernels (zero-
+    padded to 64); SAC with exp_ppo.py's 256x5 critic, or with more 128-wide layers than a tile's LDS holds, trains on the layered
+    path (INTEGRATION.md "Network shapes"); PPO still names its cap."""
     from mbpo import _hip
     from mbpo.optimizers.policy_optimizers.ppo.ppo import PPO
     from mbpo.optimizers.policy_optimizers.sac.sac import SAC
@@ -403,10 +475,23 @@ def test_sac_trainer_accepts_reference_experiment_shapes(dev):
     assert pp.kernel_width == 64
     params, metrics = pp.run_training(key=2)
     assert bool(torch.isfinite(params[1]).all())
+    small = dict(environment=env, num_timesteps=32 + 32 * 2 * 3, episode_length=10, num_env_steps_between_updates=2, num_envs=32,
+                 batch_size=32, grad_updates_per_step=2, min_replay_size=32)
+    wide = SAC(**small, policy_hidden_layer_sizes=(32,) * 4, critic_hidden_layer_sizes=(256,) * 5)      # exp_ppo.py's critic
+    assert wide.kernel_width == 64 and wide.q_width is None and wide.q_dims == [4, 256, 256, 256, 256, 256, 1]
+    params, metrics = wide.run_training(key=3)
+    assert bool(torch.isfinite(params[1]).all()) and bool(torch.isfinite(wide.updater.params).all())
+    # four 128-wide hidden layers in the policy: the stored activations of a 16-row tile exceed the 160 KiB of LDS -> layered as well
+    deep = SAC(**small, policy_hidden_layer_sizes=(32,) * 4, critic_hidden_layer_sizes=(128,) * 3)
+    assert deep.kernel_width == 128
+    params, metrics = deep.run_training(key=4)
+    assert bool(torch.isfinite(deep.updater.params).all())
+    wide_pol = SAC(**small, policy_hidden_layer_sizes=(200, 200), critic_hidden_layer_sizes=(300, 100))      # policy padded to 256 (rollout kernels)
+    assert wide_pol.kernel_width == 256 and wide_pol.q_dims == [4, 300, 100, 1]
+    params, metrics = wide_pol.run_training(key=5)
+    assert bool(torch.isfinite(wide_pol.updater.params).all())
     with pytest.raises(_hip.MbpoHipError, match="exceeds"):
-        SAC(environment=env, num_timesteps=1000, episode_length=10, critic_hidden_layer_sizes=(256,) * 5)
-    # four 128-wide hidden layers: the stored activations of a tile exceed the 160 KiB of LDS — refused at construction, by name
-    with pytest.raises(_hip.MbpoHipError, match="LDS"):
-        SAC(environment=env, num_timesteps=1000, episode_length=10, policy_hidden_layer_sizes=(32,) * 4, critic_hidden_layer_sizes=(128,) * 3)
+        PPO(environment=env, num_timesteps=2000, episode_length=10, num_envs=32, unroll_length=5, batch_size=16, num_minibatches=2,
+            critic_hidden_layer_sizes=(256,) * 5)
     ok = SAC(environment=env, num_timesteps=1000, episode_length=10, policy_hidden_layer_sizes=(100, 100, 100), critic_hidden_layer_sizes=(128,) * 3)
     assert ok.kernel_width == 128
