@@ -12,6 +12,7 @@
 // Algorithmic work per sample: 3*(2P + 2V) FLOP fwd+bwd (+2V for the value pre-pass), 4*(2x+2u+4) B of row data.
 #include "common.hpp"
 #include "chain_run.hpp"
+#include "ppo_layered.hpp"
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
 #define LOG_2 0.69314718055994530942f
@@ -515,7 +516,10 @@ struct PpoPlan {
   long long M;
   int ld_x, ld_h, ld_y;
   size_t lds_values, lds_fb;
-  long long off_baseline, off_boot, off_trunc, off_term, off_rew, off_vs, off_adv, off_mom, off_part, off_slabs, off_extras, total;
+  long long off_baseline, off_boot, off_trunc, off_term, off_rew, off_vs, off_adv, off_mom, off_part, off_slabs, off_extras, off_layered, total;
+  // hidden layers outside the fused kernels' range (one width in {64,128}): values pre-pass and loss forward/backward run layer by
+  // layer (ppo_layered.hip) and leave ONE slab; GAE scan, moments, reduction, metrics and AdamW are shared
+  bool layered;
 };
 
 static int ppo_same_hidden(const int *dims, int n_layers) {
@@ -546,8 +550,8 @@ static int ppo_plan(const mbpo_ppo_desc *d, PpoPlan *pl, bool need_ptrs) {
                "ppo: policy must map [x_dim] -> [2*u_dim]");
   MBPO_REQUIRE(d->value_dims[0] == d->x_dim && d->value_dims[d->value_layers] == 1, MBPO_ERR_ARG, "ppo: value net must map [x_dim] -> [1]");
   const int Hp = ppo_same_hidden(d->policy_dims, d->policy_layers), Hv = ppo_same_hidden(d->value_dims, d->value_layers);
-  MBPO_REQUIRE(Hp == Hv && (Hp == 64 || Hp == 128), MBPO_ERR_UNSUPPORTED,
-               "ppo: policy and value hidden layers must share one width in {64,128} (got %d, %d)", Hp, Hv);
+  static const int layered_env = getenv("MBPO_PPO_LAYERED") ? atoi(getenv("MBPO_PPO_LAYERED")) : 0;    // 1: force the layered path (tests)
+  pl->layered = layered_env != 0 || !(Hp == Hv && (Hp == 64 || Hp == 128));
   mbpo_mlp_desc md;
   md.net_stride = 0;
   md.n_nets = 1;
@@ -588,11 +592,18 @@ static int ppo_plan(const mbpo_ppo_desc *d, PpoPlan *pl, bool need_ptrs) {
   }
   long long cap = (pl->sp2 ? 2LL : 1LL) * ppo_num_cus();
   pl->n_slabs = (int)(tiles < cap ? tiles : cap);
+  if (!pl->layered && (pl->lds_fb > 160 * 1024 || pl->lds_values > 160 * 1024)) pl->layered = true;     // more stored activations than a tile's LDS holds
+  if (pl->layered) {
+    pl->sp2 = 0;
+    pl->n_slabs = 1;
+  }
   long long o = 0;
   auto take = [&](long long n) { long long at = o; o += (n + 3) & ~3LL; return at; };
   pl->off_baseline = take(pl->M); pl->off_boot = take(d->batch_size); pl->off_trunc = take(pl->M); pl->off_term = take(pl->M);
   pl->off_rew = take(pl->M); pl->off_vs = take(pl->M); pl->off_adv = take(pl->M); pl->off_mom = take(4); pl->off_part = take(PPO_MOM_WGS);
   pl->off_slabs = take((long long)pl->n_slabs * pl->NPV); pl->off_extras = take((long long)pl->n_slabs * 4);
+  pl->off_layered = o;
+  if (pl->layered) o += ppo_layered_floats(d, pl->pi, pl->v);
   pl->total = o;
   if (need_ptrs)
     MBPO_REQUIRE(d->params && d->adam_m && d->adam_v && d->step_count && d->grads && d->workspace && d->metrics, MBPO_ERR_ARG,
@@ -625,7 +636,7 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
     // every workgroup re-reads the M advantages twice: worth a launch only while that is a few KB — C3 at T = 5 (M = 2560): 12.39 ->
     // 12.19 ms per training step; at T = 40 (M = 20480, 512 workgroups) it COST 1.8 ms (28.0 -> 29.8).  MBPO_PPO_MOM_INLINE=0 disables.
     static const int mi_env = getenv("MBPO_PPO_MOM_INLINE") ? atoi(getenv("MBPO_PPO_MOM_INLINE")) : -1;
-    A.mom_inline = (d->normalize_advantage && pl.H == 64 && pl.M <= 4096 && mi_env != 0) ? 1 : 0;
+    A.mom_inline = (!pl.layered && d->normalize_advantage && pl.H == 64 && pl.M <= 4096 && mi_env != 0) ? 1 : 0;
   }
   A.seed = d->seed; A.offset = d->offset; A.rng_dev = (const unsigned long long *)d->rng_dev;
   A.entropy_cost = d->entropy_cost; A.discounting = d->discounting; A.reward_scaling = d->reward_scaling;
@@ -638,7 +649,13 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
   // 1. values pre-pass
   long long vt = (pl.M + d->batch_size + 15) / 16;
   int vgrid = (int)(vt < 4LL * ppo_num_cus() ? vt : 4LL * ppo_num_cus());
-  if (pl.H == 64) {
+  if (pl.layered) {
+    float *values = nullptr;
+    rc = ppo_layered_values(d, pl.pi, pl.v, ws + pl.off_layered, A.trunc, A.term, A.rew, &values, st);
+    if (rc != MBPO_OK) return rc;
+    A.baseline = values;
+    A.boot = values + pl.M;
+  } else if (pl.H == 64) {
     rc = mbpo_ensure_lds<k_ppo_values<64>>(pl.lds_values, "ppo_grads");
     if (rc != MBPO_OK) return rc;
     hipLaunchKernelGGL(k_ppo_values<64>, dim3(vgrid), dim3(256), pl.lds_values, st, A);
@@ -667,7 +684,10 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
     }
   }
   // 4. loss forward/backward
-  if (pl.H == 64) {
+  if (pl.layered) {
+    rc = ppo_layered_fwd_bwd(d, pl.pi, pl.v, ws + pl.off_layered, A.vs, A.adv, A.mom, A.slabs, A.extras, st);
+    if (rc != MBPO_OK) return rc;
+  } else if (pl.H == 64) {
     const bool wide = net_is_wide(A.sh_pi) || net_is_wide(A.sh_v);
     rc = wide ? mbpo_ensure_lds<k_ppo_fwd_bwd<64, 4, true>>(pl.lds_fb, "ppo_grads") : mbpo_ensure_lds<k_ppo_fwd_bwd<64, 4, false>>(pl.lds_fb, "ppo_grads");
     if (rc != MBPO_OK) return rc;

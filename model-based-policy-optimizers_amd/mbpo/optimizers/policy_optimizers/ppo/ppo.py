@@ -115,12 +115,21 @@ class PPO:
         self.policy_dims_logical = [self.x_dim, *policy_hidden_layer_sizes, 2 * self.u_dim]
         self.value_dims_logical = [self.x_dim, *critic_hidden_layer_sizes, 1]
         dyn_hidden = list(getattr(getattr(self.env.system, "dynamics", None), "dims", [])[1:-1]) if self.env.system.fused else []
-        self.kernel_width = ops.common_width(policy_hidden_layer_sizes, critic_hidden_layer_sizes, dyn_hidden, what="PPO")
+        widest = max([int(h) for h in (*policy_hidden_layer_sizes, *critic_hidden_layer_sizes, *dyn_hidden)], default=0)
+        if widest <= ops.KERNEL_WIDTHS[-1]:
+            self.kernel_width = ops.common_width(policy_hidden_layer_sizes, critic_hidden_layer_sizes, dyn_hidden, what="PPO")
+            self.value_width = self.kernel_width
+        else:
+            # wider than the fused update kernels take (ppo.py:60-63 accepts any tuple; exp_ppo.py: a 256x5 critic): the minibatch
+            # update then runs layer by layer (csrc/ppo_layered.hip) — the value net keeps its logical sizes; the policy, which also
+            # runs inside the rollout / act kernels, is padded to one of their widths
+            self.kernel_width = ops.common_width(policy_hidden_layer_sizes, dyn_hidden, supported=ops.ROLLOUT_WIDTHS, what="PPO policy")
+            self.value_width = None
         if dyn_hidden and any(h != self.kernel_width for h in dyn_hidden):
-            raise _hip.MbpoHipError(f"PPO: the learned ensemble's hidden width {dyn_hidden} must equal the policy/value kernel width "
+            raise _hip.MbpoHipError(f"PPO: the learned ensemble's hidden width {dyn_hidden} must equal the policy's kernel width "
                                     f"{self.kernel_width} inside the fused rollout (build the EnsembleDynamics with that width)")
         self.policy_dims = ops.padded_dims(self.policy_dims_logical, self.kernel_width)     # hidden layers zero-padded (ops.py)
-        self.value_dims = ops.padded_dims(self.value_dims_logical, self.kernel_width)
+        self.value_dims = ops.padded_dims(self.value_dims_logical, self.value_width)
         self.policy_spec = ops.MlpSpec(self.policy_dims, policy_activation, 1)
         self.dp = DataParallel(process_group)
         self._all_reduce = self.dp.all_reduce_fn()
@@ -183,7 +192,7 @@ class PPO:
         pol = ops.embed_mlp_params(lecun_uniform_flat(self.policy_dims_logical, torch.Generator().manual_seed(k0 % (2 ** 63))),
                                    self.policy_dims_logical, self.kernel_width)
         val = ops.embed_mlp_params(lecun_uniform_flat(self.value_dims_logical, torch.Generator().manual_seed(k1 % (2 ** 63))),
-                                   self.value_dims_logical, self.kernel_width)
+                                   self.value_dims_logical, self.value_width)
         params = torch.cat([pol, val]).to(self.device)
         self.dp.broadcast(params, src=0)
         self.updater.load_state(params)

@@ -15,9 +15,9 @@ from oracle import ppo as oppo
 pytestmark = pytest.mark.gpu
 
 
-def _make(X, U, hidden, B, T, seed, normalize, **kw):
+def _make(X, U, hidden, B, T, seed, normalize, v_hidden=None, **kw):
     g = torch.Generator().manual_seed(seed)
-    cfg = oppo.PpoConfig(x_dim=X, u_dim=U, policy_dims=[X, *hidden, 2 * U], value_dims=[X, *hidden, 1], **kw)
+    cfg = oppo.PpoConfig(x_dim=X, u_dim=U, policy_dims=[X, *hidden, 2 * U], value_dims=[X, *(hidden if v_hidden is None else v_hidden), 1], **kw)
     st = oppo.init_state(cfg, g)
     st.params = st.params + 0.03 * torch.randn(st.params.shape, generator=g)
     D = 2 * X + 2 * U + 4
@@ -75,6 +75,41 @@ def test_ppo_gradients_and_step(dev, X, U, hidden, B, T, normalize, norm_adv):
     assert float(up.step_count.cpu()) == 1.0
 
 
+@pytest.mark.parametrize("X,U,hidden,v_hidden,B,T,normalize,norm_adv", [
+    (3, 1, (32, 32, 32, 32), (256,) * 5, 64, 10, True, True),      # experiments/train_inverted_pendulum/exp_ppo.py:36-38
+    (4, 2, (48, 80), (200, 72, 40), 20, 7, True, False),           # unequal hidden layers, ragged M = 140
+    (17, 6, (300,), (96,), 256, 12, False, True),                  # M = 3072 rows: weight gradients split over the rows
+])
+def test_ppo_layered_path_any_widths(dev, X, U, hidden, v_hidden, B, T, normalize, norm_adv):
+    """Shapes outside the fused kernels' range (ppo.py:60-63 accepts any tuple): values pre-pass and loss forward/backward run layer
+    by layer (csrc/ppo_layered.hip); GAE scan, moments, reduction and AdamW are the fused path's.  mbpo_ppo_grads + mbpo_ppo_apply
+    and mbpo_ppo_step give the same bits."""
+    cfg, st, data, noise, nm, ns = _make(X, U, hidden, B, T, 4, normalize, v_hidden=v_hidden, entropy_cost=1e-2, discounting=0.99,
+                                          reward_scaling=0.5, gae_lambda=0.95, clipping_epsilon=0.3, normalize_advantage=norm_adv,
+                                          lr=3e-4, wd=1e-5)
+    d64 = lambda t: None if t is None else t.double()
+    g_ref64, terms64, vs64, adv64 = oppo.grads(cfg, st.params.double(), data.double(), noise.double(), d64(nm), d64(ns))
+    dd = lambda t: None if t is None else t.to(dev)
+    outs = []
+    for fused in ("0", "1"):
+        up = _updater(dev, cfg, B, T)
+        up.fused_step = fused == "1"
+        up.load_state(st.params.to(dev))
+        up.minibatch_step(data.to(dev), dd(nm), dd(ns), noise.to(dev))
+        torch.cuda.synchronize()
+        outs.append((up.grads.cpu().clone(), up.params.cpu().clone(), up.metrics.cpu().clone()))
+        assert float(up.step_count.cpu()) == 1.0
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    g = outs[0][0]
+    scale = float(g_ref64.abs().max())
+    torch.testing.assert_close(g.double(), g_ref64, atol=2e-6 + 2e-6 * scale, rtol=5e-4)
+    np.testing.assert_allclose(outs[0][2].tolist(), [terms64["total_loss"], terms64["policy_loss"], terms64["v_loss"], terms64["entropy_loss"]],
+                               rtol=5e-5, atol=1e-5)
+    st_new, _, _ = oppo.minibatch_step(cfg, st, data, noise, nm, ns, grad_override=g)
+    torch.testing.assert_close(outs[0][1], st_new.params, atol=1e-7, rtol=1e-6)
+
+
 def test_ppo_clip_branches(dev):
     """Behaviour log-probs far from the target ones push rho outside [1-eps, 1+eps] on both sides: the clipped branch
     (zero gradient) and the unclipped-but-smaller branch must both match autograd."""
@@ -103,8 +138,10 @@ def test_ppo_chained_minibatches(dev):
 
 def test_ppo_bad_args(dev):
     from mbpo import ops, _hip
-    with pytest.raises(_hip.MbpoHipError):
-        ops.PpoUpdater(x_dim=3, u_dim=1, policy_dims=[3, 64, 128, 2], value_dims=[3, 64, 64, 1], batch_size=8, unroll_length=4, device=dev)
+    with pytest.raises(_hip.MbpoHipError):      # the value net ends in one output
+        ops.PpoUpdater(x_dim=3, u_dim=1, policy_dims=[3, 64, 64, 2], value_dims=[3, 64, 64, 2], batch_size=8, unroll_length=4, device=dev)
+    # unequal hidden layers are not an error: the layered path (test_ppo_layered_path_any_widths)
+    ops.PpoUpdater(x_dim=3, u_dim=1, policy_dims=[3, 64, 128, 2], value_dims=[3, 64, 64, 1], batch_size=8, unroll_length=4, device=dev)
 
 
 def test_ppo_step_against_committed_golden(dev):

@@ -450,7 +450,8 @@ def test_sac_padded_widths_match_the_logical_networks(dev, ph, qh):
 def test_sac_trainer_accepts_reference_experiment_shapes(dev):
     """exp.py / exp_ppo.py-like shapes through the trainers: policy (32,)*4 with critic (48,)*3 trains on the fused kernels (zero-
     padded to 64); SAC with exp_ppo.py's 256x5 critic, or with more 128-wide layers than a tile's LDS holds, trains on the layered
-    path (INTEGRATION.md "Network shapes"); PPO still names its cap."""
+    path (INTEGRATION.md "Network shapes"), and so does PPO with that critic; a POLICY wider than the rollout kernels take (256) is
+    refused by name."""
     from mbpo import _hip
     from mbpo.optimizers.policy_optimizers.ppo.ppo import PPO
     from mbpo.optimizers.policy_optimizers.sac.sac import SAC
@@ -490,8 +491,13 @@ def test_sac_trainer_accepts_reference_experiment_shapes(dev):
     assert wide_pol.kernel_width == 256 and wide_pol.q_dims == [4, 300, 100, 1]
     params, metrics = wide_pol.run_training(key=5)
     assert bool(torch.isfinite(wide_pol.updater.params).all())
-    with pytest.raises(_hip.MbpoHipError, match="exceeds"):
+    wide_ppo = PPO(environment=env, num_timesteps=2000, episode_length=10, num_envs=32, unroll_length=5, batch_size=16, num_minibatches=2,
+                   policy_hidden_layer_sizes=(32,) * 4, critic_hidden_layer_sizes=(256,) * 5)          # exp_ppo.py:36-38 verbatim
+    assert wide_ppo.kernel_width == 64 and wide_ppo.value_width is None and wide_ppo.value_dims == [3, 256, 256, 256, 256, 256, 1]
+    params, metrics = wide_ppo.run_training(key=6)
+    assert bool(torch.isfinite(params[1]).all())
+    with pytest.raises(_hip.MbpoHipError, match="exceeds"):       # a policy also runs inside the rollout kernels: one width up to 256
         PPO(environment=env, num_timesteps=2000, episode_length=10, num_envs=32, unroll_length=5, batch_size=16, num_minibatches=2,
-            critic_hidden_layer_sizes=(256,) * 5)
+            policy_hidden_layer_sizes=(512, 512))
     ok = SAC(environment=env, num_timesteps=1000, episode_length=10, policy_hidden_layer_sizes=(100, 100, 100), critic_hidden_layer_sizes=(128,) * 3)
     assert ok.kernel_width == 128
