@@ -267,6 +267,10 @@ int mbpo_gae_scan_discounts(const float *truncation, const float *termination, c
  *                         metrics[3] = exp(new log_alpha).
  * Noise: explicit standard-normal tensors [B,u] or NULL -> Philox(seed, offset [+ rng_dev]), streams 5/6/7: the caller
  *        advances `offset` (or the device counter) between sgd_steps.
+ * Network shapes (sac.py:84-88 takes any tuple): policy and critics with hidden layers of ONE common width in {64, 128} whose 16-row
+ *        tile fits the LDS run on the fused wave-chain kernel; every other shape (any hidden sizes, up to MBPO_MAX_LAYERS Dense layers)
+ *        runs its forward/backward layer by layer — one GEMM launch per Dense layer — behind the same entry points, with the same
+ *        results contract (mbpo_sac_step == mbpo_sac_grads + mbpo_sac_apply bit for bit).
  */
 typedef struct mbpo_sac_desc {
   int32_t x_dim, u_dim;
@@ -336,6 +340,8 @@ int mbpo_sac_finalize_advance(const mbpo_sac_desc *d, uint64_t *rng_dev, uint64_
  *   mbpo_ppo_apply : grads *= grad_scale; AdamW.   All-reduce `grads` in between for N>1 ranks (ppo.py:149-154's pmean).
  * data: one minibatch [batch_size, unroll_length, row_len] of PPO rows (row_len = 2x+2u+4), i.e. the rollout kernel's
  *       env_major output after the permutation gather.  entropy_noise [B,T,u] or NULL -> Philox(seed, offset [+ rng_dev], stream 9).
+ * Network shapes (ppo.py:60-63 takes any tuple): as for SAC — one common hidden width in {64, 128} -> fused kernels, anything else
+ *       (e.g. experiments/train_inverted_pendulum/exp_ppo.py's 256x5 critic) -> layer by layer behind the same entry points.
  */
 typedef struct mbpo_ppo_desc {
   int32_t x_dim, u_dim;
