@@ -31,7 +31,10 @@ struct PpoArgs {
   float *baseline, *boot, *trunc, *term, *rew, *vs, *adv, *mom, *slabs, *extras;
   int n_slabs;
   int ld_x, ld_h, ld_y, LH;
-  int mom_inline;            // 1: k_ppo_fwd_bwd forms the advantage moments itself (no k_moments_fused launch)
+  int mom_inline;            // (unused)
+  float *mom_part;
+  int mom_parts;
+  int vg_G;                  // k_ppo_values_gae: trajectories per workgroup; its workgroups leave {n, mean, M2} partials in mom_part
   float *step_count_rw;      // optax's count: bumped by block 0 of the FIRST launch of a minibatch_step (k_ppo_values), so that every
                              // later launch of the step — the reduce launch that also applies AdamW, or k_ppo_apply — reads the final value
 };
@@ -92,6 +95,116 @@ __device__ __forceinline__ float ppo_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;
+}
+
+// ------------------------------------------------------------------------------------------------ values + GAE + moment partials
+// One launch for k_ppo_values + mbpo_gae_scan + the advantage moments' first stage: a workgroup owns G whole trajectories (T samples +
+// the bootstrap row each), runs the value net on their rows tile by tile (values stay in LDS), then one thread per trajectory walks
+// compute_gae's recurrences backwards in the reference's own order (losses.py:150-184, as k_scan_time_major) and the first wave
+// leaves {n, mean, M2} of the workgroup's advantages (two passes over LDS: exact).  k_ppo_fwd_bwd combines the partials (Chan et
+// al.: M2 = sum M2_i + sum n_i (mean_i - mean)^2, fixed order).  Three launches and two kernel boundaries less per minibatch_step.
+template <int H, int NC>     // NC tiles at a time, each on its own chain of 4 waves (a trajectory of T = 40 is 3 tiles: one chain latency, not three)
+__global__ void __launch_bounds__(256 * NC) k_ppo_values_gae(PpoArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int HT = H / 16;
+  const int tid_ = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+  const int chain = wave >> 2, sub = wave & 3;
+  const int X = A.X, U = A.U, D = A.D, T = A.T, R = T + 1, G = A.vg_G;
+  const int per_chain = 16 * A.ld_x + 2 * 16 * A.ld_h + 16 * A.ld_y;
+  float *s_x = smem + chain * per_chain;     // [16][ld_x]
+  float *s_pp = s_x + 16 * A.ld_x;           // 2 hidden tiles
+  float *s_y = s_pp + 2 * 16 * A.ld_h;       // [16][ld_y]
+  float *s_val = smem + NC * per_chain;      // [G][R] values (the last of each row: the bootstrap)
+  float *s_tr = s_val + ((G * R + 3) & ~3);  // [G][T] truncation | termination | scaled reward | advantages
+  float *s_te = s_tr + ((G * T + 3) & ~3), *s_rw = s_te + ((G * T + 3) & ~3), *s_adv = s_rw + ((G * T + 3) & ~3);
+  const long long b0 = (long long)blockIdx.x * G;
+  const int g_here = (int)((A.B - b0 < G) ? A.B - b0 : G);
+  const int rows = g_here * R;
+  if (blockIdx.x == 0 && tid_ == 0) A.step_count_rw[0] = A.step_count_rw[0] + 1.0f;     // (nothing in this launch reads it)
+#pragma nounroll
+  for (int rr = 0; rr < rows; rr += 16 * NC) {
+    const int tid = opaque(tid_), lane = tid & 63, ctid = tid & 255;
+    const int r0 = rr + 16 * chain;
+    const bool live = r0 < rows;             // (wave-uniform: a chain without a tile only keeps the barriers)
+    WSet<HT, 4> Rw;
+    if (live) {
+      chain_fwd_prefetch<HT, 4>(Rw, A.sh_v, A.v.params, sub, lane);
+      for (int idx = ctid; idx < 16 * X; idx += 256) {
+        const int r = idx & 15, c = idx >> 4;
+        const int lrow = r0 + r;
+        float o = 0.f;
+        if (lrow < rows) {
+          const int g = lrow / R, t = lrow - g * R;
+          const long long base = ((b0 + g) * T + (t < T ? t : T - 1)) * D;
+          o = A.data[base + (t < T ? c : X + U + 2 + c)];                  // observation | next_observation[-1]  (losses.py:84-85)
+          if (A.norm_mean) o = (o - A.norm_mean[c]) / A.norm_std[c];
+        }
+        s_x[r * A.ld_x + c] = o;
+      }
+      if (ctid < 16) {
+        const int lrow = r0 + ctid;
+        if (lrow < rows) {
+          const int g = lrow / R, t = lrow - g * R;
+          if (t < T) {
+            const float *row = A.data + ((b0 + g) * T + t) * D;
+            const float tr = row[D - 1], disc = row[X + U + 1];
+            s_tr[g * T + t] = tr;
+            s_te[g * T + t] = (1.f - disc) * (1.f - tr);             // termination = (1 - discount) * (1 - truncation)   (:89)
+            s_rw[g * T + t] = row[X + U] * A.reward_scaling;          // rewards = data.reward * reward_scaling             (:87)
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (live)
+      chain_fwd_run<HT, 4>(A.sh_v, A.v.params, s_x, A.ld_x, s_pp, s_pp + 16 * A.ld_h, nullptr, nullptr, s_y, A.ld_y, A.ld_h, A.sh_v.L,
+                           sub, lane, Rw);
+    else
+      chain_idle_run(A.sh_v.L);
+    if (live && ctid < 16 && r0 + ctid < rows) s_val[r0 + ctid] = s_y[ctid * A.ld_y];
+    __syncthreads();
+  }
+  // compute_gae, one thread per trajectory, backwards (losses.py:150-184)
+  if (tid_ < g_here) {
+    const int g = tid_;
+    const float boot = s_val[g * R + T];
+    float acc = 0.f, v_next = boot, vs_next = boot;
+    for (int t = T - 1; t >= 0; --t) {
+      const float tr = s_tr[g * T + t], te = s_te[g * T + t], r = s_rw[g * T + t], v = s_val[g * R + t];
+      const float m = 1.f - tr;
+      const float g1 = A.discounting * (1.f - te);
+      const float delta = (r + g1 * v_next - v) * m;        // :157-158
+      acc = delta + g1 * m * A.gae_lambda * acc;            // :166
+      const float vs = acc + v;                             // :176
+      const float adv = (r + g1 * vs_next - v) * m;         // :181-182
+      const long long i = (b0 + g) * T + t;
+      A.vs[i] = vs;
+      A.adv[i] = adv;
+      s_adv[g * T + t] = adv;
+      v_next = v;
+      vs_next = vs;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int n = g_here * T, lane = tid_ & 63;
+    float a = 0.f;
+    for (int i = lane; i < n; i += 64) a += s_adv[i];
+    a = ppo_wave_sum(a);
+    const float mean = __shfl(a, 0, 64) / (float)n;
+    float q = 0.f;
+    for (int i = lane; i < n; i += 64) {
+      const float dd = s_adv[i] - mean;
+      q += dd * dd;
+    }
+    q = ppo_wave_sum(q);
+    if (lane == 0) {
+      A.mom_part[4 * blockIdx.x + 0] = (float)n;
+      A.mom_part[4 * blockIdx.x + 1] = mean;
+      A.mom_part[4 * blockIdx.x + 2] = q;
+    }
+  }
 }
 
 // PASS 0: partial[g] = sum x ; PASS 1: partial[g] = sum (x - mean)^2
@@ -169,6 +282,49 @@ __device__ __forceinline__ float pp_ftanh(float x) {
   const float e = pp_fexp(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
   return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
 }
+// The advantage moments from the per-workgroup partials {n_i, mean_i, M2_i} of k_ppo_values_gae (Chan et al.: mean = sum n_i mean_i / M,
+// M2 = sum M2_i + sum n_i (mean_i - mean)^2), one workgroup, fixed order.  A launch of its own: k_ppo_fwd_bwd<64,2> sits at 128 VGPRs
+// with ~50 spilled, and ANY code added to it — this combine inlined, behind a barrier-free LDS hand-off, or behind a noinline call —
+// moved the allocator's choices in its tile loop: 6-9 us per launch at every size (rocprofv3, round 3), more than this launch costs.
+// (Finishing in the last workgroup of k_ppo_values_gae behind an arrival counter cost that kernel 7 us.)
+__global__ void __launch_bounds__(256) k_ppo_moments_combine(const float *part, int n_parts, float M, float *mom) {
+  __shared__ float s_cw[4];
+  __shared__ float s_cm;
+  const int tid = threadIdx.x;
+  constexpr int NPT = 4;                      // <= 4 * CUs partials
+  float pn[NPT], pm[NPT], pq[NPT];
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const int p = tid + k * 256;
+    const bool ok = p < n_parts;
+    pn[k] = ok ? part[4 * p] : 0.f;
+    pm[k] = ok ? part[4 * p + 1] : 0.f;
+    pq[k] = ok ? part[4 * p + 2] : 0.f;
+  }
+  float a = 0.f;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) a += pn[k] * pm[k];
+  a = ppo_wave_sum(a);
+  if ((tid & 63) == 0) s_cw[tid >> 6] = a;
+  __syncthreads();
+  if (tid == 0) s_cm = (((s_cw[0] + s_cw[1]) + s_cw[2]) + s_cw[3]) / M;
+  __syncthreads();
+  const float mean = s_cm;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    const float dm = pm[k] - mean;
+    q += pq[k] + pn[k] * dm * dm;
+  }
+  q = ppo_wave_sum(q);
+  if ((tid & 63) == 0) s_cw[tid >> 6] = q;
+  __syncthreads();
+  if (tid == 0) {
+    mom[0] = mean;
+    mom[1] = sqrtf((((s_cw[0] + s_cw[1]) + s_cw[2]) + s_cw[3]) / M);     // population std (jnp.std)
+  }
+}
+
 // SP = 2 at H = 64 (512 threads, held to 128 VGPRs by the waves-per-SIMD request): TWO workgroups share a CU, so a tile's chain of
 // dependent layer steps overlaps with another tile's — the launch is a latency chain per tile (MFMA pipes ~17 % busy with one
 // 1024-thread workgroup per CU), not a throughput problem.  The host picks it when there are more tiles than CUs.
@@ -199,63 +355,8 @@ __global__ void __launch_bounds__(256 * SP, (H == 64 && SP == 2) ? 4 : 1) k_ppo_
   const int PL = A.pi.n_layers, VL = A.v.n_layers;
   const int Lmax = PL > VL ? PL : VL;
   const float invM = 1.0f / (float)M;
-  // Advantage moments over the WHOLE minibatch (losses.py:101-102), formed here by every workgroup for itself when the minibatch is
-  // small enough (mom_inline): k_moments_fused's arithmetic in k_moments_fused's order — its 1024 threads are VIRTUAL here, thread t
-  // of a 512-thread workgroup playing t and t + 512 — so the numbers are bit for bit the separate launch's, which this removes
-  // (one launch of seven per minibatch_step; at T = 5 the step is launch-bound).  M floats from L2 per workgroup.
-  float adv_mean = 0.f, adv_istd = 1.f;
-  if (A.normalize_advantage && !A.mom_inline) {
-    adv_mean = A.mom[0];
-    adv_istd = 1.0f / (A.mom[1] + 1e-8f);
-  } else if (A.normalize_advantage) {
-    __shared__ float s_mw[16];
-    __shared__ float s_mm[2];
-    constexpr int VT = 1024 / (256 * SP);            // virtual threads per thread: 1 or 2
-    float acc[VT];
-#pragma unroll
-    for (int v = 0; v < VT; ++v) {
-      acc[v] = 0.f;
-#pragma unroll 4
-      for (long long i = tid_ + v * nthreads; i < M; i += 1024) acc[v] += A.adv[i];
-      acc[v] = ppo_wave_sum(acc[v]);
-      if ((tid_ & 63) == 0) s_mw[(tid_ >> 6) + v * (nthreads >> 6)] = acc[v];
-    }
-    __syncthreads();
-    if (tid_ == 0) {
-      float a = 0.f;
-      for (int k = 0; k < 16; ++k) a += s_mw[k];
-      s_mm[0] = a / (float)M;
-    }
-    __syncthreads();
-    const float mean = s_mm[0];
-#pragma unroll
-    for (int v = 0; v < VT; ++v) {
-      acc[v] = 0.f;
-#pragma unroll 4
-      for (long long i = tid_ + v * nthreads; i < M; i += 1024) {
-        const float dd = A.adv[i] - mean;
-        acc[v] += dd * dd;
-      }
-      acc[v] = ppo_wave_sum(acc[v]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int v = 0; v < VT; ++v)
-      if ((tid_ & 63) == 0) s_mw[(tid_ >> 6) + v * (nthreads >> 6)] = acc[v];
-    __syncthreads();
-    if (tid_ == 0) {
-      float a = 0.f;
-      for (int k = 0; k < 16; ++k) a += s_mw[k];
-      s_mm[1] = sqrtf(a / (float)M);                 // population std (jnp.std)
-      if (blockIdx.x == 0) {
-        A.mom[0] = mean;
-        A.mom[1] = s_mm[1];
-      }
-    }
-    __syncthreads();
-    adv_mean = mean;
-    adv_istd = 1.0f / (s_mm[1] + 1e-8f);
-  }
+  const float adv_mean = A.normalize_advantage ? A.mom[0] : 0.f;
+  const float adv_istd = A.normalize_advantage ? 1.0f / (A.mom[1] + 1e-8f) : 1.f;          // losses.py:101-102
   const RngKey rk_ = rng_resolve(A.seed, A.offset, A.rng_dev);
   const unsigned long long rng_off = rk_.offset, rng_seed = rk_.seed;
   float *slab = A.slabs + (long long)blockIdx.x * (A.pi.n_params + A.v.n_params);
@@ -517,6 +618,11 @@ struct PpoPlan {
   int ld_x, ld_h, ld_y;
   size_t lds_values, lds_fb;
   long long off_baseline, off_boot, off_trunc, off_term, off_rew, off_vs, off_adv, off_mom, off_part, off_slabs, off_extras, off_layered, total;
+  // values + GAE + moment partials in one launch (k_ppo_values_gae): vg_G trajectories per workgroup, n_vg workgroups; 0 = the three
+  // separate launches (layered shapes; trajectories too long for a workgroup's LDS arrays; MBPO_PPO_VALUES_GAE=0)
+  int vg_G, n_vg;
+  size_t lds_vg;
+  long long off_mompart;
   // hidden layers outside the fused kernels' range (one width in {64,128}): values pre-pass and loss forward/backward run layer by
   // layer (ppo_layered.hip) and leave ONE slab; GAE scan, moments, reduction, metrics and AdamW are shared
   bool layered;
@@ -602,6 +708,20 @@ static int ppo_plan(const mbpo_ppo_desc *d, PpoPlan *pl, bool need_ptrs) {
   pl->off_baseline = take(pl->M); pl->off_boot = take(d->batch_size); pl->off_trunc = take(pl->M); pl->off_term = take(pl->M);
   pl->off_rew = take(pl->M); pl->off_vs = take(pl->M); pl->off_adv = take(pl->M); pl->off_mom = take(4); pl->off_part = take(PPO_MOM_WGS);
   pl->off_slabs = take((long long)pl->n_slabs * pl->NPV); pl->off_extras = take((long long)pl->n_slabs * 4);
+  {
+    // G = 1 while that does not oversubscribe the chip (a tile with a few rows of one trajectory wastes MFMA lanes nobody else wants:
+    // the launch is a latency chain per workgroup); beyond 4 workgroups per CU, more trajectories per workgroup
+    static const int vg_env = getenv("MBPO_PPO_VALUES_GAE") ? atoi(getenv("MBPO_PPO_VALUES_GAE")) : -1;
+    const long long cap_wg = 4LL * ppo_num_cus();
+    long long G = (d->batch_size + cap_wg - 1) / cap_wg;
+    if (G < 1) G = 1;
+    const long long R = (long long)d->unroll_length + 1;
+    pl->vg_G = (!pl->layered && vg_env != 0 && G * R <= 1024) ? (int)G : 0;
+    pl->n_vg = pl->vg_G ? (int)((d->batch_size + pl->vg_G - 1) / pl->vg_G) : 0;
+    const long long GT = (long long)pl->vg_G * d->unroll_length;
+    pl->lds_vg = pl->lds_values + sizeof(float) * (size_t)(((pl->vg_G * R + 3) & ~3LL) + 4 * ((GT + 3) & ~3LL));
+    pl->off_mompart = take(4LL * (pl->n_vg > 0 ? pl->n_vg : 1));
+  }
   pl->off_layered = o;
   if (pl->layered) o += ppo_layered_floats(d, pl->pi, pl->v);
   pl->total = o;
@@ -632,12 +752,8 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
   A.X = d->x_dim; A.U = d->u_dim; A.B = d->batch_size; A.T = d->unroll_length; A.D = d->row_len;
   A.data = d->data; A.norm_mean = d->norm_mean; A.norm_std = d->norm_std; A.ent_noise = d->entropy_noise;
   A.step_count_rw = d->step_count;
-  {
-    // every workgroup re-reads the M advantages twice: worth a launch only while that is a few KB — C3 at T = 5 (M = 2560): 12.39 ->
-    // 12.19 ms per training step; at T = 40 (M = 20480, 512 workgroups) it COST 1.8 ms (28.0 -> 29.8).  MBPO_PPO_MOM_INLINE=0 disables.
-    static const int mi_env = getenv("MBPO_PPO_MOM_INLINE") ? atoi(getenv("MBPO_PPO_MOM_INLINE")) : -1;
-    A.mom_inline = (!pl.layered && d->normalize_advantage && pl.H == 64 && pl.M <= 4096 && mi_env != 0) ? 1 : 0;
-  }
+  A.mom_inline = 0;
+  A.mom_part = ws + pl.off_mompart; A.mom_parts = pl.n_vg; A.vg_G = pl.vg_G;
   A.seed = d->seed; A.offset = d->offset; A.rng_dev = (const unsigned long long *)d->rng_dev;
   A.entropy_cost = d->entropy_cost; A.discounting = d->discounting; A.reward_scaling = d->reward_scaling;
   A.gae_lambda = d->gae_lambda; A.clip_eps = d->clipping_epsilon; A.normalize_advantage = d->normalize_advantage;
@@ -655,6 +771,25 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
     if (rc != MBPO_OK) return rc;
     A.baseline = values;
     A.boot = values + pl.M;
+  } else if (pl.vg_G) {
+    // 1-3 in one launch: values, GAE, the moments' per-workgroup partials
+    const int tiles_wg = (int)(((long long)pl.vg_G * (d->unroll_length + 1) + 15) / 16);
+    const int NCv = tiles_wg >= 4 ? 4 : tiles_wg;
+    const size_t lds = pl.lds_vg + (size_t)(NCv - 1) * pl.lds_values;
+#define LVG(H_, N_)                                                                                  \
+  {                                                                                                  \
+    rc = mbpo_ensure_lds<k_ppo_values_gae<H_, N_>>(lds, "ppo_grads");                                \
+    if (rc != MBPO_OK) return rc;                                                                    \
+    hipLaunchKernelGGL((k_ppo_values_gae<H_, N_>), dim3(pl.n_vg), dim3(256 * N_), lds, st, A);        \
+  }
+    if (pl.H == 64) {
+      if (NCv == 1) LVG(64, 1) else if (NCv == 2) LVG(64, 2) else if (NCv == 3) LVG(64, 3) else LVG(64, 4)
+    } else {
+      if (NCv == 1) LVG(128, 1) else if (NCv == 2) LVG(128, 2) else if (NCv == 3) LVG(128, 3) else LVG(128, 4)
+    }
+#undef LVG
+    if (d->normalize_advantage)
+      hipLaunchKernelGGL(k_ppo_moments_combine, dim3(1), dim3(256), 0, st, (const float *)A.mom_part, pl.n_vg, (float)pl.M, A.mom);
   } else if (pl.H == 64) {
     rc = mbpo_ensure_lds<k_ppo_values<64>>(pl.lds_values, "ppo_grads");
     if (rc != MBPO_OK) return rc;
@@ -665,17 +800,17 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
     hipLaunchKernelGGL(k_ppo_values<128>, dim3(vgrid), dim3(256), pl.lds_values, st, A);
   }
   // 2. GAE on [B,T] (batch-major: the data's native layout, no transpose)   losses.py:94-99,128-184
-  rc = mbpo_gae_scan(A.trunc, A.term, A.rew, A.baseline, A.boot, A.vs, A.adv, d->batch_size, d->unroll_length, d->discounting,
-                     d->gae_lambda, 0, stream);
-  if (rc != MBPO_OK) return rc;
+  if (!pl.vg_G) {
+    rc = mbpo_gae_scan(A.trunc, A.term, A.rew, A.baseline, A.boot, A.vs, A.adv, d->batch_size, d->unroll_length, d->discounting,
+                       d->gae_lambda, 0, stream);
+    if (rc != MBPO_OK) return rc;
+  }
   // 3. advantage moments over the whole minibatch
-  if (d->normalize_advantage) {
+  if (d->normalize_advantage && !pl.vg_G) {
     float *part = ws + pl.off_part;
     long long blocks = (pl.M + 255) / 256;
     int g = (int)(blocks < PPO_MOM_WGS ? blocks : PPO_MOM_WGS);
-    if (A.mom_inline) {
-      // (formed inside k_ppo_fwd_bwd)
-    } else if (pl.M <= PPO_MOM_FUSED_MAX) hipLaunchKernelGGL(k_moments_fused, dim3(1), dim3(1024), 0, st, (const float *)A.adv, pl.M, A.mom);
+    if (pl.M <= PPO_MOM_FUSED_MAX) hipLaunchKernelGGL(k_moments_fused, dim3(1), dim3(1024), 0, st, (const float *)A.adv, pl.M, A.mom);
     else {
     hipLaunchKernelGGL(k_moments_partial<0>, dim3(g), dim3(256), 0, st, (const float *)A.adv, pl.M, (const float *)A.mom, part);
     hipLaunchKernelGGL(k_moments_final<0>, dim3(1), dim3(64), 0, st, (const float *)part, g, pl.M, A.mom);
