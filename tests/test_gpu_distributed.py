@@ -20,11 +20,11 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _make(world, B):
+def _make(world, B, hp=(64, 64, 64), hq=(64, 64, 64)):
     from oracle import sac as osac
     X, U = 4, 1
     g = torch.Generator().manual_seed(0)
-    cfg = osac.SacConfig(X, U, [X, 64, 64, 64, 2 * U], [X + U, 64, 64, 64, 1], lr_policy=1e-3, lr_q=1e-3, lr_alpha=1e-3,
+    cfg = osac.SacConfig(X, U, [X, *hp, 2 * U], [X + U, *hq, 1], lr_policy=1e-3, lr_q=1e-3, lr_alpha=1e-3,
                          max_grad_norm=0.05)
     st = osac.init_state(cfg, g)
     D = 2 * X + U + 3
@@ -131,7 +131,7 @@ def test_p2p_all_reduce_two_ranks_one_gpu(tmp_path):
     assert all((tmp_path / f"p2p_ok{r}").exists() for r in range(world))
 
 
-def _p2p_sac_worker(rank, world, port, tmpdir, fused):
+def _p2p_sac_worker(rank, world, port, tmpdir, fused, layered=False):
     _setup_paths()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -143,7 +143,7 @@ def _p2p_sac_worker(rank, world, port, tmpdir, fused):
         from mbpo.parallel import DataParallel, P2PExchange
         dp = DataParallel(dist.group.WORLD)
         B = 32
-        cfg, st, batch, noise = _make(world, B)
+        cfg, st, batch, noise = _make(world, B, *(((96, 40), (200,)) if layered else ()))
         sl = slice(rank * B, (rank + 1) * B)
         up = _updater(cfg, B, dev, world_size=world)
         ex = P2PExchange.create(dp, up.NP, dev)
@@ -185,6 +185,16 @@ def test_sac_sgd_step_over_peer_memory_two_ranks(tmp_path, fused):
     world = 2
     port = 35500 + (os.getpid() % 2000) + (7 if fused else 0)
     mp.spawn(_p2p_sac_worker, args=(world, port, str(tmp_path), fused), nprocs=world, join=True)
+    assert all((tmp_path / f"p2psac_ok{r}").exists() for r in range(world))
+
+
+@pytest.mark.timeout(180)
+def test_sac_layered_sgd_step_over_peer_memory_two_ranks(tmp_path):
+    """The same exchange behind the layered forward/backward (hidden sizes outside the fused kernel's range: policy (96, 40), critics
+    (200,)): its first launch moves the exchange's epoch words as block 0 of the fused kernel does."""
+    world = 2
+    port = 35500 + (os.getpid() % 2000) + 13
+    mp.spawn(_p2p_sac_worker, args=(world, port, str(tmp_path), True, True), nprocs=world, join=True)
     assert all((tmp_path / f"p2psac_ok{r}").exists() for r in range(world))
 
 
