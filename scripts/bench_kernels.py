@@ -246,7 +246,9 @@ def main():
         t, te = both(lambda: up.sgd_step(batch, defer_clip_check=True), reps)
         up.finalize()
         flop = B * 2 * (5 * mlp_macs(pd) + 12 * mlp_macs(qd))
-        out.append(mfma_entry("k_sac_fwd_bwd + k_sac_reduce_apply", "mbpo_sac_step",
+        layered = not (len(set(hidden)) == 1 and hidden[0] in (64, 128))
+        out.append(mfma_entry("k_layered_gemm x ~46 + heads + k_sac_reduce + k_sac_apply (layered path)" if layered
+                              else "k_sac_fwd_bwd + k_sac_reduce_apply", "mbpo_sac_step",
                               {"x": X, "u": U, "hidden": list(hidden), "B": B}, t, flop, "2*(5P + 12Q) FLOP per sample",
                               {"updates_per_s": 1.0 / t}))
         log(f"sac sgd_step x={X} {hidden} B={B}: {t * 1e6:.1f} us")
@@ -255,6 +257,8 @@ def main():
     sac_case(3, 1, (128, 128, 128), 256, 200)      # the reference tests' width (tests/test_sac.py)
     attempt(sac_case, 4, 1, (64, 64, 64), 2048, 100)        # C4's global batch on one GPU
     attempt(sac_case, 17, 6, (64, 64, 64), 256, 200)
+    attempt(sac_case, 4, 1, (256, 256, 256), 256, 50)        # wider than the fused kernels take: one GEMM launch per Dense layer
+    attempt(sac_case, 4, 1, (256, 256, 256), 4096, 20)
 
     # ---------------------------------------------------------------- P3-P6: PPO minibatch_step (C3)
     def ppo_case(X, U, hidden, B, T, reps):
