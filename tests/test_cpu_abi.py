@@ -75,6 +75,23 @@ def test_size_queries_and_validation_without_a_device(lib):
     d.policy_dims[4] = 3                                           # a policy must end in 2 * u_dim outputs
     assert lib.mbpo_sac_workspace_floats(C.byref(d)) < 0
     assert b"policy" in lib.mbpo_last_error()
+    # PPO: fused shapes and the reference's experiments/train_inverted_pendulum/exp_ppo.py shapes (policy (32,)*4 padded, critic (256,)*5)
+    p = _hip.PpoDesc()
+    p.x_dim, p.u_dim, p.batch_size, p.unroll_length, p.row_len = 3, 1, 512, 40, 12
+    p.policy_layers, p.value_layers = 3, 3
+    for i, v in enumerate([3, 64, 64, 2]):
+        p.policy_dims[i] = v
+    for i, v in enumerate([3, 64, 64, 1]):
+        p.value_dims[i] = v
+    n_fused = lib.mbpo_ppo_workspace_floats(C.byref(p))
+    assert n_fused > 0
+    p.value_layers = 6
+    for i, v in enumerate([3, 256, 256, 256, 256, 256, 1]):
+        p.value_dims[i] = v
+    n_layered = lib.mbpo_ppo_workspace_floats(C.byref(p))
+    assert n_layered > (512 * 40 + 512) * 256 * 2 * 5              # stored z and h of five 256-wide layers for every row
+    p.value_dims[6] = 2                                            # a value net ends in one output
+    assert lib.mbpo_ppo_workspace_floats(C.byref(p)) < 0
 
 
 def test_product_path_refuses_cpu_tensors():
