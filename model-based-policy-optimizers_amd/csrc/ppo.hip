@@ -859,7 +859,7 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
 extern "C" int mbpo_ppo_grads(const mbpo_ppo_desc *d, void *stream) { return ppo_grads_impl(d, stream, false); }
 
 // One minibatch_step without a seam for a collective: the reduce launch applies AdamW to the elements it has just summed
-// (k_ppo_apply's arithmetic, bit for bit) — six launches instead of seven.
+// (k_ppo_apply's arithmetic, bit for bit) — one launch less per minibatch_step.
 extern "C" int mbpo_ppo_step(const mbpo_ppo_desc *d, void *stream) { return ppo_grads_impl(d, stream, true); }
 
 extern "C" int mbpo_ppo_apply(const mbpo_ppo_desc *d, void *stream) {
