@@ -1,5 +1,6 @@
 // layered.hip — Dense layers as whole-minibatch fp32-MFMA GEMM launches (see layered.hpp).
 #include "layered.hpp"
+#include <stdlib.h>
 
 namespace {
 constexpr int BK = 64;
@@ -9,8 +10,8 @@ constexpr int BK = 64;
 constexpr int LDK = BK + 4;
 
 // One launch = one Dense layer over the whole minibatch.  Output tile per workgroup 32T x 32T (2 x 2 waves, T x T MFMA blocks each):
-// T = 2 when that still gives the chip enough workgroups, else T = 1 — fp32 MFMA is 256 FLOP/cycle/CU, so a 256 x 256 x 256 layer on
-// sixteen 64 x 64 tiles is 8 k cycles on 16 CUs; on sixty-four 32 x 32 tiles 2 k cycles on 64.  K walks through LDS in chunks of 64;
+// T = 1 unless the problem is huge (layered_gemm) — fp32 MFMA is 256 FLOP/cycle/CU, so a 256 x 256 x 256 layer on sixteen 64 x 64
+// tiles is 8 k cycles on 16 CUs; on sixty-four 32 x 32 tiles 2 k cycles on 64.  K walks through LDS in chunks of 64;
 // the NEXT chunk's global loads are issued (into registers) before the current chunk's MFMAs.
 template <int MODE, int T>
 __global__ void __launch_bounds__(256) k_layered_gemm(GemmArgs G) {
@@ -126,7 +127,11 @@ int layered_gemm(int mode, const GemmArgs &G, hipStream_t st) {
   GemmArgs H = G;
   if (H.n_split == 1) H.k_chunk = H.K;
   const long long wg64 = (long long)((G.N + 63) / 64) * ((G.M + 63) / 64) * G.nz * G.n_split;
-  const int T = wg64 >= 128 ? 2 : 1;
+  // 32 x 32 tiles until the 64 x 64 grid alone would hold every CU many times over: measured on PPO's C3 minibatch with a 256x5 value
+  // net (M = 20 992 rows: 328 x 4 tiles of 64) 1404 us per minibatch step with 64-tiles, 1298 with 32-tiles; SAC 256x3 at B = 4096
+  // 883 -> 829 us (scripts/layered_ppo_timing.py, layered_timing.py; MBPO_LAYERED_T2_MIN overrides)
+  static const long long t2_min = getenv("MBPO_LAYERED_T2_MIN") ? atoll(getenv("MBPO_LAYERED_T2_MIN")) : 4096;
+  const int T = wg64 >= t2_min ? 2 : 1;
   const int bm = 32 * T;
   const dim3 grid((unsigned)((G.N + bm - 1) / bm), (unsigned)((G.M + bm - 1) / bm), (unsigned)(G.nz * G.n_split));
 #define LG(MODE_, T_) hipLaunchKernelGGL((k_layered_gemm<MODE_, T_>), grid, dim3(256), 0, st, H)
