@@ -501,3 +501,37 @@ def test_sac_trainer_accepts_reference_experiment_shapes(dev):
             policy_hidden_layer_sizes=(512, 512))
     ok = SAC(environment=env, num_timesteps=1000, episode_length=10, policy_hidden_layer_sizes=(100, 100, 100), critic_hidden_layer_sizes=(128,) * 3)
     assert ok.kernel_width == 128
+
+
+def test_sac_layered_gemm_tile_variants_agree(dev, tmp_path):
+    """k_layered_gemm<MODE, T>: the 64 x 64 (T = 2) and 32 x 32 (T = 1) tile variants of the layered path's GEMM, forced in turn through
+    MBPO_LAYERED_T2_MIN (read once per process: two child processes), give the same gradients within summation order."""
+    import os
+    import subprocess
+    import sys
+    code = '''
+import sys, torch
+sys.path.insert(0, "."); sys.path.insert(0, "model-based-policy-optimizers_amd"); sys.path.insert(0, "tests")
+import test_gpu_sac as T
+dev = torch.device("cuda", 0)
+cfg, st, batch, noise, nm, ns = T._make(5, 2, (200, 72), 300, 11, True, q_hidden=(136, 264, 40))
+up = T._updater(dev, cfg, 300, two_launch=False)
+up.load_state(st.params.to(dev), st.target_q.to(dev))
+up.sgd_step(batch.to(dev), nm.to(dev), ns.to(dev), *[n.to(dev) for n in noise])
+torch.cuda.synchronize()
+torch.save({"g": up.grads.cpu(), "p": up.params.cpu(), "m": up.metrics.cpu()}, sys.argv[1])
+'''
+    outs = []
+    for t2_min in ("1", "1000000000"):
+        f = tmp_path / f"out_{t2_min}.pt"
+        env = dict(os.environ, MBPO_LAYERED_T2_MIN=t2_min)
+        r = subprocess.run([sys.executable, "-c", code, str(f)], env=env, capture_output=True, text=True, cwd=str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f, weights_only=True))
+    scale = float(outs[0]["g"].abs().max())
+    torch.testing.assert_close(outs[0]["g"], outs[1]["g"], atol=1e-6 + 1e-6 * scale, rtol=1e-4)
+    torch.testing.assert_close(outs[0]["p"], outs[1]["p"], atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(outs[0]["m"], outs[1]["m"], atol=1e-6, rtol=2e-5)
+    cfg, st, batch, noise, nm, ns = _make(5, 2, (200, 72), 300, 11, True, q_hidden=(136, 264, 40))
+    g_ref, _ = osac.grads(cfg, st.params.double(), st.target_q.double(), batch.double(), *[n.double() for n in noise], nm.double(), ns.double())
+    torch.testing.assert_close(outs[0]["g"].double(), g_ref, atol=2e-6 + 2e-6 * float(g_ref.abs().max()), rtol=2e-4)
