@@ -5,6 +5,7 @@
 // contiguous side of the copy (the gather side is row-granular: row_len*4 B segments).
 // All position arithmetic is int32/int64 and identical to the reference's (bit-exact requirement).
 #include "common.hpp"
+#include <stdlib.h>
 
 // state = {insert_position, sample_position, head, total_inserted}
 struct ReplayPos {
@@ -423,8 +424,13 @@ __global__ void __launch_bounds__(256) k_perm_rank(const unsigned int *keys, lon
 // The rank count above is 2.7e8 compares from 64 workgroups at n = 16384: 498 us per update epoch, 10 % of C3's training step
 // (rocprofv3, round 3).  Padding to the next power of two with all-ones composites, which sort behind every real element.
 __global__ void __launch_bounds__(1024) k_perm_sort_lds(unsigned long long seed, unsigned long long offset, const unsigned long long *rng_dev,
-                                                         int n, int np, int *perm) {
+                                                         int n, int np, int *perm, unsigned int *flag) {
   extern __shared__ __align__(16) unsigned long long s_c[];
+  if (flag) {                      // the fallback behind k_perm_bucket_sort: only if a bucket overflowed
+    if (flag[0] == 0u) return;
+    __syncthreads();
+    if (threadIdx.x == 0) flag[0] = 0u;
+  }
   const RngKey rk = rng_resolve(seed, offset, rng_dev);
   const int tid = threadIdx.x;
   for (int i = tid; i < np; i += 1024) {
@@ -455,6 +461,66 @@ __global__ void __launch_bounds__(1024) k_perm_sort_lds(unsigned long long seed,
   for (int i = tid; i < n; i += 1024) perm[i] = (int)(unsigned int)(s_c[i] & 0xFFFFFFFFull);
 }
 
+// 1024 < n <= 16384: the same permutation from 2^lb workgroups, each owning the keys whose top lb bits equal its index.  Every workgroup
+// draws ALL n keys itself (Philox is integer arithmetic: n/256 draws per thread, nothing read from memory), counts the keys of
+// smaller buckets (= where its run starts in the output), collects its own bucket's composites in LDS (~n / 2^lb = 64 of them; LDS
+// append order does not matter: they are sorted next), bitonic-sorts them and writes its run.  A bucket that overflows the LDS list
+// (never, for uniform keys: mean 64, room for 1024) raises flag[0]; k_perm_sort_lds — launched right behind with flag != nullptr —
+// then redoes the whole permutation the old way and clears the flag, otherwise it returns at once.  The flag word's initial value
+// does not matter: a stale 1 only costs one redundant full sort.  152 -> ~10 us at n = 16384 (C3's shared permutation, 8 per training step).
+#define PERM_BUCKET_CAP 1024
+__global__ void __launch_bounds__(256) k_perm_bucket_sort(unsigned long long seed, unsigned long long offset, const unsigned long long *rng_dev,
+                                                          int n, int lb, int *perm, unsigned int *flag) {
+  __shared__ unsigned long long s_c[PERM_BUCKET_CAP];
+  __shared__ int s_cnt, s_lt[4];
+  const RngKey rk = rng_resolve(seed, offset, rng_dev);
+  const int tid = threadIdx.x;
+  const unsigned int b = blockIdx.x;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  int lt = 0;
+  for (int i = tid; i < n; i += 256) {
+    Philox4 p = philox4x32_10((uint32_t)i, 0u, MBPO_STREAM_PERM ^ (uint32_t)(rk.offset >> 32) * 0x9E3779B9u, (uint32_t)rk.offset,
+                              (uint32_t)rk.seed, (uint32_t)(rk.seed >> 32));
+    const unsigned int key = p.v[0], kb = key >> (32 - lb);
+    lt += kb < b ? 1 : 0;
+    if (kb == b) {
+      const int at = atomicAdd(&s_cnt, 1);
+      if (at < PERM_BUCKET_CAP) s_c[at] = ((unsigned long long)key << 32) | (unsigned int)i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lt += __shfl_down(lt, o, 64);
+  if ((tid & 63) == 0) s_lt[tid >> 6] = lt;
+  __syncthreads();
+  const int cnt = s_cnt;
+  if (cnt > PERM_BUCKET_CAP) {
+    if (tid == 0) flag[0] = 1u;
+    return;
+  }
+  const int base = s_lt[0] + s_lt[1] + s_lt[2] + s_lt[3];
+  int np = 2;
+  while (np < cnt) np <<= 1;
+  for (int i = cnt + tid; i < np; i += 256) s_c[i] = ~0ull;
+  for (int k = 2; k <= np; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (np >> 1); t += 256) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const unsigned long long a = s_c[lo], c = s_c[hi];
+        const bool up = (lo & k) == 0;
+        if ((a > c) == up) {
+          s_c[lo] = c;
+          s_c[hi] = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < cnt; i += 256) perm[base + i] = (int)(unsigned int)(s_c[i] & 0xFFFFFFFFull);
+}
+
 extern "C" int mbpo_philox_permutation(uint64_t seed, uint64_t offset, const uint64_t *rng_dev, int64_t n, int32_t *perm,
                                        uint32_t *workspace, void *stream) {
   MBPO_REQUIRE(n >= 0 && n <= (1 << 20), MBPO_ERR_ARG, "philox_permutation: n=%lld outside [0, 2^20] (the rank count is O(n^2))", (long long)n);
@@ -467,8 +533,17 @@ extern "C" int mbpo_philox_permutation(uint64_t seed, uint64_t offset, const uin
     const size_t lds = (size_t)np * sizeof(unsigned long long);
     int rc = mbpo_ensure_lds<k_perm_sort_lds>(lds, "philox_permutation");
     if (rc != MBPO_OK) return rc;
+    static const int bucket_env = getenv("MBPO_PERM_BUCKETS") ? atoi(getenv("MBPO_PERM_BUCKETS")) : 1;
+    unsigned int *flag = nullptr;
+    if (n > 1024 && bucket_env != 0) {
+      int lb = 1;
+      while ((n >> lb) > 64 && lb < 8) ++lb;          // ~64 keys per bucket, at most 256 buckets
+      flag = workspace;
+      hipLaunchKernelGGL(k_perm_bucket_sort, dim3(1u << lb), dim3(256), 0, st, (unsigned long long)seed, (unsigned long long)offset,
+                         (const unsigned long long *)rng_dev, (int)n, lb, perm, flag);
+    }
     hipLaunchKernelGGL(k_perm_sort_lds, dim3(1), dim3(1024), lds, st, (unsigned long long)seed, (unsigned long long)offset,
-                       (const unsigned long long *)rng_dev, (int)n, np, perm);
+                       (const unsigned long long *)rng_dev, (int)n, np, perm, flag);
     MBPO_CHECK_LAUNCH("philox_permutation");
     return MBPO_OK;
   }

@@ -309,11 +309,21 @@ def test_ppo_training_epoch_graph_equals_eager(dev, kind):
 
 def test_philox_permutation_bit_exact(dev):
     from mbpo import ops
-    for n, seed, off in ((1, 3, 0), (64, 5, 7), (1000, 2 ** 40 + 3, (1024 << 32) + 9), (16384, 11, 1 << 33)):
+    # n <= 1024: one workgroup's LDS sort; 1024 < n <= 16384: one workgroup per key bucket (k_perm_bucket_sort); above: rank count
+    for n, seed, off in ((1, 3, 0), (64, 5, 7), (1000, 2 ** 40 + 3, (1024 << 32) + 9), (1025, 4, 1), (4096, 9, 5 << 32), (5000, 13, 77),
+                         (16384, 11, 1 << 33), (20000, 21, 3)):
         ref = philox.philox_permutation(seed, off, n)
         got = ops.philox_permutation(n, seed=seed, offset=off).cpu().numpy()
-        assert np.array_equal(got, ref)
+        assert np.array_equal(got, ref), n
         assert np.array_equal(np.sort(got), np.arange(n))
+    # the bucket path's fallback (a bucket overflowing its LDS list raises workspace[0]; uniform keys never do): a raised flag makes the
+    # one-workgroup sort behind it redo the permutation and clear the flag — the result is the same either way
+    for stale in (1, 0):
+        ws = torch.zeros(16384, dtype=torch.int32, device=dev)
+        ws[0] = stale
+        got = ops.philox_permutation(16384, seed=11, offset=1 << 33, workspace=ws).cpu().numpy()
+        assert np.array_equal(got, philox.philox_permutation(11, 1 << 33, 16384))
+        assert int(ws[0]) == 0
     # the device words are ADDED to the host (seed, offset)
     rng = ops.make_rng(dev, seed=100, counter=5)
     got = ops.philox_permutation(500, seed=7, offset=2 << 32, rng_dev=rng).cpu().numpy()
