@@ -200,7 +200,8 @@ int mbpo_replay_sample(const float *data, int64_t max_size, int32_t row_len, con
 
 /* perm = stable argsort of key_i = Philox(seed, offset [+ rng_dev], stream PERM, i).word0, i in [0, n): the ONE shared
  * permutation of PPO.sgd_step (ppo/ppo.py:166-171: jr.permutation with the same key for every leaf); gather whole
- * trajectories with mbpo_replay_gather(idx = perm).  workspace: n uint32.  n <= 2^20. */
+ * trajectories with mbpo_replay_gather(idx = perm).  workspace: n uint32 of scratch (keys for n > 16384; word 0 is an overflow flag of
+ * the bucketed sort for 1024 < n <= 16384 — its initial value does not matter, it is left at 0).  n <= 2^20. */
 int mbpo_philox_permutation(uint64_t seed, uint64_t offset, const uint64_t *rng_dev, int64_t n, int32_t *perm,
                             uint32_t *workspace, void *stream);
 
