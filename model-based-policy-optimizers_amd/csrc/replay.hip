@@ -92,10 +92,18 @@ extern "C" int mbpo_replay_insert(float *data, int64_t max_size, int32_t row_len
 // when D is a multiple of 4 (rows of 2x+u+3 floats with x=4,u=1 are 48 bytes: three lanes per row, consecutive lanes write
 // consecutive 16-byte pieces of `out`).  The gather side reads whole rows, i.e. every 64-byte sector it touches is used at 75 %
 // or more; the scatter into random rows of a table much larger than L2 is what bounds this kernel below the streaming rate.
+static int gather_rows_per_block(int row_len) {
+  const int pieces = (row_len & 3) == 0 ? row_len >> 2 : row_len;     // 16-byte (or 4-byte) pieces per row
+  int rb = (2048 + pieces - 1) / pieces;
+  return rb < 1 ? 1 : (rb > 256 ? 256 : rb);
+}
+
 template <bool SAMPLE>
 __global__ void __launch_bounds__(256) k_replay_gather(const float *data, long long max_size, int D, const int *state,
                                                         const int *idx, unsigned long long seed, unsigned long long offset,
-                                                        const unsigned long long *rng_dev, long long n, int *idx_out, float *out) {
+                                                        const unsigned long long *rng_dev, long long n, int *idx_out, float *out, int RB) {
+  // RB <= 256 rows per workgroup iteration (host: ~2 k 16-byte pieces per iteration, so long rows — PPO gathers whole trajectories of
+  // T*D floats — spread over many workgroups instead of 256 rows x 1920 B on each of 64)
   __shared__ long long s_phys[256];
   if (SAMPLE) {
     const RngKey rk = rng_resolve(seed, offset, rng_dev);
@@ -106,9 +114,9 @@ __global__ void __launch_bounds__(256) k_replay_gather(const float *data, long l
   const int lo = state[1], hi = state[0];
   const int tid = threadIdx.x;
   const bool vec = (D & 3) == 0 && ((((unsigned long long)data) | ((unsigned long long)out)) & 15ull) == 0;
-  for (long long row0 = (long long)blockIdx.x * 256; row0 < n; row0 += (long long)gridDim.x * 256) {
+  for (long long row0 = (long long)blockIdx.x * RB; row0 < n; row0 += (long long)gridDim.x * RB) {
     const long long j = row0 + tid;
-    if (j < n) {
+    if (tid < RB && j < n) {
       long long li;
       if (SAMPLE) {
         // jax.random.randint(sample_key, (n,), minval=sample_position, maxval=insert_position) — stream restated with Philox
@@ -123,7 +131,7 @@ __global__ void __launch_bounds__(256) k_replay_gather(const float *data, long l
       s_phys[tid] = (w + head) % max_size;
     }
     __syncthreads();
-    const int rows_here = (int)((n - row0) < 256 ? (n - row0) : 256);
+    const int rows_here = (int)((n - row0) < RB ? (n - row0) : RB);
     if (vec) {
       const int D4 = D >> 2, total = rows_here * D4;
       const f32x4 *src = reinterpret_cast<const f32x4 *>(data);
@@ -150,9 +158,10 @@ extern "C" int mbpo_replay_gather(const float *data, int64_t max_size, int32_t r
   MBPO_REQUIRE(max_size > 0 && row_len > 0 && n >= 0, MBPO_ERR_ARG, "replay_gather: bad sizes");
   if (n == 0) return MBPO_OK;
   MBPO_REQUIRE(idx && out, MBPO_ERR_ARG, "replay_gather: null idx/out");
-  int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  const int RB = gather_rows_per_block(row_len);
+  int grid = (int)((n + RB - 1) / RB < 4096 ? (n + RB - 1) / RB : 4096);
   hipLaunchKernelGGL(k_replay_gather<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, (long long)max_size, row_len,
-                     state, idx, 0ull, 0ull, (const unsigned long long *)nullptr, (long long)n, (int *)nullptr, out);
+                     state, idx, 0ull, 0ull, (const unsigned long long *)nullptr, (long long)n, (int *)nullptr, out, RB);
   MBPO_CHECK_LAUNCH("replay_gather");
   return MBPO_OK;
 }
@@ -164,9 +173,10 @@ extern "C" int mbpo_replay_sample(const float *data, int64_t max_size, int32_t r
   MBPO_REQUIRE(max_size > 0 && row_len > 0 && n >= 0, MBPO_ERR_ARG, "replay_sample: bad sizes");
   if (n == 0) return MBPO_OK;
   MBPO_REQUIRE(out, MBPO_ERR_ARG, "replay_sample: null out");
-  int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  const int RB = gather_rows_per_block(row_len);
+  int grid = (int)((n + RB - 1) / RB < 4096 ? (n + RB - 1) / RB : 4096);
   hipLaunchKernelGGL(k_replay_gather<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, data, (long long)max_size, row_len,
-                     state, (const int *)nullptr, (unsigned long long)seed, (unsigned long long)offset, (const unsigned long long *)rng_dev, (long long)n, idx_out, out);
+                     state, (const int *)nullptr, (unsigned long long)seed, (unsigned long long)offset, (const unsigned long long *)rng_dev, (long long)n, idx_out, out, RB);
   MBPO_CHECK_LAUNCH("replay_sample");
   return MBPO_OK;
 }
