@@ -535,3 +535,25 @@ torch.save({"g": up.grads.cpu(), "p": up.params.cpu(), "m": up.metrics.cpu()}, s
     cfg, st, batch, noise, nm, ns = _make(5, 2, (200, 72), 300, 11, True, q_hidden=(136, 264, 40))
     g_ref, _ = osac.grads(cfg, st.params.double(), st.target_q.double(), batch.double(), *[n.double() for n in noise], nm.double(), ns.double())
     torch.testing.assert_close(outs[0]["g"].double(), g_ref, atol=2e-6 + 2e-6 * float(g_ref.abs().max()), rtol=2e-4)
+
+
+@pytest.mark.parametrize("pol_act,q_act,neq", [("relu", "tanh", False), ("tanh", "relu", True), ("swish", "swish", True)])
+def test_sac_layered_path_activations_and_per_sample_discount(dev, pol_act, q_act, neq):
+    """The layered path's epilogues for every activation (act and act' inside the GEMM epilogues) and its loss head with the
+    per-sample discount of N1 (sac/losses.py:90-98), on shapes the fused kernel does not take; B = 1 included (one row, one tile)."""
+    X, U = 5, 2
+    kw = dict(non_equidistant_time=True, continuous_discounting=0.9, min_time_between_switches=0.05, max_time_between_switches=0.75,
+              env_dt=0.05) if neq else {}
+    for B in (70, 1):
+        cfg, st, batch, noise, nm, ns = _make(X, U, (40, 72), B, 21, True, q_hidden=(136, 24), policy_act=pol_act, q_act=q_act,
+                                               reward_scaling=1.5, **kw)
+        g_ref, (cl, ac, al) = osac.grads(cfg, st.params.double(), st.target_q.double(), batch.double(), *[n.double() for n in noise],
+                                         nm.double(), ns.double())
+        up = _updater(dev, cfg, B, policy_activation=pol_act, q_activation=q_act, **kw)
+        up.load_state(st.params.to(dev), st.target_q.to(dev))
+        up.sgd_step(batch.to(dev), nm.to(dev), ns.to(dev), *[n.to(dev) for n in noise])
+        up.finalize()
+        torch.cuda.synchronize()
+        g = up.grads.cpu().double()
+        torch.testing.assert_close(g, g_ref, atol=2e-6 + 2e-6 * float(g_ref.abs().max()), rtol=3e-4)
+        np.testing.assert_allclose(up.metrics.cpu().tolist()[:3], [cl, ac, al], rtol=1e-4, atol=2e-6)
