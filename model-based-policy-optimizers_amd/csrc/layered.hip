@@ -25,24 +25,40 @@ __global__ void __launch_bounds__(256) k_layered_gemm(GemmArgs G) {
   const int k_begin = sp * G.k_chunk;
   const int k_end = (k_begin + G.k_chunk < G.K) ? k_begin + G.k_chunk : G.K;
   const bool a_kfast = G.sak == 1, b_kfast = G.sbk == 1 && G.sbn != 1;
-  // element e = tid + 256 i of an operand tile: (fast index, slow index) = (e % 64, e / 64) when k is the fast one, (e % BM, e / BM) else
+  // Element e = tid + 256 i of an operand tile: (fast, slow) index = (e % 64, e / 64) when k is the contiguous one, (e % BM, e / BM)
+  // otherwise — 256 is a multiple of both, so the fast index is the same for every i and the slow one advances by a constant: the
+  // global offset, the LDS slot and the bounds of element i are all affine in i (a handful of integer operations per load; forming
+  // every address from scratch cost more VALU time per chunk than its MFMAs).
+  constexpr int SLOW_K = 256 / BK, SLOW_R = 256 / BM;     // slow-index step per i
+  //   A
+  const int a_r0 = a_kfast ? tid / BK : tid % BM, a_k0 = a_kfast ? tid % BK : tid / BM;   // tile row / k of element i = 0
+  const int a_ri = a_kfast ? SLOW_K : 0, a_ki = a_kfast ? 0 : SLOW_R;                     // rows / k advanced per i
+  const int a_rrem = G.M - (m0 + a_r0);                                                   // valid while i * a_ri < a_rrem
+  const long long a_gstep = (long long)a_ri * G.sam + (long long)a_ki * G.sak;
+  const float *a_ptr = A + (long long)(m0 + a_r0) * G.sam + (long long)a_k0 * G.sak;       // + k0 * sak per chunk
+  const int a_ls0 = a_kfast ? a_r0 * LDK + a_k0 : a_k0 * LDT + a_r0, a_lstep = a_kfast ? SLOW_K * LDK : SLOW_R * LDT;
+  const int a_one = G.ones_row ? (G.M - 1) - (m0 + a_r0) : -1;                             // element i is the all-ones row iff i * a_ri == a_one
+  //   B
+  const int b_c0 = b_kfast ? tid / BK : tid % BM, b_k0 = b_kfast ? tid % BK : tid / BM;
+  const int b_ci = b_kfast ? SLOW_K : 0, b_ki = b_kfast ? 0 : SLOW_R;
+  const int b_crem = G.N - (n0 + b_c0);
+  const long long b_gstep = (long long)b_ci * G.sbn + (long long)b_ki * G.sbk;
+  const float *b_ptr = B + (long long)(n0 + b_c0) * G.sbn + (long long)b_k0 * G.sbk;
+  const int b_ls0 = b_kfast ? b_c0 * LDK + b_k0 : b_k0 * LDT + b_c0, b_lstep = b_kfast ? SLOW_K * LDK : SLOW_R * LDT;
   float ra[PER_T], rb[PER_T];
   auto fetch = [&](int k0) {
+    const int krem = k_end - k0;                       // valid while k index < krem
+    const float *pa = a_ptr + (long long)k0 * G.sak, *pb = b_ptr + (long long)k0 * G.sbk;
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
-      const int e = tid + 256 * i;
-      {
-        const int r = a_kfast ? e / BK : e % BM, k = a_kfast ? e % BK : e / BM;
-        const int gm = m0 + r, gk = k0 + k;
-        float v = 0.f;
-        if (gm < G.M && gk < k_end) v = (G.ones_row && gm == G.M - 1) ? 1.0f : A[(long long)gm * G.sam + (long long)gk * G.sak];
-        ra[i] = v;
-      }
-      {
-        const int c = b_kfast ? e / BK : e % BM, k = b_kfast ? e % BK : e / BM;
-        const int gn = n0 + c, gk = k0 + k;
-        rb[i] = (gn < G.N && gk < k_end) ? B[(long long)gk * G.sbk + (long long)gn * G.sbn] : 0.f;
-      }
+      const bool oka = (i * a_ri < a_rrem) && (a_k0 + i * a_ki < krem);
+      float v = 0.f;
+      if (oka) v = (a_one >= 0 && i * a_ri == a_one) ? 1.0f : pa[0];
+      ra[i] = v;
+      const bool okb = (i * b_ci < b_crem) && (b_k0 + i * b_ki < krem);
+      rb[i] = okb ? pb[0] : 0.f;
+      pa += a_gstep;
+      pb += b_gstep;
     }
   };
   f32x4 acc[T][T];
@@ -59,9 +75,8 @@ __global__ void __launch_bounds__(256) k_layered_gemm(GemmArgs G) {
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
-      const int e = tid + 256 * i;
-      sA[a_kfast ? (e / BK) * LDK + e % BK : (e / BM) * LDT + e % BM] = ra[i];
-      sB[b_kfast ? (e / BK) * LDK + e % BK : (e / BM) * LDT + e % BM] = rb[i];
+      sA[a_ls0 + i * a_lstep] = ra[i];
+      sB[b_ls0 + i * b_lstep] = rb[i];
     }
     __syncthreads();
     if (k0 + BK < k_end) fetch(k0 + BK);        // in flight during this chunk's MFMAs
