@@ -507,6 +507,7 @@ __global__ void __launch_bounds__(256 * SP, (H == 64 && SP == 2) ? 4 : 1) k_ppo_
 struct PpoReduceArgs {
   const float *slabs, *extras;
   int n_slabs, NPV, slab_step;
+  int n_extras;              // loss partials to add (= n_slabs on the fused path: one set per workgroup of k_ppo_fwd_bwd)
   long long M;
   float entropy_cost;
   float *grads, *metrics, *metrics_accum;
@@ -548,7 +549,7 @@ __global__ void __launch_bounds__(256) k_ppo_reduce(PpoReduceArgs A) {
     __shared__ float s_e[3][256];
     const int t = threadIdx.x;
     float e[3] = {0.f, 0.f, 0.f};
-    for (int sl = t; sl < A.n_slabs; sl += 256) {
+    for (int sl = t; sl < A.n_extras; sl += 256) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) e[k] += A.extras[(long long)sl * 4 + k];
     }
@@ -819,8 +820,10 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
     }
   }
   // 4. loss forward/backward
+  float *layered_extras = nullptr;
+  int layered_n_extras = 0;
   if (pl.layered) {
-    rc = ppo_layered_fwd_bwd(d, pl.pi, pl.v, ws + pl.off_layered, A.vs, A.adv, A.mom, A.slabs, A.extras, st);
+    rc = ppo_layered_fwd_bwd(d, pl.pi, pl.v, ws + pl.off_layered, A.vs, A.adv, A.mom, A.slabs, &layered_extras, &layered_n_extras, st);
     if (rc != MBPO_OK) return rc;
   } else if (pl.H == 64) {
     const bool wide = net_is_wide(A.sh_pi) || net_is_wide(A.sh_v);
@@ -840,6 +843,8 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
   // 5. reduce
   PpoReduceArgs R;
   R.slabs = A.slabs; R.extras = A.extras; R.n_slabs = pl.n_slabs; R.NPV = pl.NPV; R.M = pl.M; R.entropy_cost = d->entropy_cost;
+  R.n_extras = pl.n_slabs;
+  if (pl.layered) { R.extras = layered_extras; R.n_extras = layered_n_extras; }
   R.grads = d->grads; R.metrics = d->metrics; R.metrics_accum = d->metrics_accum; R.step_count = d->step_count;
   R.params = fuse_apply ? d->params : nullptr; R.adam_m = d->adam_m; R.adam_v = d->adam_v;
   R.lr = d->lr; R.wd = d->wd; R.grad_scale = d->grad_scale;

@@ -52,9 +52,11 @@ struct HeadArgs {
   float *dy_pi, *dy_v;       // [M][2U], [M + B]
   float *extras;             // [3]
 };
-// one workgroup: thread t takes rows t, t + 1024, ... in order, then a fixed LDS tree over the loss partials — deterministic
-__global__ void __launch_bounds__(1024) k_ppol_heads(HeadArgs A) {
-  __shared__ float s_red[3][1024];
+// 256 rows per workgroup (one thread each), a fixed LDS tree over the workgroup's loss partials -> extras[4 * workgroup + k]; the
+// reduction launch adds the workgroups' partials in order — deterministic.  (One workgroup walking all M rows was 70 us at C3's
+// M = 20 480: as long as a whole 256-wide layer.)
+__global__ void __launch_bounds__(256) k_ppol_heads(HeadArgs A) {
+  __shared__ float s_red[3][256];
   const int tid = threadIdx.x;
   const long long M = (long long)A.B * A.T;
   const int X = A.X, U = A.U, D = A.D;
@@ -62,7 +64,7 @@ __global__ void __launch_bounds__(1024) k_ppol_heads(HeadArgs A) {
   const float adv_mean = A.normalize_advantage ? A.mom[0] : 0.f, adv_istd = A.normalize_advantage ? 1.0f / (A.mom[1] + 1e-8f) : 1.f;
   const RngKey rk = rng_resolve(A.seed, A.offset, A.rng_dev);
   float l_pol = 0.f, l_v = 0.f, l_ent = 0.f;
-  for (long long i = tid; i < M + A.B; i += 1024) {
+  for (long long i = (long long)blockIdx.x * 256 + tid; i < M + A.B; i += (long long)gridDim.x * 256) {
     if (i >= M) {
       A.dy_v[i] = 0.f;       // the bootstrap rows' values carry no gradient (stop_gradient inside compute_gae)
       continue;
@@ -106,14 +108,14 @@ __global__ void __launch_bounds__(1024) k_ppol_heads(HeadArgs A) {
   }
   s_red[0][tid] = l_pol; s_red[1][tid] = l_v; s_red[2][tid] = l_ent;
   __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
+  for (int s = 128; s > 0; s >>= 1) {
     if (tid < s) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) s_red[k][tid] += s_red[k][tid + s];
     }
     __syncthreads();
   }
-  if (tid < 3) A.extras[tid] = s_red[tid][0];
+  if (tid < 3) A.extras[4 * blockIdx.x + tid] = s_red[tid][0];
 }
 
 struct Carve {
@@ -126,7 +128,8 @@ struct Carve {
   }
 };
 struct Bufs {
-  float *x_all, *values, *outp, *dy_pi, *dy_v, *pp[2], *part;
+  float *x_all, *values, *outp, *dy_pi, *dy_v, *pp[2], *part, *extras;
+  int n_heads;
   float *Zv[MBPO_MAX_LAYERS + 1], *Hv[MBPO_MAX_LAYERS + 1], *Zp[MBPO_MAX_LAYERS + 1], *Hp[MBPO_MAX_LAYERS + 1];
 };
 long long carve_all(float *base, const mbpo_ppo_desc *d, const LayeredNet &pi, const LayeredNet &v, Bufs *b) {
@@ -141,6 +144,8 @@ long long carve_all(float *base, const mbpo_ppo_desc *d, const LayeredNet &pi, c
   b->pp[0] = c.take(R * mh); b->pp[1] = c.take(R * mh);
   const long long pa = layered_part_floats(pi, (int)M), pb = layered_part_floats(v, (int)R);
   b->part = c.take(pa > pb ? pa : pb);
+  b->n_heads = (int)((R + 255) / 256);
+  b->extras = c.take(4LL * b->n_heads);
   return c.off;
 }
 }  // namespace
@@ -167,7 +172,7 @@ int ppo_layered_values(const mbpo_ppo_desc *d, const MlpDev &pi, const MlpDev &v
 }
 
 int ppo_layered_fwd_bwd(const mbpo_ppo_desc *d, const MlpDev &pi, const MlpDev &v, float *ws, const float *vs, const float *adv,
-                        const float *mom, float *slab, float *extras, hipStream_t st) {
+                        const float *mom, float *slab, float **extras_out, int *n_extras_out, hipStream_t st) {
   const LayeredNet npi = layered_net(pi, d->params, 0, 1), nv = layered_net(v, d->params + pi.n_params, 0, 1);
   Bufs b;
   carve_all(ws, d, npi, nv, &b);
@@ -176,8 +181,10 @@ int ppo_layered_fwd_bwd(const mbpo_ppo_desc *d, const MlpDev &pi, const MlpDev &
   if (rc != MBPO_OK) return rc;
   HeadArgs A = {d->data, b.outp, b.values, vs, adv, mom, d->entropy_noise, d->seed, d->offset, (const unsigned long long *)d->rng_dev,
                 d->batch_size, d->unroll_length, d->row_len, d->x_dim, d->u_dim, d->normalize_advantage, d->entropy_cost,
-                d->clipping_epsilon, b.dy_pi, b.dy_v, extras};
-  hipLaunchKernelGGL(k_ppol_heads, dim3(1), dim3(1024), 0, st, A);
+                d->clipping_epsilon, b.dy_pi, b.dy_v, b.extras};
+  hipLaunchKernelGGL(k_ppol_heads, dim3(b.n_heads), dim3(256), 0, st, A);
+  *extras_out = b.extras;
+  *n_extras_out = b.n_heads;
   if ((rc = layered_backward(npi, b.x_all, 0, (int)M, b.Zp, b.Hp, b.dy_pi, slab, 0, nullptr, b.pp[0], b.pp[1], b.part, st)) != MBPO_OK) return rc;
   if ((rc = layered_backward(nv, b.x_all, 0, (int)R, b.Zv, b.Hv, b.dy_v, slab + pi.n_params, 0, nullptr, b.pp[0], b.pp[1], b.part, st)) != MBPO_OK)
     return rc;

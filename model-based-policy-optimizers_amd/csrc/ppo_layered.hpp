@@ -10,6 +10,7 @@ long long ppo_layered_floats(const mbpo_ppo_desc *d, const MlpDev &pi, const Mlp
 int ppo_layered_values(const mbpo_ppo_desc *d, const MlpDev &pi, const MlpDev &v, float *ws, float *trunc, float *term, float *rew,
                        float **values_out, hipStream_t st);
 // step 2 (after the GAE scan and the advantage moments): policy forward, loss terms and output gradients (ppo/losses.py:91-126),
-// both backward passes.  Leaves slab [P + V] (the minibatch's gradient, divided by M) and extras[0..2] (loss sums).
+// both backward passes.  Leaves slab [P + V] (the minibatch's gradient, divided by M) and *n_extras_out loss partials {policy, value,
+// entropy, -} at *extras_out (one per 256 rows; the reduction launch adds them in order).
 int ppo_layered_fwd_bwd(const mbpo_ppo_desc *d, const MlpDev &pi, const MlpDev &v, float *ws, const float *vs, const float *adv,
-                        const float *mom, float *slab, float *extras, hipStream_t st);
+                        const float *mom, float *slab, float **extras_out, int *n_extras_out, hipStream_t st);
