@@ -49,6 +49,9 @@ def _updater(dev, cfg, B, T, **kw):
     (17, 6, (64, 64), 8, 3, False, True),
     (3, 1, (64, 64, 64), 512, 40, True, True),    # BASELINE configs[2] at FULL size: B=512, T=40 (20 480 samples per minibatch)
     (4, 1, (64, 64, 64), 512, 5, True, True),     # the same at horizon-5 unrolls
+    (3, 1, (64, 64), 2000, 3, True, True),        # k_ppo_values_gae with two trajectories per workgroup (B > 4 x CUs)
+    (3, 1, (64, 64), 3, 1023, False, True),       # the longest trajectory a workgroup's LDS arrays hold (64 tiles, four at a time)
+    (3, 1, (64, 64), 2, 1024, False, True),       # one step longer: values, GAE scan and moments as separate launches
 ])
 def test_ppo_gradients_and_step(dev, X, U, hidden, B, T, normalize, norm_adv):
     cfg, st, data, noise, nm, ns = _make(X, U, hidden, B, T, 0, normalize, entropy_cost=1e-2, discounting=0.99,
