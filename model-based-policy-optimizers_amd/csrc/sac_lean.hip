@@ -1,0 +1,748 @@
+// sac_lean.hip — k_sac_lean<X>: the SAC forward/backward launch (S3-S6 of sgd_step, sac/sac.py:227-281, sac/losses.py:61-125)
+// specialised for the benchmark networks: policy X -> 64 -> 64 -> 64 -> 2, critics X+1 -> 64 -> 64 -> 64 -> 1, swish, u = 1.
+//
+// Why a second kernel (round 4): the generic k_sac_fwd_bwd (sac.hip) serves every shape from kernel-argument tables — chain
+// descriptors, NetShape scalars, one runner per chain kind — and sits at 104 SGPRs with 219 spilled to VGPR lanes, 3.5 KB of
+// kernel arguments that need a warm-up wave, ~1.4 k cycles of chain set-up in front of every phase (profiles/r03_phase_stamps.txt).
+// Here every shape, LDS offset, role and chain layout is a compile-time constant: the role paths are straight-line code, the
+// kernel arguments are ~50 dwords, nothing is decoded at run time.
+//
+// What is kept bit for bit: every number.  Each dot product is formed by the same v_mfma_f32_16x16x4_f32 sequence over the same
+// k groups in the same order as the generic kernel's (chain_run.hpp), the thin layers by the same FMA chains, the elementwise
+// sections by the same expressions — so the per-tile gradient slabs, and with them everything behind this launch, are identical
+// to the generic kernel's (tests/test_gpu_sac_lean.py compares the slabs with torch.equal).
+//
+// What is different:
+//  * MFMA operands SWAPPED (A = weights, B = activations): D^T comes out, so a lane holds FOUR CONSECUTIVE COLUMNS of ONE row
+//    instead of one column of four rows — every activation / delta store is one ds_write_b128 (was 4 x b32), every pre-activation
+//    read of the backward one ds_read_b128, every weight-gradient store one global_store_dwordx4 (was 4 dwords: 16 + 1 store
+//    instructions per wave and layer became 4 + 1).  a*b = b*a and the k order is unchanged, so the sums are the same bits.
+//  * The weights of a whole PHASE (thin layer, two hidden layers, output layer) are requested at once, one phase ahead, into
+//    registers that are simply named per layer: no register-set swapping, no loop unrolled by two, no descriptor fetch.
+//  * The wave that forms a network's output layer keeps it in registers and runs the elementwise section itself (NormalTanh
+//    sample / value hand-off) — the output image maps matrix row i to column i & 3, so all four lane groups hold (loc, raw) of
+//    their row and the actor role's two samples run side by side in one pass.  One barrier and one LDS round trip less per section.
+//  * Tile load: one coalesced dword per thread (the tile's 16 rows are contiguous), classified by column.
+//
+// Roles as in the generic kernel's `split` launch: 3 workgroups per 16-sample tile — critic 0, actor(+alpha), critic 1; 8 waves =
+// 2 chains x 4 waves; forward-mode dQ/da in the actor role (the tangent rides along the critics' forward pass).
+#include "common.hpp"
+#include "chain_run.hpp"
+#include "sac_shared.hpp"
+#include "sac_lean.hpp"
+
+namespace {
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int LH = 64;            // hidden width
+constexpr int LDH = 68;           // row stride of a hidden tile (floats): rows 16-byte aligned, bank offset 4 per row
+constexpr int LT = 16 * LDH;      // one hidden tile
+constexpr int LDX = 8;            // row stride of an input tile ([obs | action], x + u <= 8)
+constexpr int HID = LH * LH + LH; // one hidden layer's parameters (W + b)
+
+template <int X>
+struct Net {
+  static constexpr int KP = X, KQ = X + 1, D = 2 * X + 4;
+  static constexpr int P_W1 = KP * LH + LH, P_OUT = P_W1 + 2 * HID, P = P_OUT + LH * 2 + 2;
+  static constexpr int Q_W1 = KQ * LH + LH, Q_OUT = Q_W1 + 2 * HID, Q = Q_OUT + LH + 1;
+};
+
+// LDS carve (floats)
+constexpr int O_QIN = 0;               // [16][8]  [sn | a]   (critic: the transition's action; actor: the sampled action)
+constexpr int O_QIN2 = 128;            // [16][8]  [s'n | a'] (critic role)
+constexpr int O_AUX = 256;             // [16][4]  reward, discount, truncation, transitions.action[..., -1]
+constexpr int O_EPS = 320;             // [16] noise of the role's first sample
+constexpr int O_EPS2 = 336;            // [16] actor role: noise of the alpha-loss sample, then that sample's log-prob
+constexpr int O_LP = 352;              // [16]
+constexpr int O_A = 368, O_SIG = 384, O_RAW = 400;
+constexpr int O_Q = 416;               // [2][16] network values: critic role target critics, actor role Q1/Q2
+constexpr int O_DQ = 448;              // [2][16] actor role: dQ/da
+constexpr int O_QOLD = 480;            // [16] critic role: Q_k(s, a)
+constexpr int O_DY = 496;              // [16][4] output-layer gradient of the network being differentiated
+constexpr int O_TILES = 560;
+constexpr int N_TILES = 14;
+constexpr size_t LEAN_LDS_BYTES = (size_t)(O_TILES + N_TILES * LT) * sizeof(float);
+
+// ---- register images ----------------------------------------------------------------------------------------------
+// forward, hidden layer (W [64][64] then bias [64]), this wave's 16 columns c0..c0+15:
+//   w[s] = W[16 g + s][c0 + i]   (A operand: matrix row i = column c0 + i, k = g -> input 16 g + s)
+//   b[i'] = bias[c0 + 4 g + i']  (the lane's results are y[row j][c0 + 4 g + i'], j = lane & 15)
+struct ImgF {
+  float w[16];
+  float b[4];
+};
+__device__ __forceinline__ void img_fwd_request(ImgF &I, const float *__restrict__ W, int c0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const float *p = W + (16 * g) * LH + c0 + i;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) I.w[s] = p[s * LH];
+  const f4u t = *reinterpret_cast<const f4u *>(W + LH * LH + c0 + 4 * g);
+  I.b[0] = t[0]; I.b[1] = t[1]; I.b[2] = t[2]; I.b[3] = t[3];
+}
+// forward, output layer (W [64][N], N <= 2): matrix row i stands for column i & 3, so every lane group ends up with the outputs of
+// its row: w[s] = W[16 g + s][(i & 3) < N ? i & 3 : 0]
+template <int N>
+__device__ __forceinline__ void img_out_request(float (&w)[16], const float *__restrict__ W, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int col = ((i & 3) < N) ? (i & 3) : 0;
+  const float *p = W + (16 * g) * N + col;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) w[s] = p[s * N];
+}
+// input-gradient of a hidden layer: w[n] = W[k0 + i][16 g + n]  (A operand: matrix row i = input k0 + i, k = g -> output 16 g + n)
+__device__ __forceinline__ void img_dgrad_request(float (&w)[16], const float *__restrict__ W, int k0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const float *p = W + (k0 + i) * LH + 16 * g;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f4u t = *reinterpret_cast<const f4u *>(p + 4 * q);
+    w[4 * q] = t[0]; w[4 * q + 1] = t[1]; w[4 * q + 2] = t[2]; w[4 * q + 3] = t[3];
+  }
+}
+// thin first layer: this lane's column of W0 [K][64] and its bias
+template <int K>
+__device__ __forceinline__ void thin_col_request(float (&tw)[K + 1], const float *__restrict__ W0, int lane) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) tw[k] = W0[k * LH + lane];
+  tw[K] = W0[K * LH + lane];
+}
+
+// the B operand of a hidden layer: 16 consecutive activations of row j from k group g (four ds_read_b128)
+__device__ __forceinline__ void read_row16(float (&av)[16], const float *tile, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+  const float *xr = tile + j * LDH + 16 * g;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) load_vec_lds<4>(xr + 4 * q, *reinterpret_cast<float(*)[4]>(&av[4 * q]));
+}
+
+// ---- layer steps --------------------------------------------------------------------------------------------------
+// hidden layer forward: h_out[row j][c0 + 4 g ..] = swish(x W + b), optionally the pre-activation to z_out
+template <bool STORE_Z>
+__device__ __forceinline__ void hid_fwd(const ImgF &I, const float *xin, float *h_out, float *z_out, int c0, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+  float av[16];
+  read_row16(av, xin, lane);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 16; ++s) acc = MFMA(I.w[s], av[s], acc);
+  float zv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) zv[i] = acc[i] + I.b[i];
+  const int o = j * LDH + c0 + 4 * g;
+  if (STORE_Z) store_vec_lds<4>(z_out + o, zv);
+  act_apply_vec<4>(zv, MBPO_ACT_SWISH);
+  store_vec_lds<4>(h_out + o, zv);
+}
+// the same with the tangent tile riding along (chain_run.hpp JVP): t_out = swish'(z) * (t_in W)
+__device__ __forceinline__ void hid_fwd_jvp(const ImgF &I, const float *xin, const float *tin, float *h_out, float *t_out, int c0, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+  float av[16], tv_in[16];
+  read_row16(av, xin, lane);
+  read_row16(tv_in, tin, lane);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, tacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    acc = MFMA(I.w[s], av[s], acc);
+    tacc = MFMA(I.w[s], tv_in[s], tacc);
+  }
+  float zv[4], tv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    zv[i] = acc[i] + I.b[i];
+    tv[i] = tacc[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float sg = fast_sigmoid(zv[i]);
+    tv[i] *= sg * (1.0f + zv[i] * (1.0f - sg));
+    zv[i] = zv[i] * sg;
+  }
+  const int o = j * LDH + c0 + 4 * g;
+  store_vec_lds<4>(t_out + o, tv);
+  store_vec_lds<4>(h_out + o, zv);
+}
+// output layer forward: every lane ends up with y[row j][col i] in acc[i] (bias not added)
+__device__ __forceinline__ f32x4 out_fwd(const float (&w)[16], const float *xin, int lane) {
+  float av[16];
+  read_row16(av, xin, lane);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 16; ++s) acc = MFMA(w[s], av[s], acc);
+  return acc;
+}
+// hidden layer input-gradient: d_out[row j][k0 + 4 g ..] = (delta W^T) * swish'(z_prev)
+__device__ __forceinline__ void hid_dgrad(const float (&w)[16], const float *din, const float *zprev, float *d_out, int k0, int lane) {
+  const int j = lane & 15, g = lane >> 4;
+  float av[16];
+  read_row16(av, din, lane);
+  const int o = j * LDH + k0 + 4 * g;
+  float zv[4];
+  load_vec_lds<4>(zprev + o, zv);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < 16; ++n) acc = MFMA(w[n], av[n], acc);
+  float ov[4] = {acc[0], acc[1], acc[2], acc[3]};
+  act_grad_mul_vec<4>(ov, zv, MBPO_ACT_SWISH);
+  store_vec_lds<4>(d_out + o, ov);
+}
+// hidden layer weight gradient (chain_run.hpp wgrad_tile_fast<4, 1, true>, operands swapped): columns c0..c0+15 of dW [64][64] and
+// of db.  acc[a] lane (j, g) reg i = dW[4 j + a][c0 + 4 g + i]; the bias tile's B operand is the indicator of column 0.
+__device__ __forceinline__ void hid_wgrad(const float *hin, const float *delta, float *__restrict__ gW, int c0, int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  f32x4 acc[4], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float hv[4][4], dv[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int row = 4 * g + s;
+    load_vec_lds<4>(hin + row * LDH + 4 * r, hv[s]);
+    dv[s] = delta[row * LDH + c0 + r];
+  }
+  const float one0 = (r == 0) ? 1.f : 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = MFMA(dv[s], hv[s][a], acc[a]);
+    accb = MFMA(dv[s], one0, accb);
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const float ov[4] = {acc[a][0], acc[a][1], acc[a][2], acc[a][3]};
+    store_vec_global<4>(gW + (4 * r + a) * LH + c0 + 4 * g, ov);
+  }
+  if (r == 0) {
+    const float ov[4] = {accb[0], accb[1], accb[2], accb[3]};
+    store_vec_global<4>(gW + LH * LH + c0 + 4 * g, ov);
+  }
+}
+
+// ---- thin layers (chain_run.hpp "thin layers by VALU", shapes as constants) -----------------------------------------
+// layer 0 of a forward chain: rows 4 sub .. 4 sub + 3, column = lane
+template <int K, bool STORE_Z, bool TANGENT>
+__device__ __forceinline__ void thin_first(const float (&tw)[K + 1], const float *x, float *h0, float *z0, float *t0, int sub, int lane) {
+  float xv[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    load_vec_lds<4>(x + (4 * sub + i) * LDX, *reinterpret_cast<float(*)[4]>(&xv[i][0]));
+    if (K > 4) load_vec_lds<4>(x + (4 * sub + i) * LDX + 4, *reinterpret_cast<float(*)[4]>(&xv[i][4]));
+  }
+  float zv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float z = tw[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) z = fmaf(xv[i][k], tw[k], z);
+    zv[i] = z;
+  }
+  if (STORE_Z) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z0[(4 * sub + i) * LDH + lane] = zv[i];
+  }
+  if (TANGENT) {      // d h0 / d x[K - 1] = swish'(z0) * W0[K - 1][col]
+    float tv[4] = {tw[K - 1], tw[K - 1], tw[K - 1], tw[K - 1]};
+    act_grad_mul_vec<4>(tv, zv, MBPO_ACT_SWISH);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t0[(4 * sub + i) * LDH + lane] = tv[i];
+  }
+  act_apply_vec<4>(zv, MBPO_ACT_SWISH);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) h0[(4 * sub + i) * LDH + lane] = zv[i];
+}
+// delta_2 = (dY Wout^T) * swish'(z_2), rows 4 sub .. 4 sub + 3, column = lane; two[o] = Wout[lane][o]
+template <int N>
+__device__ __forceinline__ void thin_dgrad_last(const float (&two)[N], const float *dY, const float *z2, float *d_out, int sub, int lane) {
+  float dv[4][4], zv[4], sv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    load_vec_lds<4>(dY + (4 * sub + i) * 4, dv[i]);
+    zv[i] = z2[(4 * sub + i) * LDH + lane];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int o = 0; o < N; ++o) s = fmaf(dv[i][o], two[o], s);
+    sv[i] = s;
+  }
+  act_grad_mul_vec<4>(sv, zv, MBPO_ACT_SWISH);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d_out[(4 * sub + i) * LDH + lane] = sv[i];
+}
+// output layer's weight gradient: dWout[c][o] = sum_r h2[r][c] dY[r][o] (wave `sub` takes o = sub), db[o] (wave 0)
+template <int N>
+__device__ __forceinline__ void thin_wgrad_last(const float *h2, const float *dY, float *__restrict__ gW, int sub, int lane) {
+  if (sub < N) {
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = fmaf(h2[r * LDH + lane], dY[r * 4 + sub], acc);
+    gW[lane * N + sub] = acc;
+  }
+  if (sub == 0 && lane < N) {
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc += dY[r * 4 + lane];
+    gW[LH * N + lane] = acc;
+  }
+}
+// layer 0's weight gradient: wave w8 takes input row k = w8 (< K), wave K the bias; column = lane
+template <int K>
+__device__ __forceinline__ void thin_wgrad_first_(const float *x, const float *d0, float *__restrict__ gW, int w8, int lane) {
+  if (w8 > K) return;
+  float dv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dv[r] = d0[r * LDH + lane];
+  if (w8 < K) {
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = fmaf(x[r * LDX + w8], dv[r], acc);
+    gW[w8 * LH + lane] = acc;
+  } else {
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc += dv[r];
+    gW[K * LH + lane] = acc;
+  }
+}
+
+#define LEAN_STAMP(i)                                                                   \
+  if (STAMPS) {                                                                         \
+    if (A.stamps && tile == 0 && tid == 0) {                                            \
+      unsigned long long t_;                                                            \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+      A.stamps[(trole == 1 ? 16 : 0) + (i)] = t_;                                       \
+    }                                                                                   \
+  }
+
+template <int X, bool STAMPS>
+__global__ void __launch_bounds__(512) k_sac_lean(const SacLeanArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  using N = Net<X>;
+  constexpr int D = N::D, KP = N::KP, KQ = N::KQ;
+  static_assert(X >= 1 && X + 1 <= LDX, "x + u must fit an 8-column input tile");
+  const int tid_ = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+  const int c = wave >> 2, sub = wave & 3, c0 = sub * 16;
+  const int trole = blockIdx.x % 3, tile = blockIdx.x / 3;      // 0 = critic 0, 1 = actor + alpha, 2 = critic 1
+  const int B = A.B, row0 = tile * 16;
+  {
+    const int tid = tid_;
+    LEAN_STAMP(0);
+  }
+  // the clip check of the previous speculative optimizer step: sac.hip k_sac_fwd_bwd, same protocol, same words
+  const uint4 qw0 = *reinterpret_cast<const uint4 *>(A.opt.seq), qw1 = *reinterpret_cast<const uint4 *>(A.opt.seq + 4);
+  const float count_in = A.step_count_rw[0];
+  const unsigned int ep0_in = A.p2p_epoch ? A.p2p_epoch[0] : 0u, ep1_in = A.p2p_epoch ? A.p2p_epoch[1] : 0u;
+  const float log_alpha_top = A.params[N::P + 2 * N::Q];
+  const float invB = 1.0f / (float)B;
+  bool maybe_clip = false;
+
+  float *const s_qin = smem + O_QIN, *const s_qin2 = smem + O_QIN2, *const s_aux = smem + O_AUX;
+  float *const tiles = smem + O_TILES;
+#define TILE(n) (tiles + (n) * LT)
+
+  // The words requested at the top are used up behind the first barrier (they have arrived with the tile): folded into the quick
+  // verdict, and block 0 publishes this step's slot, the optimizer count and the exchange epoch (idempotent: a second pass repeats
+  // the same stores).  Nothing above may WAIT for these loads (sac.hip: +2 us when the tile loads queued behind them).
+  auto fold_clip_words = [&]() __attribute__((always_inline)) {
+    const unsigned int seq_issued = qw0.x, seq_resolved = qw0.y;
+    const bool odd = (seq_issued & 1u) == 0u;
+    const float q0 = __uint_as_float(odd ? qw1.y : qw0.z), q1 = __uint_as_float(odd ? qw1.z : qw0.w), q2 = __uint_as_float(odd ? qw1.w : qw1.x);
+    const float lim = (A.opt.max_norm / A.opt.grad_scale) * (A.opt.max_norm / A.opt.grad_scale) * 0.9998f;
+    maybe_clip = seq_issued != seq_resolved && !(q0 < lim && q1 < lim && q2 < lim);
+    if (blockIdx.x == 0 && tid_ == 0) {
+      const unsigned int slot = qw0.x & 1u;
+      A.opt.slot_word[0] = slot;
+      float *q = reinterpret_cast<float *>(A.opt.seq) + 2 + 3 * slot;
+      q[0] = 0.f; q[1] = 0.f; q[2] = 0.f;
+      A.step_count_rw[0] = count_in + 1.0f;
+      if (A.p2p_epoch) {
+        A.p2p_epoch[0] = ep0_in + 1u;
+        A.p2p_epoch[1] = ep1_in + A.p2p_blocks;
+      }
+    }
+  };
+
+  auto run = [&](const float log_alpha_v) __attribute__((always_inline)) {
+    const int tid = opaque(tid_), lane = tid & 63;
+    const float *const pi_p = A.params;
+    if (trole != 1) {
+      // =========================================== CRITIC kq (sac/losses.py:74-110) ===========================================
+      const int kq = trole >> 1;
+      const float *const qk_p = A.params + N::P + kq * N::Q;
+      const float *const qt_p = A.target_q + c * N::Q;                  // the target critic chain c walks in F1
+      // ---- requests of phase F0: chain 0 = pi(s'), chain 1 = Q_k(s, a) ----
+      float tw[KQ + 1];
+      ImgF I1, I2;
+      float wo[16];
+      float bo0 = 0.f, bo1 = 0.f;
+      if (c == 0) {
+        thin_col_request<KP>(*reinterpret_cast<float(*)[KP + 1]>(&tw[0]), pi_p, lane);
+        img_fwd_request(I1, pi_p + N::P_W1, c0, lane);
+        img_fwd_request(I2, pi_p + N::P_W1 + HID, c0, lane);
+        if (sub == 0) {
+          img_out_request<2>(wo, pi_p + N::P_OUT, lane);
+          bo0 = pi_p[N::P_OUT + LH * 2];
+          bo1 = pi_p[N::P_OUT + LH * 2 + 1];
+        }
+      } else {
+        thin_col_request<KQ>(tw, qk_p, lane);
+        img_fwd_request(I1, qk_p + N::Q_W1, c0, lane);
+        img_fwd_request(I2, qk_p + N::Q_W1 + HID, c0, lane);
+        if (sub == 1) {
+          img_out_request<1>(wo, qk_p + N::Q_OUT, lane);
+          bo0 = qk_p[N::Q_OUT + LH];
+        }
+      }
+      // ---- tile section: one coalesced dword per thread, classified by column ----
+      {
+        if (tid < 16 * D) {
+          const int r = tid / D, cc = tid - r * D;
+          const int nvalid = (B - row0 < 16 ? B - row0 : 16) * D;
+          float v = tid < nvalid ? A.batch[(long long)row0 * D + tid] : 0.f;
+          if (cc < X || (cc >= X + 3 && cc < 2 * X + 3)) {
+            const int oc = cc < X ? cc : cc - (X + 3);
+            if (A.norm_mean) v = (v - A.norm_mean[oc]) / A.norm_std[oc];
+            (cc < X ? s_qin : s_qin2)[r * LDX + oc] = v;
+          } else if (cc == X) {
+            s_qin[r * LDX + X] = v;            // transitions.action
+            s_aux[r * 4 + 3] = v;
+          } else if (cc == X + 1) s_aux[r * 4 + 0] = v;
+          else if (cc == X + 2) s_aux[r * 4 + 1] = v;
+          else s_aux[r * 4 + 2] = v;           // truncation
+        } else if (wave == 7 && lane < 16) {
+          // next-action noise, drawn beside the tile load (it depends on the key and the element only)
+          const RngKey rk = rng_resolve(A.seed, A.offset, A.rng_dev);
+          const long long nidx = row0 + lane;
+          float e = 0.f;
+          if (row0 + lane < B) e = A.noise_critic ? A.noise_critic[nidx] : philox_normal(rk.seed, rk.offset, MBPO_STREAM_SAC_CRITIC, (unsigned long long)nidx);
+          smem[O_EPS + lane] = e;
+        }
+      }
+      __syncthreads();
+      fold_clip_words();
+      LEAN_STAMP(1);
+      if (c == 0) thin_first<KP, false, false>(*reinterpret_cast<float(*)[KP + 1]>(&tw[0]), s_qin2, TILE(0), nullptr, nullptr, sub, lane);
+      else thin_first<KQ, true, false>(tw, s_qin, TILE(7), TILE(4), nullptr, sub, lane);
+      // ---- requests of phase F1: both target critics on (s', a') ----
+      float tw1[KQ + 1];
+      ImgF J1, J2;
+      float wo1[16];
+      float bt = 0.f;
+      thin_col_request<KQ>(tw1, qt_p, lane);
+      img_fwd_request(J1, qt_p + N::Q_W1, c0, lane);
+      img_fwd_request(J2, qt_p + N::Q_W1 + HID, c0, lane);
+      if (sub == c) {
+        img_out_request<1>(wo1, qt_p + N::Q_OUT, lane);
+        bt = qt_p[N::Q_OUT + LH];
+      }
+      __syncthreads();
+      LEAN_STAMP(2);
+      if (c == 0) hid_fwd<false>(I1, TILE(0), TILE(1), nullptr, c0, lane);
+      else hid_fwd<true>(I1, TILE(7), TILE(8), TILE(5), c0, lane);
+      __syncthreads();
+      LEAN_STAMP(3);
+      if (c == 0) hid_fwd<false>(I2, TILE(1), TILE(0), nullptr, c0, lane);
+      else hid_fwd<true>(I2, TILE(8), TILE(9), TILE(6), c0, lane);
+      __syncthreads();
+      LEAN_STAMP(4);
+      // ---- output layers + the sampling section on the wave that holds the policy's output ----
+      if (c == 0 && sub == 0) {
+        const f32x4 y = out_fwd(wo, TILE(0), lane);
+        const float loc = y[0] + bo0, raw = y[1] + bo1;
+        const int j = lane & 15;
+        const ActSample sm = normal_tanh_sample(loc, raw, smem[O_EPS + j]);      // next_action, next_log_prob (:80-87)
+        if (lane < 16) {
+          s_qin2[j * LDX + X] = sm.a;
+          smem[O_LP + j] = sm.lp;
+        }
+      } else if (c == 1 && sub == 1) {
+        const f32x4 y = out_fwd(wo, TILE(9), lane);
+        if (lane < 16) smem[O_QOLD + lane] = y[0] + bo0;                         // q_old_action (:78-79), this workgroup's critic
+      }
+      __syncthreads();
+      LEAN_STAMP(5);
+      // ---- F1: target critics ----
+      thin_first<KQ, false, false>(tw1, s_qin2, TILE(2 * c), nullptr, nullptr, sub, lane);
+      // requests of the backward phase: chain 0 walks Q_k's input gradients, chain 1 its weight gradients (no weights)
+      float two[1];
+      float G2[16], G1[16];
+      if (c == 0) {
+        two[0] = qk_p[N::Q_OUT + lane];
+        img_dgrad_request(G2, qk_p + N::Q_W1 + HID, c0, lane);
+        img_dgrad_request(G1, qk_p + N::Q_W1, c0, lane);
+      }
+      __syncthreads();
+      LEAN_STAMP(6);
+      hid_fwd<false>(J1, TILE(2 * c), TILE(2 * c + 1), nullptr, c0, lane);
+      __syncthreads();
+      LEAN_STAMP(7);
+      hid_fwd<false>(J2, TILE(2 * c + 1), TILE(2 * c), nullptr, c0, lane);
+      __syncthreads();
+      LEAN_STAMP(8);
+      if (sub == c) {
+        const f32x4 y = out_fwd(wo1, TILE(2 * c), lane);
+        if (lane < 16) smem[O_Q + 16 * c + lane] = y[0] + bt;
+      }
+      __syncthreads();
+      LEAN_STAMP(9);
+      // ---- targets, errors, dL/dq (:88-110): 16 lanes of wave 0 ----
+      if (wave == 0) {
+        const float alpha = expf(log_alpha_v);
+        float e2 = 0.f;
+        if (lane < 16) {
+          const int r = lane;
+          const bool ok = row0 + r < B;
+          float nlp = 0.f;
+          nlp += smem[O_LP + r];
+          const float nq = fminf(smem[O_Q + r], smem[O_Q + 16 + r]);
+          const float next_v = nq - alpha * nlp;                                                   // :89
+          const float rew = s_aux[r * 4 + 0], disc = s_aux[r * 4 + 1];
+          float gamma = A.discounting;
+          if (A.neq) {                                                                             // :90-96
+            const float pseudo = s_aux[r * 4 + 3];
+            float tfa = (A.neq_tu - A.neq_tl) / 2.0f * pseudo + (A.neq_tu + A.neq_tl) / 2.0f;
+            tfa = floor_divide_f(tfa, A.neq_dt) * A.neq_dt;
+            gamma = expf(-A.neq_cd * tfa);
+          }
+          const float target = rew * A.reward_scaling + disc * gamma * next_v;                     // :101-103
+          const float trunc = s_aux[r * 4 + 2];
+          const float err = ok ? (smem[O_QOLD + r] - target) * (1.f - trunc) : 0.f;                // :104-108
+          e2 = err * err;
+          smem[O_DY + r * 4] = err * (1.f - trunc) * (0.5f * invB);
+        }
+        const float acc = wave_sum64(e2);
+        if (lane == 0) A.slab_ex[tile * 4 + (kq == 1 ? 3 : 0)] = acc;
+      }
+      __syncthreads();
+      LEAN_STAMP(10);
+      // ---- backward of Q_k: chain 0 input gradients, chain 1 weight gradients ----
+      float *const slab = A.slab_q + (long long)tile * (2 * N::Q) + kq * N::Q;
+      if (c == 0) thin_dgrad_last<1>(two, smem + O_DY, TILE(6), TILE(0), sub, lane);
+      else thin_wgrad_last<1>(TILE(9), smem + O_DY, slab + N::Q_OUT, sub, lane);
+      __syncthreads();
+      LEAN_STAMP(11);
+      if (c == 0) hid_dgrad(G2, TILE(0), TILE(5), TILE(1), c0, lane);                              // delta_1
+      else hid_wgrad(TILE(8), TILE(0), slab + N::Q_W1 + HID, c0, lane);                            // dW2 = h1^T delta_2
+      __syncthreads();
+      LEAN_STAMP(12);
+      if (c == 0) hid_dgrad(G1, TILE(1), TILE(4), TILE(2), c0, lane);                              // delta_0
+      else hid_wgrad(TILE(7), TILE(1), slab + N::Q_W1, c0, lane);                                  // dW1 = h0^T delta_1
+      __syncthreads();
+      LEAN_STAMP(13);
+      thin_wgrad_first_<KQ>(s_qin, TILE(2), slab, wave, lane);
+      LEAN_STAMP(14);
+    } else {
+      // =========================================== ACTOR + ALPHA (sac/losses.py:61-72, 112-125) ===========================================
+      const float *const q_p = A.params + N::P + c * N::Q;              // the critic chain c walks in F1
+      // ---- requests of phase F0: chain 0 = pi(s) ----
+      float tw[KP + 1];
+      ImgF I1, I2;
+      float wo[16];
+      float bo0 = 0.f, bo1 = 0.f;
+      if (c == 0) {
+        thin_col_request<KP>(tw, pi_p, lane);
+        img_fwd_request(I1, pi_p + N::P_W1, c0, lane);
+        img_fwd_request(I2, pi_p + N::P_W1 + HID, c0, lane);
+        if (sub == 0) {
+          img_out_request<2>(wo, pi_p + N::P_OUT, lane);
+          bo0 = pi_p[N::P_OUT + LH * 2];
+          bo1 = pi_p[N::P_OUT + LH * 2 + 1];
+        }
+      }
+      {
+        if (tid < 16 * D) {
+          const int r = tid / D, cc = tid - r * D;
+          const int nvalid = (B - row0 < 16 ? B - row0 : 16) * D;
+          if (cc < X) {
+            float v = tid < nvalid ? A.batch[(long long)row0 * D + tid] : 0.f;
+            if (A.norm_mean) v = (v - A.norm_mean[cc]) / A.norm_std[cc];
+            s_qin[r * LDX + cc] = v;
+          }
+        } else if (wave >= 6 && lane < 16) {
+          // actor-loss noise (wave 6) and alpha-loss noise (wave 7)
+          const bool second = wave == 7;
+          const RngKey rk = rng_resolve(A.seed, A.offset, A.rng_dev);
+          const long long nidx = row0 + lane;
+          float e = 0.f;
+          if (row0 + lane < B) {
+            const float *given = second ? A.noise_alpha : A.noise_actor;
+            e = given ? given[nidx] : philox_normal(rk.seed, rk.offset, second ? MBPO_STREAM_SAC_ALPHA : MBPO_STREAM_SAC_ACTOR, (unsigned long long)nidx);
+          }
+          smem[(second ? O_EPS2 : O_EPS) + lane] = e;
+        }
+      }
+      __syncthreads();
+      fold_clip_words();
+      LEAN_STAMP(1);
+      if (c == 0) thin_first<KP, true, false>(tw, s_qin, TILE(7), TILE(4), nullptr, sub, lane);
+      // ---- requests of phase F1: Q1 / Q2 on (s, a~) with the tangent d/da ----
+      float tw1[KQ + 1];
+      ImgF J1, J2;
+      float wo1[16];
+      float bq = 0.f;
+      thin_col_request<KQ>(tw1, q_p, lane);
+      img_fwd_request(J1, q_p + N::Q_W1, c0, lane);
+      img_fwd_request(J2, q_p + N::Q_W1 + HID, c0, lane);
+      if (sub == c) {
+        img_out_request<1>(wo1, q_p + N::Q_OUT, lane);
+        bq = q_p[N::Q_OUT + LH];
+      }
+      __syncthreads();
+      LEAN_STAMP(2);
+      if (c == 0) hid_fwd<true>(I1, TILE(7), TILE(8), TILE(5), c0, lane);
+      __syncthreads();
+      LEAN_STAMP(3);
+      if (c == 0) hid_fwd<true>(I2, TILE(8), TILE(9), TILE(6), c0, lane);
+      __syncthreads();
+      LEAN_STAMP(4);
+      if (wave == 0) {
+        // policy output; lane group 0 draws the actor-loss sample (:117-120), lane group 1 the alpha-loss sample (:66-68)
+        const f32x4 y = out_fwd(wo, TILE(9), lane);
+        const float loc = y[0] + bo0, raw = y[1] + bo1;
+        const int j = lane & 15, g = lane >> 4;
+        const ActSample sm = normal_tanh_sample(loc, raw, smem[(g == 1 ? O_EPS2 : O_EPS) + j]);
+        if (g == 0) {
+          smem[O_LP + j] = sm.lp;
+          smem[O_A + j] = sm.a;
+          smem[O_SIG + j] = sm.sigma;
+          smem[O_RAW + j] = raw;
+          s_qin[j * LDX + X] = sm.a;      // postprocess(action)
+        } else if (g == 1) {
+          smem[O_EPS2 + j] = sm.lp;
+        }
+      }
+      __syncthreads();
+      LEAN_STAMP(5);
+      // ---- F1: value tiles ping-pong through (0,1) / (10,11), tangent tiles through (2,3) / (12,13) ----
+      const int tv0 = c == 0 ? 0 : 10, tt0 = c == 0 ? 2 : 12;
+      thin_first<KQ, false, true>(tw1, s_qin, TILE(tv0), nullptr, TILE(tt0), sub, lane);
+      // requests of the policy's backward phase
+      float two[2];
+      float G2[16], G1[16];
+      if (c == 0) {
+        two[0] = pi_p[N::P_OUT + lane * 2];
+        two[1] = pi_p[N::P_OUT + lane * 2 + 1];
+        img_dgrad_request(G2, pi_p + N::P_W1 + HID, c0, lane);
+        img_dgrad_request(G1, pi_p + N::P_W1, c0, lane);
+      }
+      __syncthreads();
+      LEAN_STAMP(6);
+      hid_fwd_jvp(J1, TILE(tv0), TILE(tt0), TILE(tv0 + 1), TILE(tt0 + 1), c0, lane);
+      __syncthreads();
+      LEAN_STAMP(7);
+      hid_fwd_jvp(J2, TILE(tv0 + 1), TILE(tt0 + 1), TILE(tv0), TILE(tt0), c0, lane);
+      __syncthreads();
+      LEAN_STAMP(8);
+      if (sub == c) {
+        const f32x4 y = out_fwd(wo1, TILE(tv0), lane);
+        const f32x4 ty = out_fwd(wo1, TILE(tt0), lane);
+        if (lane < 16) {
+          smem[O_Q + 16 * c + lane] = y[0] + bq;
+          smem[O_DQ + 16 * c + lane] = ty[0];
+        }
+      }
+      __syncthreads();
+      LEAN_STAMP(9);
+      if (wave == 0) {
+        const float alpha = expf(log_alpha_v);
+        float l_al = 0.f, l_ac = 0.f;
+        if (lane < 16) {
+          const int r = lane;
+          const bool ok = row0 + r < B;
+          float lp_al = 0.f, lp_ac = 0.f;
+          lp_al += smem[O_EPS2 + r];
+          lp_ac += smem[O_LP + r];
+          l_al = ok ? alpha * (-lp_al - A.target_entropy) : 0.f;            // alpha_loss (:70-72)
+          const float q0 = smem[O_Q + r], q1 = smem[O_Q + 16 + r];
+          const float mq = fminf(q0, q1);
+          l_ac = ok ? (alpha * lp_ac - mq) : 0.f;                           // actor_loss (:123-124)
+          float g0 = 0.f, g1 = 0.f;
+          if (ok) {
+            if (q0 < q1) g0 = -invB;
+            else if (q1 < q0) g1 = -invB;
+            else g0 = g1 = -0.5f * invB;
+          }
+          const float dLda = g0 * smem[O_DQ + r] + g1 * smem[O_DQ + 16 + r];
+          const float a = smem[O_A + r], sg = smem[O_SIG + r], eps = smem[O_EPS + r], raw = smem[O_RAW + r];
+          const float gz = dLda * (1.f - a * a) + alpha * invB * 2.f * a;
+          const float gsig = gz * eps - alpha * invB / sg;
+          smem[O_DY + r * 4] = ok ? gz : 0.f;                               // d/dloc
+          smem[O_DY + r * 4 + 1] = ok ? gsig * fast_sigmoid(raw) : 0.f;     // d/draw
+        }
+        const float al = wave_sum64(l_al), ac = wave_sum64(l_ac);
+        if (lane == 0) {
+          A.slab_ex[tile * 4 + 1] = ac;
+          A.slab_ex[tile * 4 + 2] = al;
+        }
+      }
+      __syncthreads();
+      LEAN_STAMP(10);
+      // ---- backward of the policy ----
+      float *const slab = A.slab_pi + (long long)tile * N::P;
+      if (c == 0) thin_dgrad_last<2>(two, smem + O_DY, TILE(6), TILE(0), sub, lane);
+      else thin_wgrad_last<2>(TILE(9), smem + O_DY, slab + N::P_OUT, sub, lane);
+      __syncthreads();
+      LEAN_STAMP(11);
+      if (c == 0) hid_dgrad(G2, TILE(0), TILE(5), TILE(1), c0, lane);
+      else hid_wgrad(TILE(8), TILE(0), slab + N::P_W1 + HID, c0, lane);
+      __syncthreads();
+      LEAN_STAMP(12);
+      if (c == 0) hid_dgrad(G1, TILE(1), TILE(4), TILE(2), c0, lane);
+      else hid_wgrad(TILE(7), TILE(1), slab + N::P_W1, c0, lane);
+      __syncthreads();
+      LEAN_STAMP(13);
+      thin_wgrad_first_<KP>(s_qin, TILE(2), slab, wave, lane);
+      LEAN_STAMP(14);
+    }
+  };
+
+  run(log_alpha_top);
+  if (!maybe_clip) return;
+  // RARE: the previous optimizer step may have needed clipping.  Canonical norms, the exact decision, and if a group really clips:
+  // fix its step up from the undo log and run the whole pass again on the repaired parameters (sac.hip, same order of events).
+  float *const s_gn = smem + O_DQ;
+  __syncthreads();
+  sac_group_norms(A.opt, s_gn, tid_);
+  __syncthreads();
+  if (s_gn[0] < A.opt.max_norm && s_gn[1] < A.opt.max_norm && s_gn[2] < A.opt.max_norm) return;
+  if (blockIdx.x == 0 && tid_ == 0) A.opt.seq[SAC_CTL_CLIP_EVENTS] += 1u;
+  sac_clip_fixup(A.opt, s_gn, opaque(tid_), 512);
+  __threadfence();
+  __syncthreads();
+  run(A.params[N::P + 2 * N::Q]);
+}
+
+template <int X>
+int launch_x(const SacLeanArgs &A, int n_tiles, hipStream_t st) {
+  int rc;
+  if (A.stamps) {
+    rc = mbpo_ensure_lds<k_sac_lean<X, true>>(LEAN_LDS_BYTES, "sac_lean");
+    if (rc != MBPO_OK) return rc;
+    hipLaunchKernelGGL((k_sac_lean<X, true>), dim3(3 * n_tiles), dim3(512), LEAN_LDS_BYTES, st, A);
+  } else {
+    rc = mbpo_ensure_lds<k_sac_lean<X, false>>(LEAN_LDS_BYTES, "sac_lean");
+    if (rc != MBPO_OK) return rc;
+    hipLaunchKernelGGL((k_sac_lean<X, false>), dim3(3 * n_tiles), dim3(512), LEAN_LDS_BYTES, st, A);
+  }
+  return MBPO_OK;
+}
+
+}  // namespace
+
+bool sac_lean_supports(int x_dim, int u_dim, const int *policy_dims, int policy_layers, int policy_act, const int *q_dims, int q_layers, int q_act) {
+  if (u_dim != 1 || (x_dim != 3 && x_dim != 4)) return false;
+  if (policy_layers != 4 || q_layers != 4 || policy_act != MBPO_ACT_SWISH || q_act != MBPO_ACT_SWISH) return false;
+  for (int l = 1; l <= 3; ++l)
+    if (policy_dims[l] != LH || q_dims[l] != LH) return false;
+  return policy_dims[0] == x_dim && policy_dims[4] == 2 && q_dims[0] == x_dim + 1 && q_dims[4] == 1;
+}
+
+int sac_lean_launch(const SacLeanArgs &A, int x_dim, int n_tiles, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dim == 3) return launch_x<3>(A, n_tiles, st);
+  if (x_dim == 4) return launch_x<4>(A, n_tiles, st);
+  mbpo_set_error("sac_lean: x_dim %d has no instantiation", x_dim);
+  return MBPO_ERR_UNSUPPORTED;
+}
