@@ -190,13 +190,19 @@ __device__ __forceinline__ RngKey rng_resolve(unsigned long long seed, unsigned 
 
 // standard normal for element `idx` of stream `stream` at call counter `offset` under `seed`
 // (Box-Muller on two of the four Philox words; one Philox call per element keeps draws order-independent).
-__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx) {
-  Philox4 p = philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), stream ^ (uint32_t)(offset >> 32) * 0x9E3779B9u,
-                            (uint32_t)offset, (uint32_t)seed, (uint32_t)(seed >> 32));
+// (in two halves so that a kernel can place the integer rounds and the transcendental part in different barrier intervals)
+__device__ __forceinline__ Philox4 philox_normal_bits(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx) {
+  return philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), stream ^ (uint32_t)(offset >> 32) * 0x9E3779B9u,
+                       (uint32_t)offset, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ float philox_normal_from_bits(const Philox4 &p) {
   float u1 = ((float)(p.v[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
   float u2 = (float)(p.v[1] >> 8) * (1.0f / 16777216.0f);           // [0,1)
   float rad = sqrtf(-2.0f * logf(u1));
   return rad * cosf(6.28318530717958647692f * u2);
+}
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx) {
+  return philox_normal_from_bits(philox_normal_bits(seed, offset, stream, idx));
 }
 
 // uniform integer in [lo, hi) for element idx: lo + mulhi(u32, span)   (span = hi-lo > 0)

@@ -60,7 +60,8 @@ constexpr int O_Q = 416;               // [2][16] network values: critic role ta
 constexpr int O_DQ = 448;              // [2][16] actor role: dQ/da
 constexpr int O_QOLD = 480;            // [16] critic role: Q_k(s, a)
 constexpr int O_DY = 496;              // [16][4] output-layer gradient of the network being differentiated
-constexpr int O_TILES = 560;
+constexpr int O_FLAG = 560;            // [4] word 0: the aux wave's quick clip verdict for the end of the pass
+constexpr int O_TILES = 564;
 constexpr int N_TILES = 14;
 constexpr size_t LEAN_LDS_BYTES = (size_t)(O_TILES + N_TILES * LT) * sizeof(float);
 
@@ -117,15 +118,53 @@ __device__ __forceinline__ void read_row16(float (&av)[16], const float *tile, i
 }
 
 // ---- layer steps --------------------------------------------------------------------------------------------------
+// Requests that ride in a layer step's MFMA shadow: a wave issues in order and every MFMA of a chain waits ~40 cycles for its
+// predecessor, so vector-memory requests placed BETWEEN the MFMAs cost nothing, while the same requests in front of the step cost
+// their issue time on every wave of the workgroup at once (the CU's address path takes one wave-instruction per ~6 cycles: 8 waves x
+// 40 requests in one burst were 2.5 k cycles of a 25 k-cycle kernel).  `pf(s)` issues the s-th piece of the riding request; a
+// schedule fence that only ALU and LDS instructions may cross pins "MFMA s, then request s" (hipcc otherwise gathers the requests in
+// front of the first MFMA; sched_group_barrier pipelines were ignored here).
+struct NoPf {
+  static constexpr bool active = false;
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <class F>
+struct Pf {
+  static constexpr bool active = true;
+  F f;
+  __device__ __forceinline__ void operator()(int s) const { f(s); }
+};
+template <class F>
+__device__ __forceinline__ Pf<F> make_pf(F f) {
+  return Pf<F>{f};
+}
+#define PIN_ORDER() __builtin_amdgcn_sched_barrier(0x0086)      /* VALU, SALU and DS may cross; MFMA and VMEM may not */
+
+// piece s (0..15) of a forward hidden image request: one weight each, the bias vector with the last
+__device__ __forceinline__ void img_fwd_request_piece(ImgF &I, const float *__restrict__ W, int c0, int lane, int s) {
+  const int i = lane & 15, g = lane >> 4;
+  I.w[s] = W[(16 * g + s) * LH + c0 + i];
+  if (s == 15) {
+    const f4u t = *reinterpret_cast<const f4u *>(W + LH * LH + c0 + 4 * g);
+    I.b[0] = t[0]; I.b[1] = t[1]; I.b[2] = t[2]; I.b[3] = t[3];
+  }
+}
+
 // hidden layer forward: h_out[row j][c0 + 4 g ..] = swish(x W + b), optionally the pre-activation to z_out
-template <bool STORE_Z>
-__device__ __forceinline__ void hid_fwd(const ImgF &I, const float *xin, float *h_out, float *z_out, int c0, int lane) {
+template <bool STORE_Z, class PF = NoPf>
+__device__ __forceinline__ void hid_fwd(const ImgF &I, const float *xin, float *h_out, float *z_out, int c0, int lane, PF pf = PF()) {
   const int j = lane & 15, g = lane >> 4;
   float av[16];
   read_row16(av, xin, lane);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < 16; ++s) acc = MFMA(I.w[s], av[s], acc);
+  for (int s = 0; s < 16; ++s) {
+    acc = MFMA(I.w[s], av[s], acc);
+    if (PF::active) {
+      pf(s);
+      PIN_ORDER();
+    }
+  }
   float zv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) zv[i] = acc[i] + I.b[i];
@@ -170,6 +209,20 @@ __device__ __forceinline__ f32x4 out_fwd(const float (&w)[16], const float *xin,
 #pragma unroll
   for (int s = 0; s < 16; ++s) acc = MFMA(w[s], av[s], acc);
   return acc;
+}
+// value and tangent of an output layer side by side (two independent accumulation chains: 32-cycle issue instead of 40)
+__device__ __forceinline__ void out_fwd2(const float (&w)[16], const float *xin, const float *tin, int lane, f32x4 &y, f32x4 &ty) {
+  float av[16], tv[16];
+  read_row16(av, xin, lane);
+  read_row16(tv, tin, lane);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, tacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    acc = MFMA(w[s], av[s], acc);
+    tacc = MFMA(w[s], tv[s], tacc);
+  }
+  y = acc;
+  ty = tacc;
 }
 // hidden layer input-gradient: d_out[row j][k0 + 4 g ..] = (delta W^T) * swish'(z_prev)
 __device__ __forceinline__ void hid_dgrad(const float (&w)[16], const float *din, const float *zprev, float *d_out, int k0, int lane) {
@@ -218,6 +271,22 @@ __device__ __forceinline__ void hid_wgrad(const float *hin, const float *delta, 
   }
 }
 
+// Sum over the 16 lanes of a row, result on the row's lane 0: v_l += v_{l+8}, += v_{l+4}, += v_{l+2}, += v_{l+1} on DPP row shifts.
+// For values that are zero outside lanes 0..15 this is wave_sum64's tree (sac_shared.hpp: shuffles by 32, 16, 8, 4, 2, 1 — the
+// first two steps add zeros) with the same pairs in the same order — the same bits — in 4 VALU instructions instead of 6
+// ds_bpermute round trips on the one wave every other wave waits for.
+template <int CTRL>
+__device__ __forceinline__ float dpp_shl(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+  v += dpp_shl<0x108>(v);
+  v += dpp_shl<0x104>(v);
+  v += dpp_shl<0x102>(v);
+  v += dpp_shl<0x101>(v);
+  return v;
+}
+
 // ---- thin layers (chain_run.hpp "thin layers by VALU", shapes as constants) -----------------------------------------
 // layer 0 of a forward chain: rows 4 sub .. 4 sub + 3, column = lane
 template <int K, bool STORE_Z, bool TANGENT>
@@ -250,15 +319,13 @@ __device__ __forceinline__ void thin_first(const float (&tw)[K + 1], const float
 #pragma unroll
   for (int i = 0; i < 4; ++i) h0[(4 * sub + i) * LDH + lane] = zv[i];
 }
-// delta_2 = (dY Wout^T) * swish'(z_2), rows 4 sub .. 4 sub + 3, column = lane; two[o] = Wout[lane][o]
+// delta_2 = (dY Wout^T) * swish'(z_2), rows 4 sub .. 4 sub + 3, column = lane; two[o] = Wout[lane][o]; zv = this lane's z_2 of those
+// rows, read before the section that produces dY
 template <int N>
-__device__ __forceinline__ void thin_dgrad_last(const float (&two)[N], const float *dY, const float *z2, float *d_out, int sub, int lane) {
-  float dv[4][4], zv[4], sv[4];
+__device__ __forceinline__ void thin_dgrad_last(const float (&two)[N], const float *dY, const float (&zv)[4], float *d_out, int sub, int lane) {
+  float dv[4][4], sv[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    load_vec_lds<4>(dY + (4 * sub + i) * 4, dv[i]);
-    zv[i] = z2[(4 * sub + i) * LDH + lane];
-  }
+  for (int i = 0; i < 4; ++i) load_vec_lds<4>(dY + (4 * sub + i) * 4, dv[i]);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float s = 0.f;
@@ -270,13 +337,21 @@ __device__ __forceinline__ void thin_dgrad_last(const float (&two)[N], const flo
 #pragma unroll
   for (int i = 0; i < 4; ++i) d_out[(4 * sub + i) * LDH + lane] = sv[i];
 }
-// output layer's weight gradient: dWout[c][o] = sum_r h2[r][c] dY[r][o] (wave `sub` takes o = sub), db[o] (wave 0)
+__device__ __forceinline__ void thin_z_preload(float (&zv)[4], const float *z2, int sub, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) zv[i] = z2[(4 * sub + i) * LDH + lane];
+}
+// output layer's weight gradient: dWout[c][o] = sum_r h2[r][c] dY[r][o] (wave `sub` takes o = sub), db[o] (wave 0); hc = this lane's
+// column of h2, read before the section that produces dY
 template <int N>
-__device__ __forceinline__ void thin_wgrad_last(const float *h2, const float *dY, float *__restrict__ gW, int sub, int lane) {
+__device__ __forceinline__ void thin_wgrad_last(const float (&hc)[16], const float *dY, float *__restrict__ gW, int sub, int lane) {
   if (sub < N) {
+    float dv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv[r] = dY[r * 4 + sub];
     float acc = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc = fmaf(h2[r * LDH + lane], dY[r * 4 + sub], acc);
+    for (int r = 0; r < 16; ++r) acc = fmaf(hc[r], dv[r], acc);
     gW[lane * N + sub] = acc;
   }
   if (sub == 0 && lane < N) {
@@ -285,6 +360,10 @@ __device__ __forceinline__ void thin_wgrad_last(const float *h2, const float *dY
     for (int r = 0; r < 16; ++r) acc += dY[r * 4 + lane];
     gW[LH * N + lane] = acc;
   }
+}
+__device__ __forceinline__ void thin_col_preload(float (&hc)[16], const float *h2, int lane) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hc[r] = h2[r * LDH + lane];
 }
 // layer 0's weight gradient: wave w8 takes input row k = w8 (< K), wave K the bias; column = lane
 template <int K>
@@ -316,7 +395,7 @@ __device__ __forceinline__ void thin_wgrad_first_(const float *x, const float *d
   }
 
 template <int X, bool STAMPS>
-__global__ void __launch_bounds__(512) k_sac_lean(const SacLeanArgs A) {
+__global__ void __launch_bounds__(576) k_sac_lean(const SacLeanArgs A) {
   extern __shared__ __align__(16) float smem[];
   using N = Net<X>;
   constexpr int D = N::D, KP = N::KP, KQ = N::KQ;
@@ -325,53 +404,188 @@ __global__ void __launch_bounds__(512) k_sac_lean(const SacLeanArgs A) {
   const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   const int c = wave >> 2, sub = wave & 3, c0 = sub * 16;
   const int trole = blockIdx.x % 3, tile = blockIdx.x / 3;      // 0 = critic 0, 1 = actor + alpha, 2 = critic 1
-  const int B = A.B, row0 = tile * 16;
+  // The chain waves' arguments: ONE scalar load of the first 16 dwords, pinned in SGPRs here.  (Left to itself hipcc fetched the
+  // argument block piecemeal next to each use, every piece with a full wait, and the clip words behind a pointer in between: six
+  // dependent scalar round trips — 5.4 k cycles — before the tile load was issued.)
+  const float *a_params = A.params, *a_target_q = A.target_q, *a_batch = A.batch, *a_norm_mean = A.norm_mean, *a_norm_std = A.norm_std;
+  float *a_slab_pi = A.slab_pi, *a_slab_q = A.slab_q;
+  int B = A.B;
+  asm volatile("" : "+s"(a_params), "+s"(a_target_q), "+s"(a_batch), "+s"(a_norm_mean), "+s"(a_norm_std), "+s"(a_slab_pi), "+s"(a_slab_q), "+s"(B));
+  const int row0 = tile * 16;
   {
     const int tid = tid_;
     LEAN_STAMP(0);
   }
-  // the clip check of the previous speculative optimizer step: sac.hip k_sac_fwd_bwd, same protocol, same words
-  const uint4 qw0 = *reinterpret_cast<const uint4 *>(A.opt.seq), qw1 = *reinterpret_cast<const uint4 *>(A.opt.seq + 4);
-  const float count_in = A.step_count_rw[0];
-  const unsigned int ep0_in = A.p2p_epoch ? A.p2p_epoch[0] : 0u, ep1_in = A.p2p_epoch ? A.p2p_epoch[1] : 0u;
-  const float log_alpha_top = A.params[N::P + 2 * N::Q];
   const float invB = 1.0f / (float)B;
-  bool maybe_clip = false;
 
   float *const s_qin = smem + O_QIN, *const s_qin2 = smem + O_QIN2, *const s_aux = smem + O_AUX;
   float *const tiles = smem + O_TILES;
 #define TILE(n) (tiles + (n) * LT)
 
-  // The words requested at the top are used up behind the first barrier (they have arrived with the tile): folded into the quick
-  // verdict, and block 0 publishes this step's slot, the optimizer count and the exchange epoch (idempotent: a second pass repeats
-  // the same stores).  Nothing above may WAIT for these loads (sac.hip: +2 us when the tile loads queued behind them).
-  auto fold_clip_words = [&]() __attribute__((always_inline)) {
+  // The clip check of the previous speculative optimizer step (sac.hip k_sac_fwd_bwd: same protocol, same words) is the aux wave's:
+  // it reads the sequence numbers and the quick verdict, leaves "maybe clipped" in LDS for the end of the pass, and block 0's aux
+  // wave publishes this step's slot, the optimizer count and the exchange epoch (idempotent: a second pass repeats the same stores).
+  auto aux_clip_words = [&]() __attribute__((always_inline)) {
+    const uint4 qw0 = *reinterpret_cast<const uint4 *>(A.opt.seq), qw1 = *reinterpret_cast<const uint4 *>(A.opt.seq + 4);
     const unsigned int seq_issued = qw0.x, seq_resolved = qw0.y;
     const bool odd = (seq_issued & 1u) == 0u;
     const float q0 = __uint_as_float(odd ? qw1.y : qw0.z), q1 = __uint_as_float(odd ? qw1.z : qw0.w), q2 = __uint_as_float(odd ? qw1.w : qw1.x);
     const float lim = (A.opt.max_norm / A.opt.grad_scale) * (A.opt.max_norm / A.opt.grad_scale) * 0.9998f;
-    maybe_clip = seq_issued != seq_resolved && !(q0 < lim && q1 < lim && q2 < lim);
-    if (blockIdx.x == 0 && tid_ == 0) {
+    const bool maybe = seq_issued != seq_resolved && !(q0 < lim && q1 < lim && q2 < lim);
+    if (tid_ == 512) smem[O_FLAG] = maybe ? 1.f : 0.f;
+    if (blockIdx.x == 0 && tid_ == 512) {
+      const float count_in = A.step_count_rw[0];
       const unsigned int slot = qw0.x & 1u;
       A.opt.slot_word[0] = slot;
       float *q = reinterpret_cast<float *>(A.opt.seq) + 2 + 3 * slot;
       q[0] = 0.f; q[1] = 0.f; q[2] = 0.f;
       A.step_count_rw[0] = count_in + 1.0f;
       if (A.p2p_epoch) {
+        const unsigned int ep0_in = A.p2p_epoch[0], ep1_in = A.p2p_epoch[1];
         A.p2p_epoch[0] = ep0_in + 1u;
         A.p2p_epoch[1] = ep1_in + A.p2p_blocks;
       }
     }
   };
 
-  auto run = [&](const float log_alpha_v) __attribute__((always_inline)) {
+  auto run = [&](const bool second_pass) __attribute__((always_inline)) {
     const int tid = opaque(tid_), lane = tid & 63;
-    const float *const pi_p = A.params;
-    if (trole != 1) {
+    const float *const pi_p = a_params;
+    // ---- the tile's transitions: ONE coalesced dword per thread (the 16 rows are contiguous), requested before anything else —
+    // vector-memory results return in order, so whatever is requested in front of it is waited for with it.  Column cc of row r goes
+    // to: obs -> s_qin, action -> s_qin[X] (critic role), reward / discount / truncation -> s_aux, next obs -> s_qin2 (critic role).
+    const bool has_elem = tid < 16 * D;
+    const int r_t = tid / D, cc_t = tid - r_t * D;
+    const bool is_obs = cc_t < X, is_obs2 = cc_t >= X + 3 && cc_t < 2 * X + 3;
+    const int oc_t = is_obs ? cc_t : (is_obs2 ? cc_t - (X + 3) : 0);
+    float v_t = 0.f, mu_t = 0.f, sd_t = 1.f;
+    if (has_elem && (trole != 1 || is_obs)) {
+      const int nvalid = (B - row0 < 16 ? B - row0 : 16) * D;
+      if (tid < nvalid) v_t = a_batch[(long long)row0 * D + tid];
+      if (a_norm_mean && (is_obs || is_obs2)) {
+        mu_t = a_norm_mean[oc_t];
+        sd_t = a_norm_std[oc_t];
+      }
+    }
+    auto tile_to_lds = [&]() __attribute__((always_inline)) {
+      if (has_elem) {
+        float v = v_t;
+        if (a_norm_mean && (is_obs || is_obs2)) v = (v - mu_t) / sd_t;
+        int dst = -1;
+        if (is_obs) dst = O_QIN + r_t * LDX + cc_t;
+        else if (trole != 1) {
+          if (is_obs2) dst = O_QIN2 + r_t * LDX + oc_t;
+          else if (cc_t == X) dst = O_QIN + r_t * LDX + X;                  // transitions.action
+          else if (cc_t == X + 1) dst = O_AUX + r_t * 4 + 0;                // reward
+          else if (cc_t == X + 2) dst = O_AUX + r_t * 4 + 1;                // discount
+          else dst = O_AUX + r_t * 4 + 2;                                   // truncation
+        }
+        if (dst >= 0) smem[dst] = v;
+      }
+    };
+    if (wave == 8) {
+      // =========================================== AUX WAVE ===========================================
+      // The ninth wave walks no chain.  It owns what would otherwise sit on a chain wave's critical path: the sampling noise (Philox
+      // rounds in the first hidden-layer interval, Box-Muller in the second: a chain wave that drew it behind its 46 weight requests
+      // held the first barrier for 5.5 k cycles) and the loss section (its operands that exist early are in registers before the
+      // output layers finish).  It executes the chain waves' 13 barriers.
+      const bool critic = trole != 1;
+      const int kq = trole >> 1;
+      const RngKey rk = rng_resolve(A.seed, A.offset, A.rng_dev);
+      const bool second = lane >= 16;                          // actor role: lanes 16..31 draw the alpha-loss noise
+      const int r = lane & 15;
+      const bool draws = lane < (critic ? 16 : 32);
+      const float *const given = critic ? A.noise_critic : (second ? A.noise_alpha : A.noise_actor);
+      const unsigned int stream = critic ? MBPO_STREAM_SAC_CRITIC : (second ? MBPO_STREAM_SAC_ALPHA : MBPO_STREAM_SAC_ACTOR);
+      const long long nidx = row0 + r;
+      float e_given = 0.f;
+      if (draws && given && row0 + r < B) e_given = given[nidx];
+      __syncthreads();      // 1: tile in LDS
+      aux_clip_words();
+      __syncthreads();      // 2: thin layer 0
+      Philox4 bits;
+      bits.v[0] = bits.v[1] = bits.v[2] = bits.v[3] = 0u;
+      if (draws && !given) bits = philox_normal_bits(rk.seed, rk.offset, stream, (unsigned long long)nidx);
+      __syncthreads();      // 3: hidden layer 1
+      if (draws) {
+        float e = 0.f;
+        if (row0 + r < B) e = given ? e_given : philox_normal_from_bits(bits);
+        smem[(second ? O_EPS2 : O_EPS) + r] = e;
+      }
+      __syncthreads();      // 4: hidden layer 2 (the noise is in LDS for the sampling section)
+      __syncthreads();      // 5: output layer + sample
+      __syncthreads();      // 6: thin layer (F1)
+      __syncthreads();      // 7
+      // (second pass: the fix-up has just rewritten log_alpha; an agent-scope load does not come from this CU's caches)
+      const float log_alpha_v = second_pass ? __hip_atomic_load(a_params + N::P + 2 * N::Q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                            : a_params[N::P + 2 * N::Q];
+      const float alpha = expf(log_alpha_v);
+      const bool ok = row0 + r < B;
+      if (critic) {
+        // ---- targets, errors, dL/dq (:88-110) ----
+        float nlp = 0.f;
+        nlp += smem[O_LP + r];
+        const float rew = s_aux[r * 4 + 0], disc = s_aux[r * 4 + 1], trunc = s_aux[r * 4 + 2], qold = smem[O_QOLD + r];
+        float gamma = A.discounting;
+        if (A.neq) {                                                                             // :90-96
+          const float pseudo = s_qin[r * LDX + X];                                               // transitions.action[..., -1]
+          float tfa = (A.neq_tu - A.neq_tl) / 2.0f * pseudo + (A.neq_tu + A.neq_tl) / 2.0f;
+          tfa = floor_divide_f(tfa, A.neq_dt) * A.neq_dt;
+          gamma = expf(-A.neq_cd * tfa);
+        }
+        __syncthreads();    // 8
+        __syncthreads();    // 9: the target critics' outputs
+        float e2 = 0.f;
+        if (lane < 16) {
+          const float nq = fminf(smem[O_Q + r], smem[O_Q + 16 + r]);
+          const float next_v = nq - alpha * nlp;                                                   // :89
+          const float target = rew * A.reward_scaling + disc * gamma * next_v;                     // :101-103
+          const float err = ok ? (qold - target) * (1.f - trunc) : 0.f;                            // :104-108
+          e2 = err * err;
+          smem[O_DY + r * 4] = err * (1.f - trunc) * (0.5f * invB);
+        }
+        const float acc = row_sum16(e2);
+        if (lane == 0) A.slab_ex[tile * 4 + (kq == 1 ? 3 : 0)] = acc;
+      } else {
+        float lp_al = 0.f, lp_ac = 0.f;
+        lp_al += smem[O_EPS2 + r];
+        lp_ac += smem[O_LP + r];
+        const float a = smem[O_A + r], sg = smem[O_SIG + r], eps = smem[O_EPS + r], raw = smem[O_RAW + r];
+        __syncthreads();    // 8
+        __syncthreads();    // 9: the critics' values and tangents
+        float l_al = 0.f, l_ac = 0.f;
+        if (lane < 16) {
+          l_al = ok ? alpha * (-lp_al - A.target_entropy) : 0.f;            // alpha_loss (:70-72)
+          const float q0 = smem[O_Q + r], q1 = smem[O_Q + 16 + r];
+          const float mq = fminf(q0, q1);
+          l_ac = ok ? (alpha * lp_ac - mq) : 0.f;                           // actor_loss (:123-124)
+          float g0 = 0.f, g1 = 0.f;
+          if (ok) {
+            if (q0 < q1) g0 = -invB;
+            else if (q1 < q0) g1 = -invB;
+            else g0 = g1 = -0.5f * invB;
+          }
+          const float dLda = g0 * smem[O_DQ + r] + g1 * smem[O_DQ + 16 + r];
+          const float gz = dLda * (1.f - a * a) + alpha * invB * 2.f * a;
+          const float gsig = gz * eps - alpha * invB / sg;
+          smem[O_DY + r * 4] = ok ? gz : 0.f;                               // d/dloc
+          smem[O_DY + r * 4 + 1] = ok ? gsig * fast_sigmoid(raw) : 0.f;     // d/draw
+        }
+        const float al = row_sum16(l_al), ac = row_sum16(l_ac);
+        if (lane == 0) {
+          A.slab_ex[tile * 4 + 1] = ac;
+          A.slab_ex[tile * 4 + 2] = al;
+        }
+      }
+      __syncthreads();      // 10: dY
+      __syncthreads();      // 11
+      __syncthreads();      // 12
+      __syncthreads();      // 13
+    } else if (trole != 1) {
       // =========================================== CRITIC kq (sac/losses.py:74-110) ===========================================
       const int kq = trole >> 1;
-      const float *const qk_p = A.params + N::P + kq * N::Q;
-      const float *const qt_p = A.target_q + c * N::Q;                  // the target critic chain c walks in F1
+      const float *const qk_p = a_params + N::P + kq * N::Q;
+      const float *const qt_p = a_target_q + c * N::Q;                  // the target critic chain c walks in F1
       // ---- requests of phase F0: chain 0 = pi(s'), chain 1 = Q_k(s, a) ----
       float tw[KQ + 1];
       ImgF I1, I2;
@@ -395,59 +609,38 @@ __global__ void __launch_bounds__(512) k_sac_lean(const SacLeanArgs A) {
           bo0 = qk_p[N::Q_OUT + LH];
         }
       }
-      // ---- tile section: one coalesced dword per thread, classified by column ----
-      {
-        if (tid < 16 * D) {
-          const int r = tid / D, cc = tid - r * D;
-          const int nvalid = (B - row0 < 16 ? B - row0 : 16) * D;
-          float v = tid < nvalid ? A.batch[(long long)row0 * D + tid] : 0.f;
-          if (cc < X || (cc >= X + 3 && cc < 2 * X + 3)) {
-            const int oc = cc < X ? cc : cc - (X + 3);
-            if (A.norm_mean) v = (v - A.norm_mean[oc]) / A.norm_std[oc];
-            (cc < X ? s_qin : s_qin2)[r * LDX + oc] = v;
-          } else if (cc == X) {
-            s_qin[r * LDX + X] = v;            // transitions.action
-            s_aux[r * 4 + 3] = v;
-          } else if (cc == X + 1) s_aux[r * 4 + 0] = v;
-          else if (cc == X + 2) s_aux[r * 4 + 1] = v;
-          else s_aux[r * 4 + 2] = v;           // truncation
-        } else if (wave == 7 && lane < 16) {
-          // next-action noise, drawn beside the tile load (it depends on the key and the element only)
-          const RngKey rk = rng_resolve(A.seed, A.offset, A.rng_dev);
-          const long long nidx = row0 + lane;
-          float e = 0.f;
-          if (row0 + lane < B) e = A.noise_critic ? A.noise_critic[nidx] : philox_normal(rk.seed, rk.offset, MBPO_STREAM_SAC_CRITIC, (unsigned long long)nidx);
-          smem[O_EPS + lane] = e;
-        }
-      }
+      tile_to_lds();
       __syncthreads();
-      fold_clip_words();
       LEAN_STAMP(1);
-      if (c == 0) thin_first<KP, false, false>(*reinterpret_cast<float(*)[KP + 1]>(&tw[0]), s_qin2, TILE(0), nullptr, nullptr, sub, lane);
-      else thin_first<KQ, true, false>(tw, s_qin, TILE(7), TILE(4), nullptr, sub, lane);
-      // ---- requests of phase F1: both target critics on (s', a') ----
+      // ---- F0 thin layer; the target critics' thin columns are requested here (6 requests) ----
       float tw1[KQ + 1];
       ImgF J1, J2;
-      float wo1[16];
-      float bt = 0.f;
+      if (c == 0) thin_first<KP, false, false>(*reinterpret_cast<float(*)[KP + 1]>(&tw[0]), s_qin2, TILE(0), nullptr, nullptr, sub, lane);
+      else thin_first<KQ, true, false>(tw, s_qin, TILE(7), TILE(4), nullptr, sub, lane);
       thin_col_request<KQ>(tw1, qt_p, lane);
-      img_fwd_request(J1, qt_p + N::Q_W1, c0, lane);
-      img_fwd_request(J2, qt_p + N::Q_W1 + HID, c0, lane);
-      if (sub == c) {
-        img_out_request<1>(wo1, qt_p + N::Q_OUT, lane);
-        bt = qt_p[N::Q_OUT + LH];
-      }
       __syncthreads();
       LEAN_STAMP(2);
-      if (c == 0) hid_fwd<false>(I1, TILE(0), TILE(1), nullptr, c0, lane);
-      else hid_fwd<true>(I1, TILE(7), TILE(8), TILE(5), c0, lane);
+      // ---- F0 hidden layers; F1's two images are requested in their MFMA shadows ----
+      {
+        auto pf = make_pf([&](int s) __attribute__((always_inline)) { img_fwd_request_piece(J1, qt_p + N::Q_W1, c0, lane, s); });
+        if (c == 0) hid_fwd<false>(I1, TILE(0), TILE(1), nullptr, c0, lane, pf);
+        else hid_fwd<true>(I1, TILE(7), TILE(8), TILE(5), c0, lane, pf);
+      }
       __syncthreads();
       LEAN_STAMP(3);
-      if (c == 0) hid_fwd<false>(I2, TILE(1), TILE(0), nullptr, c0, lane);
-      else hid_fwd<true>(I2, TILE(8), TILE(9), TILE(6), c0, lane);
+      {
+        auto pf = make_pf([&](int s) __attribute__((always_inline)) { img_fwd_request_piece(J2, qt_p + N::Q_W1 + HID, c0, lane, s); });
+        if (c == 0) hid_fwd<false>(I2, TILE(1), TILE(0), nullptr, c0, lane, pf);
+        else hid_fwd<true>(I2, TILE(8), TILE(9), TILE(6), c0, lane, pf);
+      }
       __syncthreads();
       LEAN_STAMP(4);
-      // ---- output layers + the sampling section on the wave that holds the policy's output ----
+      // ---- output layers + the sampling section on the wave that holds the policy's output; the idle waves request what comes
+      // later: F1's output images (waves 1 and 6) and the backward phase's images (chain 0) ----
+      float wo1[16];
+      float bt = 0.f;
+      float two[1];
+      float G2[16], G1[16];
       if (c == 0 && sub == 0) {
         const f32x4 y = out_fwd(wo, TILE(0), lane);
         const float loc = y[0] + bo0, raw = y[1] + bo1;
@@ -461,18 +654,19 @@ __global__ void __launch_bounds__(512) k_sac_lean(const SacLeanArgs A) {
         const f32x4 y = out_fwd(wo, TILE(9), lane);
         if (lane < 16) smem[O_QOLD + lane] = y[0] + bo0;                         // q_old_action (:78-79), this workgroup's critic
       }
-      __syncthreads();
-      LEAN_STAMP(5);
-      // ---- F1: target critics ----
-      thin_first<KQ, false, false>(tw1, s_qin2, TILE(2 * c), nullptr, nullptr, sub, lane);
-      // requests of the backward phase: chain 0 walks Q_k's input gradients, chain 1 its weight gradients (no weights)
-      float two[1];
-      float G2[16], G1[16];
+      if (sub == c + 1) {
+        img_out_request<1>(wo1, qt_p + N::Q_OUT, lane);
+        bt = qt_p[N::Q_OUT + LH];
+      }
       if (c == 0) {
         two[0] = qk_p[N::Q_OUT + lane];
         img_dgrad_request(G2, qk_p + N::Q_W1 + HID, c0, lane);
         img_dgrad_request(G1, qk_p + N::Q_W1, c0, lane);
       }
+      __syncthreads();
+      LEAN_STAMP(5);
+      // ---- F1: target critics ----
+      thin_first<KQ, false, false>(tw1, s_qin2, TILE(2 * c), nullptr, nullptr, sub, lane);
       __syncthreads();
       LEAN_STAMP(6);
       hid_fwd<false>(J1, TILE(2 * c), TILE(2 * c + 1), nullptr, c0, lane);
@@ -481,46 +675,23 @@ __global__ void __launch_bounds__(512) k_sac_lean(const SacLeanArgs A) {
       hid_fwd<false>(J2, TILE(2 * c + 1), TILE(2 * c), nullptr, c0, lane);
       __syncthreads();
       LEAN_STAMP(8);
-      if (sub == c) {
+      // output layers (waves 1 and 6); the backward phase's LDS operands that exist already are read meanwhile
+      float zq[4], hc[16];
+      if (sub == c + 1) {
         const f32x4 y = out_fwd(wo1, TILE(2 * c), lane);
         if (lane < 16) smem[O_Q + 16 * c + lane] = y[0] + bt;
       }
+      if (c == 0) thin_z_preload(zq, TILE(6), sub, lane);
+      else if (sub == 0) thin_col_preload(hc, TILE(9), lane);
       __syncthreads();
       LEAN_STAMP(9);
-      // ---- targets, errors, dL/dq (:88-110): 16 lanes of wave 0 ----
-      if (wave == 0) {
-        const float alpha = expf(log_alpha_v);
-        float e2 = 0.f;
-        if (lane < 16) {
-          const int r = lane;
-          const bool ok = row0 + r < B;
-          float nlp = 0.f;
-          nlp += smem[O_LP + r];
-          const float nq = fminf(smem[O_Q + r], smem[O_Q + 16 + r]);
-          const float next_v = nq - alpha * nlp;                                                   // :89
-          const float rew = s_aux[r * 4 + 0], disc = s_aux[r * 4 + 1];
-          float gamma = A.discounting;
-          if (A.neq) {                                                                             // :90-96
-            const float pseudo = s_aux[r * 4 + 3];
-            float tfa = (A.neq_tu - A.neq_tl) / 2.0f * pseudo + (A.neq_tu + A.neq_tl) / 2.0f;
-            tfa = floor_divide_f(tfa, A.neq_dt) * A.neq_dt;
-            gamma = expf(-A.neq_cd * tfa);
-          }
-          const float target = rew * A.reward_scaling + disc * gamma * next_v;                     // :101-103
-          const float trunc = s_aux[r * 4 + 2];
-          const float err = ok ? (smem[O_QOLD + r] - target) * (1.f - trunc) : 0.f;                // :104-108
-          e2 = err * err;
-          smem[O_DY + r * 4] = err * (1.f - trunc) * (0.5f * invB);
-        }
-        const float acc = wave_sum64(e2);
-        if (lane == 0) A.slab_ex[tile * 4 + (kq == 1 ? 3 : 0)] = acc;
-      }
+      // (the loss section runs on the aux wave)
       __syncthreads();
       LEAN_STAMP(10);
       // ---- backward of Q_k: chain 0 input gradients, chain 1 weight gradients ----
-      float *const slab = A.slab_q + (long long)tile * (2 * N::Q) + kq * N::Q;
-      if (c == 0) thin_dgrad_last<1>(two, smem + O_DY, TILE(6), TILE(0), sub, lane);
-      else thin_wgrad_last<1>(TILE(9), smem + O_DY, slab + N::Q_OUT, sub, lane);
+      float *const slab = a_slab_q + (long long)tile * (2 * N::Q) + kq * N::Q;
+      if (c == 0) thin_dgrad_last<1>(two, smem + O_DY, zq, TILE(0), sub, lane);
+      else if (sub == 0) thin_wgrad_last<1>(hc, smem + O_DY, slab + N::Q_OUT, sub, lane);
       __syncthreads();
       LEAN_STAMP(11);
       if (c == 0) hid_dgrad(G2, TILE(0), TILE(5), TILE(1), c0, lane);                              // delta_1
@@ -535,12 +706,16 @@ __global__ void __launch_bounds__(512) k_sac_lean(const SacLeanArgs A) {
       LEAN_STAMP(14);
     } else {
       // =========================================== ACTOR + ALPHA (sac/losses.py:61-72, 112-125) ===========================================
-      const float *const q_p = A.params + N::P + c * N::Q;              // the critic chain c walks in F1
-      // ---- requests of phase F0: chain 0 = pi(s) ----
+      const float *const q_p = a_params + N::P + c * N::Q;              // the critic chain c walks in F1
+      // ---- requests: chain 0 = pi(s) for F0; chain 1 has no F0 work and requests its F1 images (Q2) at once ----
       float tw[KP + 1];
       ImgF I1, I2;
       float wo[16];
       float bo0 = 0.f, bo1 = 0.f;
+      float tw1[KQ + 1];
+      ImgF J1, J2;
+      float wo1[16];
+      float bq = 0.f;
       if (c == 0) {
         thin_col_request<KP>(tw, pi_p, lane);
         img_fwd_request(I1, pi_p + N::P_W1, c0, lane);
@@ -550,53 +725,38 @@ __global__ void __launch_bounds__(512) k_sac_lean(const SacLeanArgs A) {
           bo0 = pi_p[N::P_OUT + LH * 2];
           bo1 = pi_p[N::P_OUT + LH * 2 + 1];
         }
-      }
-      {
-        if (tid < 16 * D) {
-          const int r = tid / D, cc = tid - r * D;
-          const int nvalid = (B - row0 < 16 ? B - row0 : 16) * D;
-          if (cc < X) {
-            float v = tid < nvalid ? A.batch[(long long)row0 * D + tid] : 0.f;
-            if (A.norm_mean) v = (v - A.norm_mean[cc]) / A.norm_std[cc];
-            s_qin[r * LDX + cc] = v;
-          }
-        } else if (wave >= 6 && lane < 16) {
-          // actor-loss noise (wave 6) and alpha-loss noise (wave 7)
-          const bool second = wave == 7;
-          const RngKey rk = rng_resolve(A.seed, A.offset, A.rng_dev);
-          const long long nidx = row0 + lane;
-          float e = 0.f;
-          if (row0 + lane < B) {
-            const float *given = second ? A.noise_alpha : A.noise_actor;
-            e = given ? given[nidx] : philox_normal(rk.seed, rk.offset, second ? MBPO_STREAM_SAC_ALPHA : MBPO_STREAM_SAC_ACTOR, (unsigned long long)nidx);
-          }
-          smem[(second ? O_EPS2 : O_EPS) + lane] = e;
+      } else {
+        thin_col_request<KQ>(tw1, q_p, lane);
+        img_fwd_request(J1, q_p + N::Q_W1, c0, lane);
+        img_fwd_request(J2, q_p + N::Q_W1 + HID, c0, lane);
+        if (sub == 2) {
+          img_out_request<1>(wo1, q_p + N::Q_OUT, lane);
+          bq = q_p[N::Q_OUT + LH];
         }
       }
+      tile_to_lds();
       __syncthreads();
-      fold_clip_words();
       LEAN_STAMP(1);
-      if (c == 0) thin_first<KP, true, false>(tw, s_qin, TILE(7), TILE(4), nullptr, sub, lane);
-      // ---- requests of phase F1: Q1 / Q2 on (s, a~) with the tangent d/da ----
-      float tw1[KQ + 1];
-      ImgF J1, J2;
-      float wo1[16];
-      float bq = 0.f;
-      thin_col_request<KQ>(tw1, q_p, lane);
-      img_fwd_request(J1, q_p + N::Q_W1, c0, lane);
-      img_fwd_request(J2, q_p + N::Q_W1 + HID, c0, lane);
-      if (sub == c) {
-        img_out_request<1>(wo1, q_p + N::Q_OUT, lane);
-        bq = q_p[N::Q_OUT + LH];
+      if (c == 0) {
+        thin_first<KP, true, false>(tw, s_qin, TILE(7), TILE(4), nullptr, sub, lane);
+        thin_col_request<KQ>(tw1, q_p, lane);
       }
       __syncthreads();
       LEAN_STAMP(2);
-      if (c == 0) hid_fwd<true>(I1, TILE(7), TILE(8), TILE(5), c0, lane);
+      if (c == 0) {
+        auto pf = make_pf([&](int s) __attribute__((always_inline)) { img_fwd_request_piece(J1, q_p + N::Q_W1, c0, lane, s); });
+        hid_fwd<true>(I1, TILE(7), TILE(8), TILE(5), c0, lane, pf);
+      }
       __syncthreads();
       LEAN_STAMP(3);
-      if (c == 0) hid_fwd<true>(I2, TILE(8), TILE(9), TILE(6), c0, lane);
+      if (c == 0) {
+        auto pf = make_pf([&](int s) __attribute__((always_inline)) { img_fwd_request_piece(J2, q_p + N::Q_W1 + HID, c0, lane, s); });
+        hid_fwd<true>(I2, TILE(8), TILE(9), TILE(6), c0, lane, pf);
+      }
       __syncthreads();
       LEAN_STAMP(4);
+      float two[2];
+      float G2[16], G1[16];
       if (wave == 0) {
         // policy output; lane group 0 draws the actor-loss sample (:117-120), lane group 1 the alpha-loss sample (:66-68)
         const f32x4 y = out_fwd(wo, TILE(9), lane);
@@ -612,21 +772,22 @@ __global__ void __launch_bounds__(512) k_sac_lean(const SacLeanArgs A) {
         } else if (g == 1) {
           smem[O_EPS2 + j] = sm.lp;
         }
+      } else if (wave == 1) {
+        img_out_request<1>(wo1, q_p + N::Q_OUT, lane);          // chain 0's F1 output image (Q1)
+        bq = q_p[N::Q_OUT + LH];
+      }
+      if (c == 0) {
+        // the policy's backward images
+        two[0] = pi_p[N::P_OUT + lane * 2];
+        two[1] = pi_p[N::P_OUT + lane * 2 + 1];
+        img_dgrad_request(G2, pi_p + N::P_W1 + HID, c0, lane);
+        img_dgrad_request(G1, pi_p + N::P_W1, c0, lane);
       }
       __syncthreads();
       LEAN_STAMP(5);
       // ---- F1: value tiles ping-pong through (0,1) / (10,11), tangent tiles through (2,3) / (12,13) ----
       const int tv0 = c == 0 ? 0 : 10, tt0 = c == 0 ? 2 : 12;
       thin_first<KQ, false, true>(tw1, s_qin, TILE(tv0), nullptr, TILE(tt0), sub, lane);
-      // requests of the policy's backward phase
-      float two[2];
-      float G2[16], G1[16];
-      if (c == 0) {
-        two[0] = pi_p[N::P_OUT + lane * 2];
-        two[1] = pi_p[N::P_OUT + lane * 2 + 1];
-        img_dgrad_request(G2, pi_p + N::P_W1 + HID, c0, lane);
-        img_dgrad_request(G1, pi_p + N::P_W1, c0, lane);
-      }
       __syncthreads();
       LEAN_STAMP(6);
       hid_fwd_jvp(J1, TILE(tv0), TILE(tt0), TILE(tv0 + 1), TILE(tt0 + 1), c0, lane);
@@ -635,54 +796,26 @@ __global__ void __launch_bounds__(512) k_sac_lean(const SacLeanArgs A) {
       hid_fwd_jvp(J2, TILE(tv0 + 1), TILE(tt0 + 1), TILE(tv0), TILE(tt0), c0, lane);
       __syncthreads();
       LEAN_STAMP(8);
-      if (sub == c) {
-        const f32x4 y = out_fwd(wo1, TILE(tv0), lane);
-        const f32x4 ty = out_fwd(wo1, TILE(tt0), lane);
+      float zq[4], hc[16];
+      if (sub == c + 1) {
+        f32x4 y, ty;
+        out_fwd2(wo1, TILE(tv0), TILE(tt0), lane, y, ty);
         if (lane < 16) {
           smem[O_Q + 16 * c + lane] = y[0] + bq;
           smem[O_DQ + 16 * c + lane] = ty[0];
         }
       }
+      if (c == 0) thin_z_preload(zq, TILE(6), sub, lane);
+      else if (sub < 2 && sub != 2) thin_col_preload(hc, TILE(9), lane);
       __syncthreads();
       LEAN_STAMP(9);
-      if (wave == 0) {
-        const float alpha = expf(log_alpha_v);
-        float l_al = 0.f, l_ac = 0.f;
-        if (lane < 16) {
-          const int r = lane;
-          const bool ok = row0 + r < B;
-          float lp_al = 0.f, lp_ac = 0.f;
-          lp_al += smem[O_EPS2 + r];
-          lp_ac += smem[O_LP + r];
-          l_al = ok ? alpha * (-lp_al - A.target_entropy) : 0.f;            // alpha_loss (:70-72)
-          const float q0 = smem[O_Q + r], q1 = smem[O_Q + 16 + r];
-          const float mq = fminf(q0, q1);
-          l_ac = ok ? (alpha * lp_ac - mq) : 0.f;                           // actor_loss (:123-124)
-          float g0 = 0.f, g1 = 0.f;
-          if (ok) {
-            if (q0 < q1) g0 = -invB;
-            else if (q1 < q0) g1 = -invB;
-            else g0 = g1 = -0.5f * invB;
-          }
-          const float dLda = g0 * smem[O_DQ + r] + g1 * smem[O_DQ + 16 + r];
-          const float a = smem[O_A + r], sg = smem[O_SIG + r], eps = smem[O_EPS + r], raw = smem[O_RAW + r];
-          const float gz = dLda * (1.f - a * a) + alpha * invB * 2.f * a;
-          const float gsig = gz * eps - alpha * invB / sg;
-          smem[O_DY + r * 4] = ok ? gz : 0.f;                               // d/dloc
-          smem[O_DY + r * 4 + 1] = ok ? gsig * fast_sigmoid(raw) : 0.f;     // d/draw
-        }
-        const float al = wave_sum64(l_al), ac = wave_sum64(l_ac);
-        if (lane == 0) {
-          A.slab_ex[tile * 4 + 1] = ac;
-          A.slab_ex[tile * 4 + 2] = al;
-        }
-      }
+      // (the loss section runs on the aux wave)
       __syncthreads();
       LEAN_STAMP(10);
       // ---- backward of the policy ----
-      float *const slab = A.slab_pi + (long long)tile * N::P;
-      if (c == 0) thin_dgrad_last<2>(two, smem + O_DY, TILE(6), TILE(0), sub, lane);
-      else thin_wgrad_last<2>(TILE(9), smem + O_DY, slab + N::P_OUT, sub, lane);
+      float *const slab = a_slab_pi + (long long)tile * N::P;
+      if (c == 0) thin_dgrad_last<2>(two, smem + O_DY, zq, TILE(0), sub, lane);
+      else if (sub < 2) thin_wgrad_last<2>(hc, smem + O_DY, slab + N::P_OUT, sub, lane);
       __syncthreads();
       LEAN_STAMP(11);
       if (c == 0) hid_dgrad(G2, TILE(0), TILE(5), TILE(1), c0, lane);
@@ -698,8 +831,9 @@ __global__ void __launch_bounds__(512) k_sac_lean(const SacLeanArgs A) {
     }
   };
 
-  run(log_alpha_top);
-  if (!maybe_clip) return;
+  run(false);
+  // the aux wave left the quick verdict in LDS before the second barrier; every wave has passed the thirteenth
+  if (smem[O_FLAG] == 0.f) return;
   // RARE: the previous optimizer step may have needed clipping.  Canonical norms, the exact decision, and if a group really clips:
   // fix its step up from the undo log and run the whole pass again on the repaired parameters (sac.hip, same order of events).
   float *const s_gn = smem + O_DQ;
@@ -708,10 +842,10 @@ __global__ void __launch_bounds__(512) k_sac_lean(const SacLeanArgs A) {
   __syncthreads();
   if (s_gn[0] < A.opt.max_norm && s_gn[1] < A.opt.max_norm && s_gn[2] < A.opt.max_norm) return;
   if (blockIdx.x == 0 && tid_ == 0) A.opt.seq[SAC_CTL_CLIP_EVENTS] += 1u;
-  sac_clip_fixup(A.opt, s_gn, opaque(tid_), 512);
+  sac_clip_fixup(A.opt, s_gn, opaque(tid_), 576);
   __threadfence();
   __syncthreads();
-  run(A.params[N::P + 2 * N::Q]);
+  run(true);
 }
 
 template <int X>
@@ -720,11 +854,11 @@ int launch_x(const SacLeanArgs &A, int n_tiles, hipStream_t st) {
   if (A.stamps) {
     rc = mbpo_ensure_lds<k_sac_lean<X, true>>(LEAN_LDS_BYTES, "sac_lean");
     if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL((k_sac_lean<X, true>), dim3(3 * n_tiles), dim3(512), LEAN_LDS_BYTES, st, A);
+    hipLaunchKernelGGL((k_sac_lean<X, true>), dim3(3 * n_tiles), dim3(576), LEAN_LDS_BYTES, st, A);
   } else {
     rc = mbpo_ensure_lds<k_sac_lean<X, false>>(LEAN_LDS_BYTES, "sac_lean");
     if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL((k_sac_lean<X, false>), dim3(3 * n_tiles), dim3(512), LEAN_LDS_BYTES, st, A);
+    hipLaunchKernelGGL((k_sac_lean<X, false>), dim3(3 * n_tiles), dim3(576), LEAN_LDS_BYTES, st, A);
   }
   return MBPO_OK;
 }

@@ -4,22 +4,26 @@
 
 // Kernel arguments of k_sac_lean: ~50 dwords (the generic kernel's SacArgs is 3.5 KB of tables and needs a warm-up wave).
 struct SacLeanArgs {
+  // ---- what the chain waves need: the first 16 dwords, fetched with one scalar load at the top of the kernel ----
   const float *params;          // [policy | critic 0 | critic 1 | log_alpha]
   const float *target_q;        // [critic 0 | critic 1]
   const float *batch, *norm_mean, *norm_std;
+  float *slab_pi, *slab_q;
+  int B;
+  int pad0;
+  // ---- the aux wave's (noise, loss section, clip check of the previous speculative optimizer step, counters) ----
+  float *slab_ex;
   const float *noise_alpha, *noise_critic, *noise_actor;
   const unsigned long long *rng_dev;
   unsigned long long seed, offset;
-  float *slab_pi, *slab_q, *slab_ex;
   float *step_count_rw;
   unsigned int *p2p_epoch;
   unsigned int p2p_blocks;
-  int B;
-  float discounting, reward_scaling, target_entropy;
   int neq;
+  float discounting, reward_scaling, target_entropy;
   float neq_cd, neq_tl, neq_tu, neq_dt;
   unsigned long long *stamps;   // measurement hook (mbpo_debug_set_stamps): selects the stamping instantiation, or NULL
-  SacOptArgs opt;               // clip check of the previous speculative optimizer step
+  SacOptArgs opt;
 };
 
 // does the specialised kernel cover these networks?  (policy x -> 64^3 -> 2, critics x+1 -> 64^3 -> 1, swish, u = 1, x in {3, 4})

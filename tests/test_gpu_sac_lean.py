@@ -84,16 +84,18 @@ def test_lean_kernel_chain_of_steps_and_clip_fixup(dev):
     the generic kernel's parameters bit for bit, and counts the same clip events."""
     X, B = 4, 64
     cfg, st, batch, noise, nm, ns = _make(X, 1, (64, 64, 64), B, 4, True, discounting=0.95)
-    outs = []
-    for max_norm in (1e5, 0.35, 1e-3):
+    outs = {}
+    for max_norm in (1e5, 3.0, 1.0, 0.3, 0.1, 1e-3):
         cfg.max_grad_norm = max_norm
         up_g, g = _run(dev, False, cfg, st, batch, noise, nm, ns, B, steps=12, given_noise=False)
         up_l, l = _run(dev, True, cfg, st, batch, noise, nm, ns, B, steps=12, given_noise=False)
         for k in ("grads", "metrics", "metrics_accum", "params", "target_q", "adam_m", "adam_v", "step_count"):
             assert torch.equal(g[k], l[k]), (max_norm, k)
         assert up_g.clip_events() == up_l.clip_events()
-        outs.append(up_l.clip_events())
-    assert outs[0] == 0 and outs[2] == 12 and 0 < outs[1] < 12, outs
+        outs[max_norm] = up_l.clip_events()
+    # never, always, and at least one threshold in between at which some steps clip and others do not
+    assert outs[1e5] == 0 and outs[1e-3] == 12, outs
+    assert any(0 < n < 12 for n in outs.values()), outs
 
 
 def test_lean_kernel_non_equidistant_discount(dev):
