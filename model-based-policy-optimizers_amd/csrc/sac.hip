@@ -1162,6 +1162,7 @@ static int sac_grads_impl(const mbpo_sac_desc *d, int phase_mask, void *stream, 
     L.discounting = A.discounting; L.reward_scaling = A.reward_scaling; L.target_entropy = A.target_entropy;
     L.neq = A.neq; L.neq_cd = A.neq_cd; L.neq_tl = A.neq_tl; L.neq_tu = A.neq_tu; L.neq_dt = A.neq_dt;
     L.stamps = g_sac_stamps;
+    L.pad0 = 0;
     L.opt = A.opt;
     rc = sac_lean_launch(L, d->x_dim, pl.n_tiles, stream);
     if (rc != MBPO_OK) return rc;

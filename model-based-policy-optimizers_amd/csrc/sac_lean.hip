@@ -63,7 +63,11 @@ constexpr int O_DY = 496;              // [16][4] output-layer gradient of the n
 constexpr int O_FLAG = 560;            // [4] word 0: the aux wave's quick clip verdict for the end of the pass
 constexpr int O_TILES = 564;
 constexpr int N_TILES = 14;
-constexpr size_t LEAN_LDS_BYTES = (size_t)(O_TILES + N_TILES * LT) * sizeof(float);
+constexpr int N_AUX = 3;                             // waves 8..10: no chain; noise, loss section, clip words (wave 8), gradient copy-out (all)
+constexpr int LEAN_THREADS = 64 * (8 + N_AUX);
+constexpr int O_STAGE = O_TILES + N_TILES * LT;      // [2][GST] weight gradients of the two hidden layers on their way to the slab
+constexpr int GST = LH * LH + LH;                    // one hidden layer's block: dW [64][64] (16-byte chunks rotated per row) then db [64]
+constexpr size_t LEAN_LDS_BYTES = (size_t)(O_STAGE + 2 * GST) * sizeof(float);
 
 // ---- register images ----------------------------------------------------------------------------------------------
 // forward, hidden layer (W [64][64] then bias [64]), this wave's 16 columns c0..c0+15:
@@ -124,6 +128,9 @@ __device__ __forceinline__ void read_row16(float (&av)[16], const float *tile, i
 // 40 requests in one burst were 2.5 k cycles of a 25 k-cycle kernel).  `pf(s)` issues the s-th piece of the riding request; a
 // schedule fence that only ALU and LDS instructions may cross pins "MFMA s, then request s" (hipcc otherwise gathers the requests in
 // front of the first MFMA; sched_group_barrier pipelines were ignored here).
+struct NoSt {
+  __device__ __forceinline__ void operator()(int) const {}
+};
 struct NoPf {
   static constexpr bool active = false;
   __device__ __forceinline__ void operator()(int) const {}
@@ -150,7 +157,19 @@ __device__ __forceinline__ void img_fwd_request_piece(ImgF &I, const float *__re
   }
 }
 
-// hidden layer forward: h_out[row j][c0 + 4 g ..] = swish(x W + b), optionally the pre-activation to z_out
+// h = swish(z) (in place) and d = swish'(z) from ONE sigmoid: the expressions of act_apply_vec / act_grad_mul_vec (common.hpp) on the
+// same z, so h and, later, delta * d are the bits the generic kernel forms — but the backward pass, whose epilogues sit on the
+// critical path, multiplies by a stored factor instead of evaluating 2 transcendentals per element again.
+__device__ __forceinline__ void swish_and_grad4(float (&z)[4], float (&d)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float sg = fast_sigmoid(z[i]);
+    d[i] = sg * (1.0f + z[i] * (1.0f - sg));
+    z[i] = z[i] * sg;
+  }
+}
+
+// hidden layer forward: h_out[row j][c0 + 4 g ..] = swish(x W + b); STORE_Z: swish'(pre-activation) to z_out for the backward pass
 template <bool STORE_Z, class PF = NoPf>
 __device__ __forceinline__ void hid_fwd(const ImgF &I, const float *xin, float *h_out, float *z_out, int c0, int lane, PF pf = PF()) {
   const int j = lane & 15, g = lane >> 4;
@@ -169,8 +188,13 @@ __device__ __forceinline__ void hid_fwd(const ImgF &I, const float *xin, float *
 #pragma unroll
   for (int i = 0; i < 4; ++i) zv[i] = acc[i] + I.b[i];
   const int o = j * LDH + c0 + 4 * g;
-  if (STORE_Z) store_vec_lds<4>(z_out + o, zv);
-  act_apply_vec<4>(zv, MBPO_ACT_SWISH);
+  if (STORE_Z) {
+    float dv[4];
+    swish_and_grad4(zv, dv);
+    store_vec_lds<4>(z_out + o, dv);
+  } else {
+    act_apply_vec<4>(zv, MBPO_ACT_SWISH);
+  }
   store_vec_lds<4>(h_out + o, zv);
 }
 // the same with the tangent tile riding along (chain_run.hpp JVP): t_out = swish'(z) * (t_in W)
@@ -224,25 +248,35 @@ __device__ __forceinline__ void out_fwd2(const float (&w)[16], const float *xin,
   y = acc;
   ty = tacc;
 }
-// hidden layer input-gradient: d_out[row j][k0 + 4 g ..] = (delta W^T) * swish'(z_prev)
-__device__ __forceinline__ void hid_dgrad(const float (&w)[16], const float *din, const float *zprev, float *d_out, int k0, int lane) {
+// hidden layer input-gradient: d_out[row j][k0 + 4 g ..] = (delta W^T) * swish'(z_prev); `zprev` holds swish'(z_prev) itself
+template <class ST = NoSt>
+__device__ __forceinline__ void hid_dgrad(const float (&w)[16], const float *din, const float *zprev, float *d_out, int k0, int lane, ST st = ST()) {
   const int j = lane & 15, g = lane >> 4;
   float av[16];
+  st(0);
   read_row16(av, din, lane);
   const int o = j * LDH + k0 + 4 * g;
   float zv[4];
   load_vec_lds<4>(zprev + o, zv);
+  st(1);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int n = 0; n < 16; ++n) acc = MFMA(w[n], av[n], acc);
-  float ov[4] = {acc[0], acc[1], acc[2], acc[3]};
-  act_grad_mul_vec<4>(ov, zv, MBPO_ACT_SWISH);
+  float ov[4];
+  st(2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ov[i] = acc[i] * zv[i];      // zv = swish'(z_prev), stored by the forward pass
   store_vec_lds<4>(d_out + o, ov);
+  st(3);
 }
 // hidden layer weight gradient (chain_run.hpp wgrad_tile_fast<4, 1, true>, operands swapped): columns c0..c0+15 of dW [64][64] and
 // of db.  acc[a] lane (j, g) reg i = dW[4 j + a][c0 + 4 g + i]; the bias tile's B operand is the indicator of column 0.
-__device__ __forceinline__ void hid_wgrad(const float *hin, const float *delta, float *__restrict__ gW, int c0, int lane) {
+// Results go to an LDS stage, not to the slab: a 1-KB global store costs the issuing wave ~200 cycles (stores are issue-bound,
+// ~20 B/clk per CU), and the wave that forms the gradients must reach the layer's barrier; copy_stage_out moves them later.
+template <class ST = NoSt>
+__device__ __forceinline__ void hid_wgrad(const float *hin, const float *delta, float *gst, int c0, int lane, ST st = ST()) {
   const int r = lane & 15, g = lane >> 4;
+  st(0);
   f32x4 acc[4], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -254,20 +288,40 @@ __device__ __forceinline__ void hid_wgrad(const float *hin, const float *delta, 
     dv[s] = delta[row * LDH + c0 + r];
   }
   const float one0 = (r == 0) ? 1.f : 0.f;
+  st(1);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[a] = MFMA(dv[s], hv[s][a], acc[a]);
     accb = MFMA(dv[s], one0, accb);
   }
+  st(2);
+  // to the LDS stage: row k = 4 r + a, 16-byte chunk (c0 / 4 + g) rotated by r — eight lanes of a ds_write_b128 group then hit eight
+  // different bank groups (rows are 256 bytes apart: unrotated they would all hit one)
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const float ov[4] = {acc[a][0], acc[a][1], acc[a][2], acc[a][3]};
-    store_vec_global<4>(gW + (4 * r + a) * LH + c0 + 4 * g, ov);
+    store_vec_lds<4>(gst + (4 * r + a) * LH + 4 * (((c0 >> 2) + g + r) & 15), ov);
   }
   if (r == 0) {
     const float ov[4] = {accb[0], accb[1], accb[2], accb[3]};
-    store_vec_global<4>(gW + LH * LH + c0 + 4 * g, ov);
+    store_vec_lds<4>(gst + LH * LH + c0 + 4 * g, ov);
+  }
+  st(3);
+}
+
+// LDS stage -> slab: participant `t` of `n_part` threads moves 16-byte chunks t, t + n_part, ... of one hidden layer's block
+// (1024 rotated chunks of dW, 16 of db) with ds_read_b128 + global_store_dwordx4.
+__device__ __forceinline__ void copy_stage_out(const float *gst, float *__restrict__ gW, int t, int n_part, int q_begin = 0, int q_end = 1040) {
+  for (int q = q_begin + t; q < q_end; q += n_part) {
+    float v[4];
+    load_vec_lds<4>(gst + 4 * q, v);
+    int dst = 4 * q;
+    if (q < 1024) {
+      const int k = q >> 4, cc = q & 15;
+      dst = k * LH + 4 * ((cc - (k >> 2)) & 15);
+    }
+    store_vec_global<4>(gW + dst, v);
   }
 }
 
@@ -305,17 +359,20 @@ __device__ __forceinline__ void thin_first(const float (&tw)[K + 1], const float
     for (int k = 0; k < K; ++k) z = fmaf(xv[i][k], tw[k], z);
     zv[i] = z;
   }
-  if (STORE_Z) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) z0[(4 * sub + i) * LDH + lane] = zv[i];
-  }
   if (TANGENT) {      // d h0 / d x[K - 1] = swish'(z0) * W0[K - 1][col]
     float tv[4] = {tw[K - 1], tw[K - 1], tw[K - 1], tw[K - 1]};
     act_grad_mul_vec<4>(tv, zv, MBPO_ACT_SWISH);
 #pragma unroll
     for (int i = 0; i < 4; ++i) t0[(4 * sub + i) * LDH + lane] = tv[i];
   }
-  act_apply_vec<4>(zv, MBPO_ACT_SWISH);
+  if (STORE_Z) {      // swish'(z0) for the backward pass
+    float dv[4];
+    swish_and_grad4(zv, dv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z0[(4 * sub + i) * LDH + lane] = dv[i];
+  } else {
+    act_apply_vec<4>(zv, MBPO_ACT_SWISH);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) h0[(4 * sub + i) * LDH + lane] = zv[i];
 }
@@ -323,17 +380,18 @@ __device__ __forceinline__ void thin_first(const float (&tw)[K + 1], const float
 // rows, read before the section that produces dY
 template <int N>
 __device__ __forceinline__ void thin_dgrad_last(const float (&two)[N], const float *dY, const float (&zv)[4], float *d_out, int sub, int lane) {
-  float dv[4][4], sv[4];
+  float dv[4][N], sv[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) load_vec_lds<4>(dY + (4 * sub + i) * 4, dv[i]);
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int o = 0; o < N; ++o) dv[i][o] = dY[(4 * sub + i) * 4 + o];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float s = 0.f;
 #pragma unroll
     for (int o = 0; o < N; ++o) s = fmaf(dv[i][o], two[o], s);
-    sv[i] = s;
+    sv[i] = s * zv[i];      // zv = swish'(z_2), stored by the forward pass
   }
-  act_grad_mul_vec<4>(sv, zv, MBPO_ACT_SWISH);
 #pragma unroll
   for (int i = 0; i < 4; ++i) d_out[(4 * sub + i) * LDH + lane] = sv[i];
 }
@@ -394,8 +452,18 @@ __device__ __forceinline__ void thin_wgrad_first_(const float *x, const float *d
     }                                                                                   \
   }
 
+// per-wave fine stamps (diagnostic instantiation only): wave `w`'s first lane writes slot 32 + i
+#define FINE_STAMP(w, i)                                                                \
+  if (STAMPS) {                                                                         \
+    if (A.stamps && tile == 0 && trole == 0 && wave == (w) && lane == 0) {              \
+      unsigned long long t_;                                                            \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+      A.stamps[32 + (i)] = t_;                                                          \
+    }                                                                                   \
+  }
+
 template <int X, bool STAMPS>
-__global__ void __launch_bounds__(576) k_sac_lean(const SacLeanArgs A) {
+__global__ void __launch_bounds__(LEAN_THREADS) k_sac_lean(const SacLeanArgs A) {
   extern __shared__ __align__(16) float smem[];
   using N = Net<X>;
   constexpr int D = N::D, KP = N::KP, KQ = N::KQ;
@@ -424,7 +492,7 @@ __global__ void __launch_bounds__(576) k_sac_lean(const SacLeanArgs A) {
 
   // The clip check of the previous speculative optimizer step (sac.hip k_sac_fwd_bwd: same protocol, same words) is the aux wave's:
   // it reads the sequence numbers and the quick verdict, leaves "maybe clipped" in LDS for the end of the pass, and block 0's aux
-  // wave publishes this step's slot, the optimizer count and the exchange epoch (idempotent: a second pass repeats the same stores).
+  // wave publishes this step's slot, the optimizer count and the exchange epoch.  First pass only.
   auto aux_clip_words = [&]() __attribute__((always_inline)) {
     const uint4 qw0 = *reinterpret_cast<const uint4 *>(A.opt.seq), qw1 = *reinterpret_cast<const uint4 *>(A.opt.seq + 4);
     const unsigned int seq_issued = qw0.x, seq_resolved = qw0.y;
@@ -483,8 +551,9 @@ __global__ void __launch_bounds__(576) k_sac_lean(const SacLeanArgs A) {
         if (dst >= 0) smem[dst] = v;
       }
     };
-    if (wave == 8) {
-      // =========================================== AUX WAVE ===========================================
+    if (wave >= 8) {
+      const int ax = wave - 8;
+      // =========================================== AUX WAVES ===========================================
       // The ninth wave walks no chain.  It owns what would otherwise sit on a chain wave's critical path: the sampling noise (Philox
       // rounds in the first hidden-layer interval, Box-Muller in the second: a chain wave that drew it behind its 46 weight requests
       // held the first barrier for 5.5 k cycles) and the loss section (its operands that exist early are in registers before the
@@ -494,14 +563,14 @@ __global__ void __launch_bounds__(576) k_sac_lean(const SacLeanArgs A) {
       const RngKey rk = rng_resolve(A.seed, A.offset, A.rng_dev);
       const bool second = lane >= 16;                          // actor role: lanes 16..31 draw the alpha-loss noise
       const int r = lane & 15;
-      const bool draws = lane < (critic ? 16 : 32);
+      const bool draws = ax == 0 && lane < (critic ? 16 : 32);
       const float *const given = critic ? A.noise_critic : (second ? A.noise_alpha : A.noise_actor);
       const unsigned int stream = critic ? MBPO_STREAM_SAC_CRITIC : (second ? MBPO_STREAM_SAC_ALPHA : MBPO_STREAM_SAC_ACTOR);
       const long long nidx = row0 + r;
       float e_given = 0.f;
       if (draws && given && row0 + r < B) e_given = given[nidx];
       __syncthreads();      // 1: tile in LDS
-      aux_clip_words();
+      if (ax == 0 && !second_pass) aux_clip_words();      // (a second pass must not bump the counters again)
       __syncthreads();      // 2: thin layer 0
       Philox4 bits;
       bits.v[0] = bits.v[1] = bits.v[2] = bits.v[3] = 0u;
@@ -536,7 +605,7 @@ __global__ void __launch_bounds__(576) k_sac_lean(const SacLeanArgs A) {
         __syncthreads();    // 8
         __syncthreads();    // 9: the target critics' outputs
         float e2 = 0.f;
-        if (lane < 16) {
+        if (ax == 0 && lane < 16) {
           const float nq = fminf(smem[O_Q + r], smem[O_Q + 16 + r]);
           const float next_v = nq - alpha * nlp;                                                   // :89
           const float target = rew * A.reward_scaling + disc * gamma * next_v;                     // :101-103
@@ -545,7 +614,7 @@ __global__ void __launch_bounds__(576) k_sac_lean(const SacLeanArgs A) {
           smem[O_DY + r * 4] = err * (1.f - trunc) * (0.5f * invB);
         }
         const float acc = row_sum16(e2);
-        if (lane == 0) A.slab_ex[tile * 4 + (kq == 1 ? 3 : 0)] = acc;
+        if (ax == 0 && lane == 0) A.slab_ex[tile * 4 + (kq == 1 ? 3 : 0)] = acc;
       } else {
         float lp_al = 0.f, lp_ac = 0.f;
         lp_al += smem[O_EPS2 + r];
@@ -554,7 +623,7 @@ __global__ void __launch_bounds__(576) k_sac_lean(const SacLeanArgs A) {
         __syncthreads();    // 8
         __syncthreads();    // 9: the critics' values and tangents
         float l_al = 0.f, l_ac = 0.f;
-        if (lane < 16) {
+        if (ax == 0 && lane < 16) {
           l_al = ok ? alpha * (-lp_al - A.target_entropy) : 0.f;            // alpha_loss (:70-72)
           const float q0 = smem[O_Q + r], q1 = smem[O_Q + 16 + r];
           const float mq = fminf(q0, q1);
@@ -572,15 +641,23 @@ __global__ void __launch_bounds__(576) k_sac_lean(const SacLeanArgs A) {
           smem[O_DY + r * 4 + 1] = ok ? gsig * fast_sigmoid(raw) : 0.f;     // d/draw
         }
         const float al = row_sum16(l_al), ac = row_sum16(l_ac);
-        if (lane == 0) {
+        if (ax == 0 && lane == 0) {
           A.slab_ex[tile * 4 + 1] = ac;
           A.slab_ex[tile * 4 + 2] = al;
         }
       }
       __syncthreads();      // 10: dY
       __syncthreads();      // 11
-      __syncthreads();      // 12
-      __syncthreads();      // 13
+      __syncthreads();      // 12: dW2 is in stage 0 — moved to the slab while the chain waves walk layer 1
+      float *const aslab = critic ? a_slab_q + (long long)tile * (2 * N::Q) + kq * N::Q : a_slab_pi + (long long)tile * N::P;
+      const int w1 = critic ? N::Q_W1 : N::P_W1, kk = critic ? KQ : KP;
+      FINE_STAMP(8, 16);
+      copy_stage_out(smem + O_STAGE, aslab + w1 + HID, ax * 64 + lane, N_AUX * 64);
+      FINE_STAMP(8, 17);
+      __syncthreads();      // 13: dW1 is in stage 1 — moved by this wave and the chain waves that have no row of layer 0's gradient
+      FINE_STAMP(8, 18);
+      copy_stage_out(smem + O_STAGE + GST, aslab + w1, (7 - kk + ax) * 64 + lane, (7 - kk + N_AUX) * 64);
+      FINE_STAMP(8, 19);
     } else if (trole != 1) {
       // =========================================== CRITIC kq (sac/losses.py:74-110) ===========================================
       const int kq = trole >> 1;
@@ -694,15 +771,28 @@ __global__ void __launch_bounds__(576) k_sac_lean(const SacLeanArgs A) {
       else if (sub == 0) thin_wgrad_last<1>(hc, smem + O_DY, slab + N::Q_OUT, sub, lane);
       __syncthreads();
       LEAN_STAMP(11);
-      if (c == 0) hid_dgrad(G2, TILE(0), TILE(5), TILE(1), c0, lane);                              // delta_1
-      else hid_wgrad(TILE(8), TILE(0), slab + N::Q_W1 + HID, c0, lane);                            // dW2 = h1^T delta_2
+      {
+        auto st0 = [&](int i) __attribute__((always_inline)) { FINE_STAMP(0, i); };
+        auto st4 = [&](int i) __attribute__((always_inline)) { FINE_STAMP(4, 8 + i); };
+        if (c == 0) hid_dgrad(G2, TILE(0), TILE(5), TILE(1), c0, lane, st0);                       // delta_1
+        else hid_wgrad(TILE(8), TILE(0), smem + O_STAGE, c0, lane, st4);                           // dW2 = h1^T delta_2 -> stage 0
+      }
+      FINE_STAMP(0, 4);
+      FINE_STAMP(4, 12);
       __syncthreads();
+      FINE_STAMP(0, 5);
+      FINE_STAMP(4, 13);
       LEAN_STAMP(12);
       if (c == 0) hid_dgrad(G1, TILE(1), TILE(4), TILE(2), c0, lane);                              // delta_0
-      else hid_wgrad(TILE(7), TILE(1), slab + N::Q_W1, c0, lane);                                  // dW1 = h0^T delta_1
+      else hid_wgrad(TILE(7), TILE(1), smem + O_STAGE + GST, c0, lane);                            // dW1 = h0^T delta_1 -> stage 1
+      FINE_STAMP(0, 20);
+      FINE_STAMP(4, 21);
       __syncthreads();
+      FINE_STAMP(0, 22);
       LEAN_STAMP(13);
-      thin_wgrad_first_<KQ>(s_qin, TILE(2), slab, wave, lane);
+      // layer 0's weight gradient on waves 0..K; the other chain waves help the aux wave move stage 1 to the slab
+      if (wave <= KQ) thin_wgrad_first_<KQ>(s_qin, TILE(2), slab, wave, lane);
+      else copy_stage_out(smem + O_STAGE + GST, slab + N::Q_W1, (wave - (KQ + 1)) * 64 + lane, (7 - KQ + N_AUX) * 64);
       LEAN_STAMP(14);
     } else {
       // =========================================== ACTOR + ALPHA (sac/losses.py:61-72, 112-125) ===========================================
@@ -819,14 +909,15 @@ __global__ void __launch_bounds__(576) k_sac_lean(const SacLeanArgs A) {
       __syncthreads();
       LEAN_STAMP(11);
       if (c == 0) hid_dgrad(G2, TILE(0), TILE(5), TILE(1), c0, lane);
-      else hid_wgrad(TILE(8), TILE(0), slab + N::P_W1 + HID, c0, lane);
+      else hid_wgrad(TILE(8), TILE(0), smem + O_STAGE, c0, lane);
       __syncthreads();
       LEAN_STAMP(12);
       if (c == 0) hid_dgrad(G1, TILE(1), TILE(4), TILE(2), c0, lane);
-      else hid_wgrad(TILE(7), TILE(1), slab + N::P_W1, c0, lane);
+      else hid_wgrad(TILE(7), TILE(1), smem + O_STAGE + GST, c0, lane);
       __syncthreads();
       LEAN_STAMP(13);
-      thin_wgrad_first_<KP>(s_qin, TILE(2), slab, wave, lane);
+      if (wave <= KP) thin_wgrad_first_<KP>(s_qin, TILE(2), slab, wave, lane);
+      else copy_stage_out(smem + O_STAGE + GST, slab + N::P_W1, (wave - (KP + 1)) * 64 + lane, (7 - KP + N_AUX) * 64);
       LEAN_STAMP(14);
     }
   };
@@ -842,8 +933,9 @@ __global__ void __launch_bounds__(576) k_sac_lean(const SacLeanArgs A) {
   __syncthreads();
   if (s_gn[0] < A.opt.max_norm && s_gn[1] < A.opt.max_norm && s_gn[2] < A.opt.max_norm) return;
   if (blockIdx.x == 0 && tid_ == 0) A.opt.seq[SAC_CTL_CLIP_EVENTS] += 1u;
-  sac_clip_fixup(A.opt, s_gn, opaque(tid_), 576);
+  sac_clip_fixup(A.opt, s_gn, opaque(tid_), LEAN_THREADS);
   __threadfence();
+  __builtin_amdgcn_s_dcache_inv();      // the output layers' biases are scalar loads: the scalar cache may hold the pre-fix-up lines
   __syncthreads();
   run(true);
 }
@@ -854,11 +946,11 @@ int launch_x(const SacLeanArgs &A, int n_tiles, hipStream_t st) {
   if (A.stamps) {
     rc = mbpo_ensure_lds<k_sac_lean<X, true>>(LEAN_LDS_BYTES, "sac_lean");
     if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL((k_sac_lean<X, true>), dim3(3 * n_tiles), dim3(576), LEAN_LDS_BYTES, st, A);
+    hipLaunchKernelGGL((k_sac_lean<X, true>), dim3(3 * n_tiles), dim3(LEAN_THREADS), LEAN_LDS_BYTES, st, A);
   } else {
     rc = mbpo_ensure_lds<k_sac_lean<X, false>>(LEAN_LDS_BYTES, "sac_lean");
     if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL((k_sac_lean<X, false>), dim3(3 * n_tiles), dim3(576), LEAN_LDS_BYTES, st, A);
+    hipLaunchKernelGGL((k_sac_lean<X, false>), dim3(3 * n_tiles), dim3(LEAN_THREADS), LEAN_LDS_BYTES, st, A);
   }
   return MBPO_OK;
 }

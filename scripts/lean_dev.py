@@ -106,7 +106,7 @@ for k, v in out.items():
 if "--no-stamps" not in sys.argv:
     lib.mbpo_debug_set_sac_lean(1)
     up = updater()
-    stamps = torch.zeros(64, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(96, dtype=torch.int64, device=dev)
     names = ["top -> tile in LDS", "thin 0 + requests F1", "hidden 1", "hidden 2", "out + sample", "thin (F1) + requests B",
              "hidden 1 (F1)", "hidden 2 (F1)", "out (F1)", "loss section", "thin dgrad / wgrad-out", "L2 dgrad || wgrad",
              "L1 dgrad || wgrad", "wgrad first"]
@@ -119,8 +119,19 @@ if "--no-stamps" not in sys.argv:
         if it >= 10:
             s = stamps.cpu()[:32].reshape(2, 16).clone()
             acc = s if acc is None else acc + s
+            f = stamps.cpu()[32:64].clone()
+            fine = f if it == 10 else fine + f
     lib.mbpo_debug_set_stamps(C.c_void_p(0))
     acc = acc.double() / 20
+    fine = fine.double() / 20
+    print("critic L2 step, wave 0 (dgrad): reads issued %d  MFMAs %d  epilogue+write %d  to barrier %d  barrier %d" %
+          tuple(float(fine[i + 1] - fine[i]) for i in (0, 1, 2, 3, 4)))
+    print("critic L2 step, wave 4 (wgrad): reads issued %d  MFMAs %d  stores %d  to barrier %d  barrier %d" %
+          tuple(float(fine[8 + i + 1] - fine[8 + i]) for i in (0, 1, 2, 3, 4)))
+    print("   wave 4 start minus wave 0 start: %d" % float(fine[8] - fine[0]))
+    b12 = float(fine[5])
+    print("critic L1 step (cycles after barrier 12): aux copy starts %d, ends %d | wave 0 (dgrad) at barrier 13 %d, wave 4 (wgrad) %d, released %d | aux final copy %d..%d" %
+          tuple(float(fine[i]) - b12 for i in (16, 17, 20, 21, 22, 18, 19)))
     for role, nm_ in ((0, "critic 0"), (1, "actor")):
         t = acc[role, :15] - acc[role, 0]
         print("role", nm_, "total cycles %.0f" % float(t[14]))
