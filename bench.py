@@ -81,7 +81,8 @@ def build_trainer(device, process_group, use_graph):
 
 
 def time_kernel_alone(trainer, reps=200):
-    """Average duration of the dominant kernel (k_sac_fwd_bwd) from HIP events on the launch stream."""
+    """Average duration of the dominant kernel (k_sac_lean<4>: the SAC forward/backward launch specialised for the benchmark
+    networks, csrc/sac_lean.hip) from HIP events on the launch stream."""
     import ctypes as C
     from mbpo import _hip
     lib = _hip.load()
@@ -265,16 +266,36 @@ def bptt_c5_extra(device, steps=(6, 26)):
             "params_finite": finite, "graph": True, "timed": f"train(train_steps={steps[1]}) - train(train_steps={steps[0]})"}
 
 
+def count_gpus_without_runtime():
+    """Visible GPUs without any HIP call: the *_VISIBLE_DEVICES lists if set, else the KFD topology nodes that have SIMDs
+    (/sys/class/kfd/kfd/topology/nodes/*/properties: CPUs report simd_count 0).  None when neither source is readable — the ranks
+    then fail by themselves with a clear message if a device is missing."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    try:
+        cnt = 0
+        for node in sorted(Path("/sys/class/kfd/kfd/topology/nodes").iterdir()):
+            for line in (node / "properties").read_text().splitlines():
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    cnt += 1
+        return cnt
+    except (OSError, ValueError):
+        return None
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` (N > 1) as ONE command: start N fresh rank processes of this same file — RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set — relay rank 0's single JSON line and
-    return non-zero if any rank failed.  This parent never touches the GPU (no torch.cuda call that initialises it): the ranks are
-    children created before anything here could."""
+    return non-zero if any rank failed.  This parent never touches the GPU: devices are counted from the environment / sysfs (on a
+    ROCm build without amdsmi bindings torch.cuda.device_count() falls back to hipGetDeviceCount, which initialises the runtime:
+    ADVICE r3), the ranks are fresh child processes."""
     import socket
     import subprocess
     share = os.environ.get("MBPO_BENCH_SHARE_GPU") == "1"
-    n_dev = torch.cuda.device_count()            # counting devices does not initialise the GPU
-    if n_dev < n and not share:
+    n_dev = count_gpus_without_runtime()
+    if n_dev is not None and n_dev < n and not share:
         print(f"bench.py --gpus {n}: only {n_dev} GPU(s) visible (MBPO_BENCH_SHARE_GPU=1 rehearses all ranks on one GPU)", file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -357,6 +378,10 @@ def main():
     # (RCCL refuses two ranks on one device — "Duplicate GPU detected" — so the shared-GPU rehearsal defaults to gloo)
     backend = os.environ.get("MBPO_BENCH_BACKEND", "gloo" if share_gpu else "nccl")
     dev_index = 0 if share_gpu else local_rank
+    if dev_index >= torch.cuda.device_count():
+        # (the launcher's sysfs count can see more devices than this container may open)
+        raise SystemExit(f"bench.py rank {rank}: only {torch.cuda.device_count()} GPU(s) visible "
+                         "(MBPO_BENCH_SHARE_GPU=1 rehearses all ranks on one GPU)")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     pg = None
@@ -516,7 +541,7 @@ def main():
             from make_pmc_traffic import source_sha16
             pmc_path = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]        # the newest round's collection
             pmc = json.loads(pmc_path.read_text())
-            cand = {n: v for n, v in pmc["kernels"].items() if n.startswith("k_sac_fwd_bwd<64")}
+            cand = {n: v for n, v in pmc["kernels"].items() if n.startswith("k_sac_lean<") or n.startswith("k_sac_fwd_bwd<64")}
             k = max(cand.values(), key=lambda v: v["dispatches"])     # the variant this workload launches
             if pmc.get("source_sha16") != source_sha16():
                 traffic_note = (f"profiles/{pmc_path.name} was collected on other kernel sources (hash mismatch): refused; "
@@ -524,8 +549,8 @@ def main():
             else:
                 traffic = int((k["fetch_kb"] + k["write_kb"]) * 1024)
                 traffic_note = (f"FETCH_SIZE + WRITE_SIZE per launch from profiles/{pmc_path.name} (rocprofv3 --pmc, separate passes; "
-                                "source hash checked); 1.65 MB written = the 16 per-tile gradient slabs the fixed-order cross-tile "
-                                "reduction reads back, 1.1 MB read = weights once per workgroup (48 workgroups, 8 L2s) + the tile rows")
+                                "source hash checked); the writes are the 16 per-tile gradient slabs the fixed-order cross-tile reduction "
+                                "reads back, the reads the weights once per workgroup (48 workgroups, 8 L2s) + the tile rows")
         except Exception as e:      # noqa: BLE001
             traffic_note = f"no usable PMC measurement ({type(e).__name__})"
         out = {
@@ -556,7 +581,7 @@ def main():
             "sac_updates_per_s": GRAD_UPDATES * args.steps / dt,
             "sac_update_samples_per_s": world * BATCH * GRAD_UPDATES * args.steps / dt,
             "params_finite": finite,
-            "roofline": {"bound": "mfma", "kernel": "k_sac_fwd_bwd<64,4,false,2,true>", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "k_sac_lean<4,false>", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_us": t_kernel * 1e6, "algorithmic_flop_per_launch": BATCH * flop_per_sample,
                          "launches_per_step": GRAD_UPDATES},

@@ -713,7 +713,9 @@ static int ppo_plan(const mbpo_ppo_desc *d, PpoPlan *pl, bool need_ptrs) {
     // G = 1 while that does not oversubscribe the chip (a tile with a few rows of one trajectory wastes MFMA lanes nobody else wants:
     // the launch is a latency chain per workgroup); beyond 4 workgroups per CU, more trajectories per workgroup
     static const int vg_env = getenv("MBPO_PPO_VALUES_GAE") ? atoi(getenv("MBPO_PPO_VALUES_GAE")) : -1;
-    const long long cap_wg = 4LL * ppo_num_cus();
+    // at most 1024 workgroups: k_ppo_moments_combine reads NPT * 256 = 1024 {n, mean, M2} partials (4 x 256 CUs sits exactly at
+    // that limit; a device with more CUs must not drop partials silently: ADVICE r3)
+    const long long cap_wg = 4LL * ppo_num_cus() < 1024 ? 4LL * ppo_num_cus() : 1024;
     long long G = (d->batch_size + cap_wg - 1) / cap_wg;
     if (G < 1) G = 1;
     const long long R = (long long)d->unroll_length + 1;

@@ -452,6 +452,8 @@ __device__ __forceinline__ void thin_wgrad_first_(const float *x, const float *d
     }                                                                                   \
   }
 
+}  // namespace
+
 // per-wave fine stamps (diagnostic instantiation only): wave `w`'s first lane writes slot 32 + i
 #define FINE_STAMP(w, i)                                                                \
   if (STAMPS) {                                                                         \
@@ -939,6 +941,8 @@ __global__ void __launch_bounds__(LEAN_THREADS) k_sac_lean(const SacLeanArgs A) 
   __syncthreads();
   run(true);
 }
+
+namespace {
 
 template <int X>
 int launch_x(const SacLeanArgs &A, int n_tiles, hipStream_t st) {

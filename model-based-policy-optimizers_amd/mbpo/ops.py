@@ -616,6 +616,10 @@ class SacUpdater:
         self.all_reduce, self.world_size = all_reduce, world_size
         self.p2p = p2p      # mbpo.parallel.P2PExchange: gradient exchange through peer memory instead of `all_reduce`
         self.p2p_fused = os.environ.get("MBPO_P2P_FUSED", "1") != "0"   # exchange inside the reduction kernel (default) or split
+        # the fused forms wait INSIDE the reduction kernel for the peers' same kernel, so all of its ceil(NP / 256) workgroups must be
+        # co-resident: the library refuses more than 1024 (mbpo_sac_step_p2p / mbpo_sac_grads_exchange_p2p).  Wide layered critics
+        # (the reference's 256 x 5: NP ~ 530 k, 2070 workgroups) take the split form — push, gather, apply — instead.
+        self._p2p_fused_fits = (self.NP + 255) // 256 <= 1024
         d = _hip.SacDesc()
         d.x_dim, d.u_dim = x_dim, u_dim
         d.policy_layers, d.q_layers = len(policy_dims) - 1, len(q_dims) - 1
@@ -705,12 +709,13 @@ class SacUpdater:
         d.rng_dev = rng_ptr(rng_dev)
         st = current_stream_ptr()
         if self.p2p is not None:
-            if self.two_launch and self.p2p_fused:
+            p2p_fused = self.p2p_fused and self._p2p_fused_fits
+            if self.two_launch and p2p_fused:
                 check(self.lib.mbpo_sac_step_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_step_p2p")
                 if not defer_clip_check:
                     self.finalize()
                 return
-            if self.p2p_fused:      # the slab reduction also exchanges: one launch less per sgd_step
+            if p2p_fused:      # the slab reduction also exchanges: one launch less per sgd_step
                 check(self.lib.mbpo_sac_grads_exchange_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_grads_exchange_p2p")
             else:
                 check(self.lib.mbpo_sac_grads_p2p(C.byref(d), C.byref(self.p2p.desc), st), "mbpo_sac_grads_p2p")

@@ -265,23 +265,28 @@ class PPO:
         """ppo.py:235-247.  The reference compiles the whole epoch scan into ONE XLA computation; here a training_step — K rollouts,
         3 statistics launches, E x (permutation, gather, M x minibatch_step) and the RNG advance, ~1.3 k launches at C3 — is captured
         once into a hipGraph and replayed (every launch reads its counters / RNG words from device memory, so a replayed step is bit
-        for bit the eagerly issued one: tests/test_gpu_trainer_parity.py).  First step of an epoch eager, as in SAC.training_epoch."""
+        for bit the eagerly issued one: tests/test_gpu_trainer_parity.py).  First step ever eager, all later ones replays, as in
+        SAC.training_epoch."""
         self.updater.metrics_accum.zero_()
         self.rekey(key)
         n = self.num_training_steps_per_epoch
         done_steps = 0
-        if self.use_graph and n >= 3 and self._capturable():
-            training_state, state, _ = self.training_step(training_state, state)
-            gkey, refs = self._graph_signature(state)
+        if self.use_graph and self._capturable():
+            # first training_step ever against these buffers: eager, then captured; every later step of every epoch replays
+            gkey, refs = self._graph_signature(training_state, state)
             if self._graph is None or self._graph_key != gkey:
+                training_state, state, _ = self.training_step(training_state, state)
+                done_steps = 1
+                gkey, refs = self._graph_signature(training_state, state)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     self.training_step(training_state, state)
                 self._graph, self._graph_key, self._graph_refs = graph, gkey, refs
-            for _ in range(n - 1):
+            replays = n - done_steps
+            for _ in range(replays):
                 self._graph.replay()
-            training_state = training_state.replace(env_steps=training_state.env_steps + (n - 1) * self.env_step_per_training_step)
+            training_state = training_state.replace(env_steps=training_state.env_steps + replays * self.env_step_per_training_step)
             done_steps = n
         while done_steps < n:
             training_state, state, _ = self.training_step(training_state, state)
@@ -306,11 +311,14 @@ class PPO:
         import torch.distributed as dist
         return dist.get_backend(self.dp.group) == "nccl" and os.environ.get("MBPO_GRAPH_NCCL", "1") != "0"
 
-    def _graph_signature(self, state: State):
-        """Every device address a captured training_step bakes in; the tensors are kept alive with the graph."""
+    def _graph_signature(self, training_state: TrainingState, state: State):
+        """Every device address a captured training_step bakes in — environment and scratch buffers AND the train state (ADVICE r3:
+        a restored or cloned TrainingState must re-capture); the tensors are kept alive with the graph."""
         spec = self.env.system.rollout_spec(state.system_params, self.device)
+        u = self.updater
         tensors = [state.obs, state.info['first_obs'], state.info['steps'], state.done, self._data, self._shuffled, self._stats_vec,
-                   self._rng, self._perm, self._perm_ws]
+                   self._rng, self._perm, self._perm_ws, training_state.params.policy, training_state.params.value,
+                   training_state.normalizer_params.vec, u.params, u.adam_m, u.adam_v, u.step_count, u.workspace]
         tensors += [v for v in spec.values() if isinstance(v, torch.Tensor)]
         return tuple(t.data_ptr() for t in tensors), tensors
 

@@ -355,18 +355,23 @@ class SAC:
     def training_epoch(self, training_state: TrainingState, env_state: State, buffer_state: ReplayBufferState, key: int):
         """sac.py:347-361: num_training_steps_per_epoch training_steps; metrics averaged over the epoch.
 
-        With use_graph the first step of an epoch runs eagerly (it also warms every kernel up), the second is captured
-        into a hipGraph and the rest replay it — all launches read their positions / counters from device memory."""
+        With use_graph the first step ever runs eagerly (it also warms every kernel up) and is captured into a hipGraph; all
+        later steps, in this and in every following epoch, replay it — all launches read their positions / counters / RNG words
+        from device memory."""
         self.updater.metrics_accum.zero_()
         n = self.num_training_steps_per_epoch
         env_steps_per = self.env_steps_per_actor_step * self.num_env_steps_between_updates
         done_steps = 0
         self.rekey(key)
-        if self.use_graph and n >= 3 and self._capturable():
-            training_state, env_state, buffer_state = self.training_step(training_state, env_state, buffer_state)
-            done_steps = 1
-            gkey, refs = self._graph_signature(env_state, buffer_state)
+        if self.use_graph and self._capturable():
+            # The first training_step EVER issued against these buffers runs eagerly (it also warms every kernel up) and is then
+            # captured; every later step — of this epoch and of all following ones, whatever num_training_steps_per_epoch is: the
+            # reference's own acceptance runs have 1 or 2 — is a replay.
+            gkey, refs = self._graph_signature(training_state, env_state, buffer_state)
             if self._graph is None or self._graph_key != gkey:
+                training_state, env_state, buffer_state = self.training_step(training_state, env_state, buffer_state)
+                done_steps = 1
+                gkey, refs = self._graph_signature(training_state, env_state, buffer_state)
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
@@ -374,13 +379,14 @@ class SAC:
                 # the graph holds raw device pointers: keep every tensor it was captured against alive with it
                 self._graph, self._graph_key, self._graph_refs = graph, gkey, refs
             # capture does not execute: every step from here on is a replay
-            for _ in range(n - 1):
+            replays = n - done_steps
+            for _ in range(replays):
                 self._graph.replay()
             done_steps = n
             # host mirrors of the replay positions (same integer arithmetic as the device)
-            for _ in range(n - 1):
+            for _ in range(replays):
                 buffer_state = _advance_mirror(self.replay_buffer, buffer_state, self._rollout_rows.shape[0])
-            training_state = training_state.replace(env_steps=training_state.env_steps + (n - 1) * env_steps_per)
+            training_state = training_state.replace(env_steps=training_state.env_steps + replays * env_steps_per)
         while done_steps < n:
             training_state, env_state, buffer_state = self.training_step(training_state, env_state, buffer_state)
             done_steps += 1
@@ -424,11 +430,16 @@ class SAC:
         import torch.distributed as dist
         return dist.get_backend(self.dp.group) == "nccl" and os.environ.get("MBPO_GRAPH_NCCL", "1") != "0"
 
-    def _graph_signature(self, env_state: State, buffer_state: ReplayBufferState):
-        """Every device address a captured training_step bakes in (`id()` of two tensors can be recycled)."""
+    def _graph_signature(self, training_state: TrainingState, env_state: State, buffer_state: ReplayBufferState):
+        """Every device address a captured training_step bakes in (`id()` of two tensors can be recycled) — the
+        environment, replay and scratch buffers AND the train state the step reads and writes (a restored or cloned
+        TrainingState must re-capture, not replay a graph that updates other tensors)."""
         spec = self.env.system.rollout_spec(env_state.system_params, self.device)
+        u = self.updater
         tensors = [env_state.obs, env_state.info['first_obs'], env_state.info['steps'], env_state.done, buffer_state.data,
-                   buffer_state.state, self._rollout_rows, self._batch_rows, self._stats_vec, self._rng]
+                   buffer_state.state, self._rollout_rows, self._batch_rows, self._stats_vec, self._rng,
+                   training_state.policy_params, training_state.normalizer_params.vec, u.params, u.target_q, u.adam_m, u.adam_v,
+                   u.step_count, u.workspace]
         tensors += [v for v in spec.values() if isinstance(v, torch.Tensor)]
         return tuple(t.data_ptr() for t in tensors) + (bool(self.updater.two_launch),), tensors
 

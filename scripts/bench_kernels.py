@@ -318,6 +318,65 @@ def main():
                           E * Bn * 3 * 2 * mlp_macs(dd), "3*(2M) FLOP per (member, sample)"))
     log(f"ensemble nll: {t * 1e6:.1f} us")
 
+    # ---------------------------------------------------------------- N4: iCEM planner at the reference's defaults (icem_optimizer.py:25-50)
+    def icem_case(H, reps):
+        from mbpo.optimizers.trajectory_optimizers.icem_optimizer import iCemParams, iCemTO
+        from mbpo.systems import PendulumSystem
+        from mbpo.utils import keys as K
+        p = iCemParams()
+        system = PendulumSystem()
+        X, U = system.x_dim, system.u_dim
+        opt = iCemTO(horizon=H, action_dim=U, opt_params=p, system=system)
+        st0 = opt.init(K.PRNGKey(0))
+        b = opt._buffers(dev)
+        spec = system.rollout_spec(st0.system_params, dev)
+        lib, stp = _hip.load(), _hip.current_stream_ptr
+        b["std"].fill_(p.init_std)
+        x0 = torch.tensor([-1.0, 0.0, 0.0], device=dev)
+        NC, N, D = b["NC"], b["N"], b["rows"].shape[1]
+
+        def sample():
+            _hip.check(lib.mbpo_icem_sample(b["mean"].data_ptr(), b["std"].data_ptr(), b["prev"].data_ptr(), b["u_min"].data_ptr(),
+                                            b["u_max"].data_ptr(), p.num_samples, opt.num_prev, H, U, p.num_particles, float(p.exponent),
+                                            11, 0, None, b["actions"].data_ptr(), b["cand"].data_ptr(), stp()), "mbpo_icem_sample")
+
+        def rollout():
+            b["obs"].copy_(x0.expand(N, X)); b["first"].copy_(b["obs"]); b["steps"].zero_(); b["done"].zero_()
+            ops.model_rollout(x_dim=X, u_dim=U, actions=b["actions"], obs=b["obs"], first_obs=b["first"], steps=b["steps"], done=b["done"],
+                              n_steps=H, episode_length=2 ** 30, seed=5, offset=0, out=b["rows"], **spec)
+
+        def update():
+            b["best_value"].fill_(float("-inf"))
+            _hip.check(lib.mbpo_icem_update_constrained(
+                b["rows"].data_ptr(), D, X + U, NC, p.num_particles, H, U, b["cand"].data_ptr(), p.num_elites, opt.num_prev, float(p.alpha),
+                0, None, float(p.lambda_constraint), 0, b["mean"].data_ptr(), b["std"].data_ptr(), b["best_value"].data_ptr(),
+                b["best_seq"].data_ptr(), b["prev"].data_ptr(), b["values"].data_ptr(), b["rank"].data_ptr(), stp()), "mbpo_icem_update")
+
+        cfg = {"num_samples": p.num_samples, "num_particles": p.num_particles, "num_elites": p.num_elites, "horizon": H, "x": X, "u": U,
+               "system": "Pendulum"}
+        sample(); rollout(); update()
+        t, te = both(sample, reps)
+        out.append(hbm_entry("k_icem_sample", "mbpo_icem_sample", cfg, t, 4 * (NC * H * U + H * N * U),
+                             "4 B per candidate element written once + once per particle (actions [H][N][u])"))
+        log(f"icem sample: {t * 1e6:.1f} us")
+        t, te = both(rollout, reps)
+        out.append(hbm_entry("k_model_rollout (open loop, Pendulum)", "mbpo_model_rollout", cfg, t, 4 * H * N * (U + D),
+                             "4 B per action read + one transition row written per (step, trajectory)",))
+        out[-1]["transitions_per_s"] = H * N / t
+        log(f"icem open-loop rollout: {t * 1e6:.1f} us  {H * N / t / 1e6:.1f} M transitions/s")
+        t, te = both(update, reps)
+        out.append(hbm_entry("k_icem_update", "mbpo_icem_update_constrained", cfg, t, 4 * H * N * 1 + 4 * NC * H * U,
+                             "4 B per reward element of the rows + the candidates read once"))
+        log(f"icem update: {t * 1e6:.1f} us")
+        ost = st0
+        t, te = both(lambda: opt.optimize(x0, ost), max(reps // 10, 3), warm=1, inner=1)
+        out.append({"kernel": "iCemTO.optimize (one MPC step)", "entry": "mbpo_icem_sample + mbpo_model_rollout + mbpo_icem_update x num_steps",
+                    "config": dict(cfg, num_steps=p.num_steps), "device_us": t * 1e6, "eager_us": te * 1e6, "bound": "launch",
+                    "note": "num_steps iterations of sample -> open-loop rollout -> update, host loop as icem_optimizer.py:135-252"})
+        log(f"icem optimize: {t * 1e6:.1f} us (eager {te * 1e6:.1f})")
+
+    attempt(icem_case, 20, 100)
+
     res = {"device": torch.cuda.get_device_name(0), "roofs": {"hbm_GBs": HBM_PEAK_GBS, "mfma_f32_TFLOPs": MFMA_F32_PEAK_TF},
            "note": "device_us = HIP-event average per call with the calls captured into a hipGraph and replayed (device time, inputs resident in HBM; multi-launch ops timed whole); eager_us = the same call issued from Python",
            "kernels": out}

@@ -15,5 +15,8 @@ for k in d["kernels"]:
                           ("state_steps_per_s", "M state-steps/s", 1e6), ("elements_per_s", "G elements/s", 1e9), ("rows_per_s", "M rows/s", 1e6)):
         if key in k:
             extra = f"{k[key] / div:.1f} {lab}"
+    if "achieved" not in k:      # a multi-launch host loop: time only
+        print(f"| `{k['entry']}` | {cs} | {k['device_us']:.1f} | — | {k['bound']}-bound | {k.get('note', '')} |")
+        continue
     ach = f"{k['achieved']:.0f} GB/s" if k["unit"] == "GB/s" else f"{k['achieved']:.1f} TFLOP/s"
     print(f"| `{k['entry']}` | {cs} | {k['device_us']:.1f} | {ach} | {k['frac'] * 100:.1f} % {k['bound']} | {extra} |")

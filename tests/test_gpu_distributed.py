@@ -131,7 +131,7 @@ def test_p2p_all_reduce_two_ranks_one_gpu(tmp_path):
     assert all((tmp_path / f"p2p_ok{r}").exists() for r in range(world))
 
 
-def _p2p_sac_worker(rank, world, port, tmpdir, fused, layered=False):
+def _p2p_sac_worker(rank, world, port, tmpdir, fused, layered=False, wide=False):
     _setup_paths()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -143,13 +143,16 @@ def _p2p_sac_worker(rank, world, port, tmpdir, fused, layered=False):
         from mbpo.parallel import DataParallel, P2PExchange
         dp = DataParallel(dist.group.WORLD)
         B = 32
-        cfg, st, batch, noise = _make(world, B, *(((96, 40), (200,)) if layered else ()))
+        cfg, st, batch, noise = _make(world, B, *(((64, 64), (256,) * 5) if wide else ((96, 40), (200,)) if layered else ()))
         sl = slice(rank * B, (rank + 1) * B)
         up = _updater(cfg, B, dev, world_size=world)
         ex = P2PExchange.create(dp, up.NP, dev)
         assert ex is not None
         up.p2p = ex
-        up.p2p_fused = fused
+        if fused is not None:      # None: the updater's own default (fused where the reduction's workgroups can be co-resident)
+            up.p2p_fused = fused
+        if wide:
+            assert up.p2p_fused and not up._p2p_fused_fits and (up.NP + 255) // 256 > 1024
         ref_rccl = _updater(cfg, B, dev, all_reduce=dp.all_reduce_fn(), world_size=world)     # library-collective path (gloo here)
         ref = _updater(cfg, world * B, dev)                                                   # single process, global minibatch
         for u in (up, ref_rccl, ref):
@@ -235,6 +238,18 @@ def _bptt_worker(rank, world, port, tmpdir):
         (Path(tmpdir) / f"bptt_ok{rank}").write_text("ok")
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_sac_wide_critics_over_peer_memory_two_ranks(tmp_path):
+    """the reference's experiment shapes (experiments/train_inverted_pendulum/exp_ppo.py: critic (256,) x 5) give
+    NP ~ 530 k parameters = 2070 reduction workgroups — more than the fused in-kernel exchange may assume co-resident (the library
+    refuses it).  With the DEFAULT flags the updater takes the split exchange (push, gather, apply) for such networks instead of
+    raising on the first update, and equals the all-reduce path bit for bit."""
+    world = 2
+    port = 35500 + (os.getpid() % 2000) + 29
+    mp.spawn(_p2p_sac_worker, args=(world, port, str(tmp_path), None, True, True), nprocs=world, join=True)
+    assert all((tmp_path / f"p2psac_ok{r}").exists() for r in range(world))
 
 
 @pytest.mark.timeout(180)

@@ -167,6 +167,36 @@ def test_sac_graph_epoch_is_bit_identical_to_eager_and_matches_oracle(dev, kind)
     np.testing.assert_allclose(b["stats"].numpy(), loop.stats, rtol=5e-4, atol=5e-5)
 
 
+def test_sac_short_epochs_replay_the_cached_graph(dev):
+    """The reference's acceptance runs have 1 or 2 training steps per epoch (tests/test_sac.py:30-57).  The first step ever is issued
+    eagerly and captured; every later step — the rest of that epoch AND the whole of every following epoch — is a replay.  Three
+    2-step epochs through the graph equal the same six steps issued eagerly, bit for bit (parameters, moments, ring, RNG words)."""
+    out = []
+    for use_graph in (False, True):
+        tr, ts, es, bs, osystem, X, U = _sac_setup(dev, "ensemble", use_graph=use_graph, n_steps=2)
+        ts, es, bs, _ = tr.prefill_replay_buffer(ts, es, bs, 17)
+        graphs = []
+        for epoch, key in enumerate((19, 23, 29)):
+            ts, es, bs, metrics = tr.training_epoch(ts, es, bs, key)
+            graphs.append(tr._graph)
+        torch.cuda.synchronize()
+        if use_graph:
+            assert graphs[0] is not None and graphs[1] is graphs[0] and graphs[2] is graphs[0]      # captured once, replayed since
+        else:
+            assert graphs == [None, None, None]
+        st = bs.state.cpu().tolist()
+        assert st[0] == bs.insert_position and st[1] == bs.sample_position and st[2] == bs.head
+        out.append(dict(params=tr.updater.params.cpu().clone(), tq=tr.updater.target_q.cpu().clone(), m=tr.updater.adam_m.cpu().clone(),
+                        v=tr.updater.adam_v.cpu().clone(), obs=es.obs.cpu().clone(), stats=tr._stats_vec.cpu().clone(),
+                        data=bs.data.cpu().clone(), state=st, count=float(tr.updater.step_count), rng=tr._rng.cpu().tolist(),
+                        env_steps=ts.env_steps, metrics=metrics))
+    a, b = out
+    for k in ("params", "tq", "m", "v", "obs", "stats", "data"):
+        assert torch.equal(a[k], b[k]), f"graph replay differs from eager in {k}"
+    assert a["state"] == b["state"] and a["count"] == b["count"] == 24 and a["rng"] == b["rng"] and a["env_steps"] == b["env_steps"]
+    assert a["metrics"] == b["metrics"]
+
+
 def test_sac_trainer_picks_the_step_flavour_from_the_clip_rate(dev, monkeypatch):
     """max_grad_norm small enough that every sgd_step clips: after the first epoch the trainer switches from the two-launch step
     (a clip costs it a fix-up and a second pass) to the three-launch step, re-captures its hipGraph, and its state stays
