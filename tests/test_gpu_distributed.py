@@ -143,7 +143,7 @@ def _p2p_sac_worker(rank, world, port, tmpdir, fused, layered=False, wide=False)
         from mbpo.parallel import DataParallel, P2PExchange
         dp = DataParallel(dist.group.WORLD)
         B = 32
-        cfg, st, batch, noise = _make(world, B, *(((64, 64), (256,) * 5) if wide else ((96, 40), (200,)) if layered else ()))
+        cfg, st, batch, noise = _make(world, B, *(((64, 64), (256,) * 3) if wide else ((96, 40), (200,)) if layered else ()))
         sl = slice(rank * B, (rank + 1) * B)
         up = _updater(cfg, B, dev, world_size=world)
         ex = P2PExchange.create(dp, up.NP, dev)
@@ -242,10 +242,12 @@ def _bptt_worker(rank, world, port, tmpdir):
 
 @pytest.mark.timeout(240)
 def test_sac_wide_critics_over_peer_memory_two_ranks(tmp_path):
-    """the reference's experiment shapes (experiments/train_inverted_pendulum/exp_ppo.py: critic (256,) x 5) give
-    NP ~ 530 k parameters = 2070 reduction workgroups — more than the fused in-kernel exchange may assume co-resident (the library
-    refuses it).  With the DEFAULT flags the updater takes the split exchange (push, gather, apply) for such networks instead of
-    raising on the first update, and equals the all-reduce path bit for bit."""
+    """wide layered critics (the reference's exp_ppo.py gives its critic (256,) x 5: NP ~ 530 k = 2070 reduction workgroups)
+    are more than the fused in-kernel exchange may assume co-resident — the library refuses above 1024.  With the DEFAULT flags the
+    updater takes the split exchange (push, gather, apply) for such networks instead of raising on the first update, and equals the
+    all-reduce path bit for bit.  Run here with critics (256,) x 3 (NP ~ 276 k, 1077 workgroups, still past the limit): both ranks
+    share this box's ONE GPU, and a waiting kernel of more workgroups than the device holds at once would leave no room for the
+    peer's producer kernel until its bounded waits expire — an artefact of the rehearsal, not of separate GPUs."""
     world = 2
     port = 35500 + (os.getpid() % 2000) + 29
     mp.spawn(_p2p_sac_worker, args=(world, port, str(tmp_path), None, True, True), nprocs=world, join=True)
