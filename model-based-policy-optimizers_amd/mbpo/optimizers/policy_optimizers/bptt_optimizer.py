@@ -253,6 +253,16 @@ class BPTTOptimizer(BaseOptimizer):
         self._critic_grad = ops.CriticGrad(x_dim=X, critic_dims=self.critic_dims, batch=self.critic_batch, device=dev,
                                            activation=critic_activation)
         self.P, self.C2 = self.actor_spec.n_params, 2 * self.critic_spec.n_params
+        # Multi-GPU (as SAC / PPO): the actor and critic gradients and the normalisers' sums go through the one-shot
+        # peer-memory exchange over xGMI (csrc/p2p.hpp) instead of a library collective — plain kernels, so the train step stays
+        # hipGraph-capturable.  create() validates the mapped regions against torch.distributed.all_reduce on every rank and
+        # returns None on every rank (keep the library collective) if anything is off; MBPO_P2P_ALLREDUCE=0 forces that.
+        self.p2p = None
+        if self.dp.group is not None and self.dp.world_size > 1:
+            from mbpo.parallel import P2PExchange
+            self.p2p = P2PExchange.create(self.dp, max(self.P, self.C2, 3 + 2 * self.obs_dim), dev)
+            if self.p2p is not None:
+                self._all_reduce = self.p2p.all_reduce_sum
         self._actor_opt = ops.AdamW(self.P, dev, lr_actor, weight_decay_actor, apply_if_finite=True)
         self._critic_opt = ops.AdamW(self.C2, dev, lr_critic, weight_decay_critic, apply_if_finite=True)
         # scratch (fixed addresses: a train step can be captured in a hipGraph)
@@ -388,6 +398,22 @@ class BPTTOptimizer(BaseOptimizer):
         ops.rng_advance(self._rng)
         return buff
 
+    def _capturable(self) -> bool:
+        """As SAC._capturable: a train step can be captured when it holds plain kernels only — single rank, the peer-memory
+        exchange, or an RCCL process group; never a host-side (gloo) collective (a failed capture is not recoverable)."""
+        if self.dp.group is None or self.p2p is not None:
+            return True
+        import os
+        import torch.distributed as dist
+        return dist.get_backend(self.dp.group) == "nccl" and os.environ.get("MBPO_GRAPH_NCCL", "1") != "0"
+
+    def close(self) -> None:
+        """Release the peer-memory regions."""
+        if self.p2p is not None:
+            self._all_reduce = self.dp.all_reduce_fn()
+            self.p2p.close()
+            self.p2p = None
+
     def _evaluate(self, w: "_Work", eval_obs: torch.Tensor) -> torch.Tensor:
         """evaluate_policy (:480-493): deterministic rollouts of evaluation_horizon steps from eval_obs; mean summed reward."""
         X, U = self.obs_dim, self.action_dim
@@ -444,10 +470,11 @@ class BPTTOptimizer(BaseOptimizer):
         state_key = train_key
         # Every launch of a train step reads its Philox offset / Adam counts / buffer positions from device memory, so the step
         # is captured once into a hipGraph (after one eager step that also sizes every workspace) and replayed: ~25 launches
-        # per step cost more host time than GPU time at the reference's sizes (n = 50, H = 20).  Library collectives are
-        # not captured (a failed capture is not recoverable); evaluation runs eagerly between replays.
+        # per step cost more host time than GPU time at the reference's sizes (n = 50, H = 20).  Under a process group the step
+        # is captured too when its exchanges are kernels: the peer-memory exchange, or RCCL collectives (stream-ordered kernels);
+        # a host-side (gloo) collective is never put inside a capture (_capturable).  Evaluation runs eagerly between replays.
         graph = None
-        can_capture = self.use_graph and self._all_reduce is None and self.train_steps >= 3 and not w.generic   # user code between the kernels
+        can_capture = self.use_graph and self._capturable() and self.train_steps >= 2 and not w.generic   # (generic: user code between the kernels)
         n_rows = self._actor_grad.transitions.shape[0]
         for i in range(self.train_steps):
             sampling_key, state_key = K.split(state_key, 2)
@@ -477,6 +504,10 @@ class BPTTOptimizer(BaseOptimizer):
             summaries[i, 4] = reward
             summaries[i, 5] = best_reward
             prev_reward = reward
+        if self.p2p is not None and self.p2p.status() != 0:
+            raise _hip.MbpoHipError("BPTT: the peer-memory gradient exchange timed out on this rank; "
+                                    "set MBPO_P2P_ALLREDUCE=0 to use the RCCL all-reduce")
+        self._last_train_captured = graph is not None          # (for tests / diagnostics)
         final = w.snapshot(self, state_key)
         if self.use_best_trained_policy and best is not None:
             trained_state = best.replace(system_params=final.system_params)

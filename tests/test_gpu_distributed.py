@@ -201,33 +201,45 @@ def test_sac_layered_sgd_step_over_peer_memory_two_ranks(tmp_path):
     assert all((tmp_path / f"p2psac_ok{r}").exists() for r in range(world))
 
 
-def _bptt_worker(rank, world, port, tmpdir):
+def _bptt_setup(dev, pg, seed_key):
+    from mbpo.optimizers import BPTTOptimizer
+    from mbpo.replay import UniformSamplingQueue
+    from mbpo.systems import PendulumSystem
+    from mbpo.types import Transition
+    system = PendulumSystem()
+    s0 = system.reset()
+    dummy = Transition(observation=s0.x_next, action=torch.zeros(1, device=dev), reward=s0.reward, discount=torch.tensor(0.99, device=dev),
+                       next_observation=s0.x_next)
+    q = UniformSamplingQueue(64, dummy, 1, device=dev)
+    g = torch.Generator().manual_seed(0)
+    th = (torch.rand(32, generator=g) * 2 - 1) * 3.14159
+    obs = torch.stack([torch.cos(th), torch.sin(th), torch.zeros(32)], 1).to(dev)
+    sbs = q.insert(q.init(0), Transition(observation=obs, action=torch.zeros(32, 1, device=dev), reward=torch.zeros(32, device=dev),
+                                         discount=torch.ones(32, device=dev), next_observation=obs))
+    opt = BPTTOptimizer(obs_dim=3, action_dim=1, horizon=6, num_samples_per_gradient_update=16, train_steps=5, sampling_buffer_size=4096,
+                        process_group=pg)
+    opt.set_system(system)
+    return opt, opt.init(key=seed_key, true_buffer_state=sbs)
+
+
+def _bptt_worker(rank, world, port, tmpdir, peer_exchange):
+    """Two ranks on the one GPU.  peer_exchange: gradients and normaliser sums go through the peer-memory exchange and the train step
+    IS captured (BPTT as SAC / PPO); otherwise the library collective — gloo here, host code — issued eagerly, never
+    captured.  Either way the replicas stay bit-identical and the normaliser counts both ranks' transitions."""
     _setup_paths()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not peer_exchange:
+        os.environ["MBPO_P2P_ALLREDUCE"] = "0"
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from mbpo.optimizers import BPTTOptimizer
-        from mbpo.replay import UniformSamplingQueue
-        from mbpo.systems import PendulumSystem
-        from mbpo.types import Transition
-        system = PendulumSystem()
-        s0 = system.reset()
-        dummy = Transition(observation=s0.x_next, action=torch.zeros(1, device=dev), reward=s0.reward, discount=torch.tensor(0.99, device=dev),
-                           next_observation=s0.x_next)
-        q = UniformSamplingQueue(64, dummy, 1, device=dev)
-        g = torch.Generator().manual_seed(0)
-        th = (torch.rand(32, generator=g) * 2 - 1) * 3.14159
-        obs = torch.stack([torch.cos(th), torch.sin(th), torch.zeros(32)], 1).to(dev)
-        sbs = q.insert(q.init(0), Transition(observation=obs, action=torch.zeros(32, 1, device=dev), reward=torch.zeros(32, device=dev),
-                                             discount=torch.ones(32, device=dev), next_observation=obs))
-        opt = BPTTOptimizer(obs_dim=3, action_dim=1, horizon=6, num_samples_per_gradient_update=16, train_steps=5, sampling_buffer_size=4096,
-                            process_group=dist.group.WORLD)
-        opt.set_system(system)
-        st = opt.init(key=100 + rank, true_buffer_state=sbs)        # different keys: the broadcast must make the nets identical
+        opt, st = _bptt_setup(dev, dist.group.WORLD, 100 + rank)     # different keys: the broadcast must make the nets identical
+        assert (opt.p2p is not None) == peer_exchange and opt._capturable() == peer_exchange
         out = opt.train(bptt_state=st)
+        assert opt._last_train_captured == peer_exchange
         o = out.optimizer_state
         for t in (o.actor_params, o.critic_params, o.target_critic_params, o.state_normalizer_state.vec):
             assert bool(torch.isfinite(t).all())
@@ -235,7 +247,33 @@ def _bptt_worker(rank, world, port, tmpdir):
             dist.all_gather(ts, t)
             assert all(torch.equal(ts[0], x) for x in ts)            # replicas stay bit-identical
         assert float(o.state_normalizer_state.size) == 5 * 16 * 6 * world
+        opt.close()
         (Path(tmpdir) / f"bptt_ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def _bptt_nccl_capture_worker(rank, world, port, tmpdir):
+    """1-rank RCCL group: the BPTT train step holds torch.distributed (RCCL) all-reduces and IS captured; the result equals the
+    group-less optimizer bit for bit (a 1-rank SUM is the identity)."""
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        opt, st = _bptt_setup(dev, dist.group.WORLD, 100)
+        assert opt.p2p is None and opt._all_reduce is not None and opt._capturable()
+        o = opt.train(bptt_state=st).optimizer_state
+        assert opt._last_train_captured
+        ref, st_ref = _bptt_setup(dev, None, 100)
+        r = ref.train(bptt_state=st_ref).optimizer_state
+        assert ref._last_train_captured
+        for name in ("actor_params", "critic_params", "target_critic_params"):
+            assert torch.equal(getattr(o, name), getattr(r, name)), name
+        assert torch.equal(o.state_normalizer_state.vec, r.state_normalizer_state.vec)
+        (Path(tmpdir) / "bptt_nccl_ok").write_text("ok")
     finally:
         dist.destroy_process_group()
 
@@ -254,13 +292,24 @@ def test_sac_wide_critics_over_peer_memory_two_ranks(tmp_path):
     assert all((tmp_path / f"p2psac_ok{r}").exists() for r in range(world))
 
 
-@pytest.mark.timeout(180)
-def test_bptt_data_parallel_two_ranks(tmp_path):
-    """BPTTOptimizer with a process group: gradients and normaliser sums are reduced, replicas stay bit-identical."""
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("peer_exchange", [True, False])
+def test_bptt_data_parallel_two_ranks(tmp_path, peer_exchange):
+    """BPTTOptimizer with a process group (bptt_optimizer.py:355-437 data-parallel): gradients and normaliser sums are reduced over the
+    ranks — through the peer-memory exchange inside a captured train step, or through the library collective issued eagerly — and the
+    replicas stay bit-identical."""
     world = 2
-    port = 37500 + (os.getpid() % 2000)
-    mp.spawn(_bptt_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    port = 37500 + (os.getpid() % 2000) + (11 if peer_exchange else 0)
+    mp.spawn(_bptt_worker, args=(world, port, str(tmp_path), peer_exchange), nprocs=world, join=True)
     assert all((tmp_path / f"bptt_ok{r}").exists() for r in range(world))
+
+
+@pytest.mark.timeout(300)
+def test_bptt_train_step_captured_with_rccl_collectives(tmp_path):
+    """BPTT under an RCCL group captures its train step like SAC (tests above): 1-rank nccl captured == group-less, bit for bit."""
+    port = 38500 + (os.getpid() % 2000)
+    mp.spawn(_bptt_nccl_capture_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "bptt_nccl_ok").exists()
 
 
 # ------------------------------------------------------------------------------------------------ trainer under a process group
