@@ -443,6 +443,16 @@ int64_t mbpo_mlp_vjp_workspace_floats(const mbpo_mlp_desc *mlp, int64_t n);
 int mbpo_mlp_vjp(const mbpo_mlp_desc *mlp, const float *x, int64_t n, const float *norm_mean, const float *norm_std,
                  const float *dy, float *y, float *dx, float *dw, float *workspace, void *stream);
 
+/* The same contract for ANY hidden sizes (bptt_optimizer.py:183-186 `actor_features` / `critic_features` accept any tuple; the fused
+ * kernel above is built for 64-wide hidden layers): one fp32-MFMA GEMM launch per Dense layer over all n rows (csrc/layered.hip),
+ * forward recomputed with its pre-activations kept in `workspace`, then input and weight gradients layer by layer.
+ *   x: [n][dims[0]], ALREADY normalised (shared by the nets);  dy: [n_nets][n][dims[n_layers]] or NULL (forward only -> y);
+ *   y (optional with dy): [n_nets][n][dims[n_layers]];  dx (optional): [n_nets][n][dims[0]] with respect to the x given;
+ *   dw (optional): [n_nets][params per net].  workspace >= mbpo_mlp_layered_workspace_floats(mlp, n) floats.  Fixed-order sums. */
+int64_t mbpo_mlp_layered_workspace_floats(const mbpo_mlp_desc *mlp, int64_t n);
+int mbpo_mlp_layered_vjp(const mbpo_mlp_desc *mlp, const float *x, int64_t n, const float *dy, float *y, float *dx, float *dw,
+                         float *workspace, void *stream);
+
 /* ---- generic optimizer step: [optax.apply_if_finite(] optax.adamw(lr, wd) [)] + optional Polyak target ----------------
  * replaces: actor_optimizer.update/apply_updates (bptt_optimizer.py:218-225, 374-378), critic_optimizer + soft_update
  *           (:406-410; utils/optimizer_utils.py:155-161).

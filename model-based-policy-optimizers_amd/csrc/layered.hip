@@ -277,3 +277,72 @@ int layered_backward(const LayeredNet &n, const float *x, long long zx, int rows
   }
   return MBPO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ C-ABI: any-shape MLP forward / VJP
+// The network halves of an autograd graph for shapes the fused wave-chain kernels are not built for (mbpo_mlp_vjp: hidden width 64
+// only): BPTT through actor (128, 128) / critic (256, 256) networks (bptt_optimizer.py:183-186 accepts any feature tuple).
+struct MlpLayeredPlan {
+  MlpDev m;
+  LayeredNet net;
+  long long off_z[MBPO_MAX_LAYERS + 1], off_h[MBPO_MAX_LAYERS + 1], off_tmp0, off_tmp1, off_part, off_y, total;
+};
+
+static int mlp_layered_plan(const mbpo_mlp_desc *mlp, int64_t n, MlpLayeredPlan *pl) {
+  MBPO_REQUIRE(mlp, MBPO_ERR_ARG, "mlp_layered: null descriptor");
+  MBPO_REQUIRE(n >= 1 && n < (1LL << 24), MBPO_ERR_ARG, "mlp_layered: n must be in [1, 2^24)");
+  mbpo_mlp_desc d = *mlp;
+  if (!d.params) d.params = (const float *)16;      // size queries
+  int rc = mbpo_make_mlp_dev(&d, &pl->m, "mlp_layered");
+  if (rc != MBPO_OK) return rc;
+  MBPO_REQUIRE(pl->m.n_layers >= 2, MBPO_ERR_UNSUPPORTED, "mlp_layered: the network needs at least one hidden layer");
+  pl->net = layered_net(pl->m, mlp->params, mlp->n_nets > 1 ? mlp->net_stride : pl->m.n_params, mlp->n_nets);
+  const long long nz = mlp->n_nets;
+  long long off = 0;
+  for (int l = 1; l < pl->m.n_layers; ++l) {
+    pl->off_z[l] = off; off += nz * n * pl->m.dims[l];
+    pl->off_h[l] = off; off += nz * n * pl->m.dims[l];
+  }
+  const long long mh = layered_max_hidden(pl->net);
+  pl->off_tmp0 = off; off += nz * n * mh;
+  pl->off_tmp1 = off; off += nz * n * mh;
+  pl->off_y = off; off += nz * n * pl->m.dims[pl->m.n_layers];
+  pl->off_part = off; off += layered_part_floats(pl->net, (int)n);
+  pl->total = off;
+  return MBPO_OK;
+}
+
+extern "C" int64_t mbpo_mlp_layered_workspace_floats(const mbpo_mlp_desc *mlp, int64_t n) {
+  MlpLayeredPlan pl;
+  int rc = mlp_layered_plan(mlp, n, &pl);
+  if (rc != MBPO_OK) return rc;
+  return pl.total;
+}
+
+extern "C" int mbpo_mlp_layered_vjp(const mbpo_mlp_desc *mlp, const float *x, int64_t n, const float *dy, float *y, float *dx, float *dw,
+                                    float *workspace, void *stream) {
+  MlpLayeredPlan pl;
+  int rc = mlp_layered_plan(mlp, n, &pl);
+  if (rc != MBPO_OK) return rc;
+  MBPO_REQUIRE(mlp->params && x && workspace, MBPO_ERR_ARG, "mlp_layered_vjp: null params / x / workspace");
+  MBPO_REQUIRE(y || dy, MBPO_ERR_ARG, "mlp_layered_vjp: nothing to compute (neither y nor dy given)");
+  MBPO_REQUIRE(!dy || dx || dw, MBPO_ERR_ARG, "mlp_layered_vjp: dy given but neither dx nor dw requested");
+  MBPO_REQUIRE(mlp->n_nets == 1 || mlp->net_stride == pl.m.n_params || !dw, MBPO_ERR_UNSUPPORTED,
+               "mlp_layered_vjp: dw is laid out [net][params]: net_stride must equal the parameters per net (%d)", pl.m.n_params);
+  hipStream_t st = (hipStream_t)stream;
+  float *Z[MBPO_MAX_LAYERS + 1], *H[MBPO_MAX_LAYERS + 1];
+  for (int l = 0; l <= MBPO_MAX_LAYERS; ++l) Z[l] = H[l] = nullptr;
+  for (int l = 1; l < pl.m.n_layers; ++l) {
+    Z[l] = dy ? workspace + pl.off_z[l] : nullptr;      // pre-activations are only needed by the backward pass
+    H[l] = workspace + pl.off_h[l];
+  }
+  float *yy = y ? y : workspace + pl.off_y;
+  rc = layered_forward(pl.net, x, 0, (int)n, Z, H, yy, st);
+  if (rc != MBPO_OK) return rc;
+  if (dy) {
+    rc = layered_backward(pl.net, x, 0, (int)n, Z, H, dy, dw, pl.m.n_params, dx, workspace + pl.off_tmp0, workspace + pl.off_tmp1,
+                          workspace + pl.off_part, st);
+    if (rc != MBPO_OK) return rc;
+  }
+  MBPO_CHECK_LAUNCH("mlp_layered_vjp");
+  return MBPO_OK;
+}

@@ -242,6 +242,10 @@ def _bind_optional(lib: C.CDLL) -> None:
     lib.mbpo_mlp_vjp_workspace_floats.argtypes = [C.POINTER(MlpDesc), i64]
     lib.mbpo_mlp_vjp.restype = C.c_int
     lib.mbpo_mlp_vjp.argtypes = [C.POINTER(MlpDesc), vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mbpo_mlp_layered_workspace_floats.restype = C.c_int64
+    lib.mbpo_mlp_layered_workspace_floats.argtypes = [C.POINTER(MlpDesc), i64]
+    lib.mbpo_mlp_layered_vjp.restype = C.c_int
+    lib.mbpo_mlp_layered_vjp.argtypes = [C.POINTER(MlpDesc), vp, i64, vp, vp, vp, vp, vp, vp]
     lib.mbpo_episode_step.restype = C.c_int
     lib.mbpo_episode_step.argtypes = [C.POINTER(EpisodeStepDesc), vp]
     lib.mbpo_running_stats_workspace_floats.restype = C.c_int64

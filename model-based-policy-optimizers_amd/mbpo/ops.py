@@ -37,8 +37,35 @@ class MlpSpec:
         return mlp_desc(params, self.dims, self.activation, self.n_nets)
 
 
+def _uniform_hidden(spec: MlpSpec) -> Optional[int]:
+    hid = [int(v) for v in spec.dims[1:-1]]
+    return hid[0] if hid and all(h == hid[0] for h in hid) else None
+
+
+def mlp_layered(params: torch.Tensor, spec: MlpSpec, xn: torch.Tensor, dy: Optional[torch.Tensor] = None, want_dx: bool = False,
+                want_dw: bool = False, want_y: bool = True):
+    """mbpo_mlp_layered_vjp: forward (and vector-Jacobian products) of an MLP of ANY hidden sizes, one fp32-MFMA GEMM launch per Dense
+    layer (csrc/layered.hip) — what ensemble_mlp_forward / mlp_vjp fall back to outside the fused kernels' shapes.  xn [n, in] is
+    the (already normalised) input shared by the nets.  Returns (dx wrt xn | None, dw | None, y | None)."""
+    lib = load()
+    _req(xn, "x")
+    n, din, dout = xn.shape[0], spec.dims[0], spec.dims[-1]
+    d = spec.desc(params)
+    need = int(lib.mbpo_mlp_layered_workspace_floats(C.byref(d), n))
+    if need < 0:
+        check(need, "mbpo_mlp_layered_workspace_floats")
+    ws = torch.empty(max(need, 1), device=xn.device, dtype=torch.float32)
+    y = torch.empty((spec.n_nets, n, dout), device=xn.device, dtype=torch.float32) if want_y else None
+    dx = torch.empty((spec.n_nets, n, din), device=xn.device, dtype=torch.float32) if (dy is not None and want_dx) else None
+    dw = torch.empty(spec.n_nets * spec.n_params, device=xn.device, dtype=torch.float32) if (dy is not None and want_dw) else None
+    check(lib.mbpo_mlp_layered_vjp(C.byref(d), xn.data_ptr(), n, ptr(dy), ptr(y), ptr(dx), ptr(dw), ws.data_ptr(), current_stream_ptr()),
+          "mbpo_mlp_layered_vjp")
+    return dx, dw, y
+
+
 def ensemble_mlp_forward(params: torch.Tensor, spec: MlpSpec, x: torch.Tensor, shared_input: bool = True) -> torch.Tensor:
-    """y[e, n, :] = MLP_e(x[n]) — R2 of SURVEY §8a."""
+    """y[e, n, :] = MLP_e(x[n]) — R2 of SURVEY §8a.  Hidden layers of one width in {64, 128, 256}: the fused wave-chain kernel;
+    any other sizes (shared input): layer by layer (mlp_layered)."""
     lib = load()
     _req(x, "x")
     d = spec.desc(params)
@@ -47,6 +74,8 @@ def ensemble_mlp_forward(params: torch.Tensor, spec: MlpSpec, x: torch.Tensor, s
         if x.dim() != 2 or x.shape[1] != din:
             raise ValueError(f"x must be [N,{din}], got {tuple(x.shape)}")
         n = x.shape[0]
+        if _uniform_hidden(spec) not in ROLLOUT_WIDTHS and len(spec.dims) > 2:
+            return mlp_layered(params, spec, x.contiguous())[2]
     else:
         if x.dim() != 3 or x.shape[0] != spec.n_nets or x.shape[2] != din:
             raise ValueError(f"x must be [{spec.n_nets},N,{din}], got {tuple(x.shape)}")
@@ -60,7 +89,9 @@ def ensemble_mlp_forward(params: torch.Tensor, spec: MlpSpec, x: torch.Tensor, s
 def mlp_vjp(params: torch.Tensor, spec: MlpSpec, x: torch.Tensor, dy: torch.Tensor, norm_mean=None, norm_std=None,
             want_dx: bool = True, want_dw: bool = True, want_y: bool = False, workspace: Optional[torch.Tensor] = None):
     """mbpo_mlp_vjp: for the spec's 1 or 2 nets on the shared input x [n, in] with upstream gradients dy [n_nets, n, out]:
-    (dx [n_nets, n, in] | None, dw [n_nets * n_params] | None, y [n_nets, n, out] | None)."""
+    (dx [n_nets, n, in] | None, dw [n_nets * n_params] | None, y [n_nets, n, out] | None).  64-wide hidden layers with input /
+    output widths <= 32 and one or two nets: the fused kernel; any other shape (or an ensemble of more nets): layer by layer
+    (mbpo_mlp_layered_vjp)."""
     lib = load()
     _req(x, "x"); _req(dy, "dy")
     din, dout = spec.dims[0], spec.dims[-1]
@@ -69,6 +100,12 @@ def mlp_vjp(params: torch.Tensor, spec: MlpSpec, x: torch.Tensor, dy: torch.Tens
         raise ValueError(f"x must be [n,{din}], got {tuple(x.shape)}")
     if tuple(dy.shape) != (spec.n_nets, n, dout):
         raise ValueError(f"dy must be [{spec.n_nets},{n},{dout}], got {tuple(dy.shape)}")
+    if len(spec.dims) > 2 and (_uniform_hidden(spec) != 64 or din > 32 or dout > 32 or spec.n_nets > 2):
+        xn = x if norm_mean is None else ((x - norm_mean) / norm_std)
+        dx, dw, y = mlp_layered(params, spec, xn.contiguous(), dy.contiguous(), want_dx=want_dx, want_dw=want_dw, want_y=want_y)
+        if dx is not None and norm_mean is not None:
+            dx = dx / norm_std               # d/dx of (x - mean) / std
+        return dx, dw, y
     d = spec.desc(params)
     dx = torch.empty((spec.n_nets, n, din), device=x.device, dtype=torch.float32) if want_dx else None
     dw = torch.empty(spec.n_nets * spec.n_params, device=x.device, dtype=torch.float32) if want_dw else None
@@ -1046,6 +1083,33 @@ class CriticGrad:
                                          self.batch, state_mean.data_ptr(), state_std.data_ptr(), self.grads.data_ptr(),
                                          self.metrics.data_ptr(), self.workspace.data_ptr(), current_stream_ptr()),
               "mbpo_critic_grads")
+        return self.grads
+
+
+class CriticGradGeneric:
+    """CriticGrad's contract (grads [2C], metrics [1]) for ANY critic hidden sizes: the twin-V regression of bptt_optimizer.py:385-404
+    — critic_loss_fn = 0.5 * (mean l2(v1, lambda) + mean l2(v2, lambda)), l2 = 0.5 (.)^2 — with the two networks as HIP autograd
+    nodes (HipMlp: forward and vector-Jacobian products layer by layer, csrc/layered.hip) and the loss head in torch."""
+
+    def __init__(self, *, x_dim: int, critic_dims: Sequence[int], batch: int, device, activation: str = "swish"):
+        self.x_dim, self.batch, self.device = x_dim, int(batch), torch.device(device)
+        self.spec = MlpSpec(list(critic_dims), activation, 2)
+        self.C = self.spec.n_params
+        self.grads = torch.zeros(2 * self.C, device=self.device, dtype=torch.float32)
+        self.metrics = torch.zeros(1, device=self.device, dtype=torch.float32)
+
+    def __call__(self, critic_params, transitions, lambda_values, idx, state_mean, state_std) -> torch.Tensor:
+        if idx.numel() != self.batch:
+            raise ValueError(f"idx must have {self.batch} entries")
+        rows = idx.long()
+        obs = transitions[rows, :self.x_dim].contiguous()
+        lam = lambda_values[rows]
+        p = critic_params.detach().clone().requires_grad_(True)
+        v = HipMlp.apply(p, obs, self.spec, state_mean.detach().contiguous(), state_std.detach().contiguous())      # [2, B, 1]
+        loss = 0.5 * ((0.5 * (v[0, :, 0] - lam) ** 2).mean() + (0.5 * (v[1, :, 0] - lam) ** 2).mean())
+        loss.backward()
+        self.grads.copy_(p.grad)
+        self.metrics[0] = loss.detach()
         return self.grads
 
 

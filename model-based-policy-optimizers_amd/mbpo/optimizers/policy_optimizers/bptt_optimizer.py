@@ -194,13 +194,24 @@ class BPTTOptimizer(BaseOptimizer):
         self.obs_dim, self.action_dim = int(obs_dim), int(action_dim)
         self.state_normalizer = Normalizer((self.obs_dim,))
         self.reward_normalizer = Normalizer((1,))
-        # logical shapes and kernel shapes: the BPTT kernels are built for 64-wide hidden layers; narrower ones are zero-padded
-        # (ops.py "hidden-width padding"), wider ones are refused (INTEGRATION.md "Network shapes")
+        # logical shapes and kernel shapes.  The fused BPTT kernels (k_bptt_actor, k_critic_fwd_bwd) are built for 64-wide hidden
+        # layers; narrower ones are zero-padded (ops.py "hidden-width padding").  WIDER networks (the reference takes any feature
+        # tuple, bptt_optimizer.py:183-186) train on the non-fused path: the horizon walked on the host with the networks as HIP
+        # autograd nodes — forward mbpo_ensemble_mlp_forward / mbpo_mlp_layered_vjp, vector-Jacobian products layer by layer
+        # (csrc/layered.hip) — and the built-in System's step in its differentiable torch form (systems/torch_steps.py).  The actor is
+        # padded to a rollout-kernel width (it also runs inside the evaluation rollout and `act`: <= 256); the critics keep any sizes.
         self.actor_dims_logical = [self.obs_dim, *[int(f) for f in actor_features], 2 * self.action_dim]
         self.critic_dims_logical = [self.obs_dim, *[int(f) for f in critic_features], 1]
-        self.kernel_width = ops.common_width(actor_features, critic_features, supported=(64,), what="BPTT")
-        self.actor_dims = ops.padded_dims(self.actor_dims_logical, self.kernel_width)
-        self.critic_dims = ops.padded_dims(self.critic_dims_logical, self.kernel_width)
+        self.wide = max([int(f) for f in (*actor_features, *critic_features)], default=0) > 64
+        if self.wide:
+            self.actor_width = ops.common_width(actor_features, supported=ops.ROLLOUT_WIDTHS, what="BPTT actor")
+            cmax = max([int(f) for f in critic_features], default=0)
+            self.critic_width = ops.common_width(critic_features, supported=ops.ROLLOUT_WIDTHS) if cmax <= 256 else None
+        else:
+            self.actor_width = self.critic_width = ops.common_width(actor_features, critic_features, supported=(64,), what="BPTT")
+        self.kernel_width = self.actor_width
+        self.actor_dims = ops.padded_dims(self.actor_dims_logical, self.actor_width)
+        self.critic_dims = ops.padded_dims(self.critic_dims_logical, self.critic_width)
         self.policy_activation, self.critic_activation = policy_activation, critic_activation
         self.actor_spec = ops.MlpSpec(self.actor_dims, policy_activation, 1)
         self.critic_spec = ops.MlpSpec(self.critic_dims, critic_activation, 2)
@@ -242,16 +253,16 @@ class BPTTOptimizer(BaseOptimizer):
         n, H, Kc = self.num_samples_per_gradient_update, self.horizon, self.critic_updates_per_policy_updates
         self.num_transitions = n * H
         self.critic_batch = math.ceil(self.num_transitions / Kc)
-        self._actor_grad = ops.BpttActorGrad(x_dim=X, u_dim=U, horizon=H, actor_dims=self.actor_dims, critic_dims=self.critic_dims,
-                                             n=n, device=dev, actor_activation=policy_activation,
-                                             critic_activation=critic_activation, init_stddev=self.init_stddev, discount=discount,
-                                             lambda_=lambda_, ent_coef=loss_ent_coefficient)
+        self._actor_grad = None if self.wide else ops.BpttActorGrad(
+            x_dim=X, u_dim=U, horizon=H, actor_dims=self.actor_dims, critic_dims=self.critic_dims, n=n, device=dev,
+            actor_activation=policy_activation, critic_activation=critic_activation, init_stddev=self.init_stddev, discount=discount,
+            lambda_=lambda_, ent_coef=loss_ent_coefficient)
         self._actor_grad_generic = ops.BpttActorGradGeneric(
             x_dim=X, u_dim=U, horizon=H, actor_dims=self.actor_dims, critic_dims=self.critic_dims, n=n, device=dev,
             actor_activation=policy_activation, critic_activation=critic_activation, init_stddev=self.init_stddev, discount=discount,
             lambda_=lambda_, ent_coef=loss_ent_coefficient)        # the same contract for a user-defined System (non-fused)
-        self._critic_grad = ops.CriticGrad(x_dim=X, critic_dims=self.critic_dims, batch=self.critic_batch, device=dev,
-                                           activation=critic_activation)
+        self._critic_grad = (ops.CriticGradGeneric if self.wide else ops.CriticGrad)(
+            x_dim=X, critic_dims=self.critic_dims, batch=self.critic_batch, device=dev, activation=critic_activation)
         self.P, self.C2 = self.actor_spec.n_params, 2 * self.critic_spec.n_params
         # Multi-GPU (as SAC / PPO): the actor and critic gradients and the normalisers' sums go through the one-shot
         # peer-memory exchange over xGMI (csrc/p2p.hpp) instead of a library collective — plain kernels, so the train step stays
@@ -285,11 +296,11 @@ class BPTTOptimizer(BaseOptimizer):
         critic_key, actor_key, system_key, key = K.split(key, 4)
         dev = self.device
         gen = torch.Generator().manual_seed(int(critic_key) % (2 ** 63))
-        emb = lambda flat, dims: ops.embed_mlp_params(flat, dims, self.kernel_width)
-        critic_params = torch.cat([emb(lecun_normal_flat(self.critic_dims_logical, gen), self.critic_dims_logical),
-                                   emb(lecun_normal_flat(self.critic_dims_logical, gen), self.critic_dims_logical)]).to(dev)
+        emb = lambda flat, dims, width: flat if width is None else ops.embed_mlp_params(flat, dims, width)
+        critic_params = torch.cat([emb(lecun_normal_flat(self.critic_dims_logical, gen), self.critic_dims_logical, self.critic_width),
+                                   emb(lecun_normal_flat(self.critic_dims_logical, gen), self.critic_dims_logical, self.critic_width)]).to(dev)
         gen = torch.Generator().manual_seed(int(actor_key) % (2 ** 63))
-        actor_params = emb(lecun_normal_flat(self.actor_dims_logical, gen), self.actor_dims_logical).to(dev)
+        actor_params = emb(lecun_normal_flat(self.actor_dims_logical, gen), self.actor_dims_logical, self.actor_width).to(dev)
         self.dp.broadcast(actor_params)
         self.dp.broadcast(critic_params)
         z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)
@@ -475,7 +486,7 @@ class BPTTOptimizer(BaseOptimizer):
         # a host-side (gloo) collective is never put inside a capture (_capturable).  Evaluation runs eagerly between replays.
         graph = None
         can_capture = self.use_graph and self._capturable() and self.train_steps >= 2 and not w.generic   # (generic: user code between the kernels)
-        n_rows = self._actor_grad.transitions.shape[0]
+        n_rows = self.num_transitions
         for i in range(self.train_steps):
             sampling_key, state_key = K.split(state_key, 2)
             critic_training_key, state_key = K.split(state_key, 2)
@@ -529,7 +540,11 @@ class _Work:
         self.state_norm = st.state_normalizer_state.clone()
         self.reward_norm = st.reward_normalizer_state.clone()
         self.rollout_spec, self.sys_kw = opt._system_kwargs(st.system_params)
-        self.generic = self.rollout_spec["system_kind"] == _hip.SYS_GENERIC
+        self.generic = self.rollout_spec["system_kind"] == _hip.SYS_GENERIC or opt.wide
+        if opt.wide and self.rollout_spec["system_kind"] != _hip.SYS_GENERIC:
+            # wider networks than the fused BPTT kernel takes: the built-in System as a node of the torch autograd graph
+            from mbpo.systems.torch_steps import DifferentiableBuiltin
+            self.sys_kw = dict(system=DifferentiableBuiltin(opt.system, self.rollout_spec), system_params=st.system_params)
         self.step_summary = torch.zeros(4, device=opt.device, dtype=torch.float32)
 
     def snapshot(self, opt: BPTTOptimizer, key: int) -> BPTTState:
