@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "chain_run.hpp"
 #include "ppo_layered.hpp"
+#include "ppo_lean.hpp"
 
 #define LOG_SQRT_2PI 0.91893853320467274178f
 #define LOG_2 0.69314718055994530942f
@@ -627,7 +628,17 @@ struct PpoPlan {
   // hidden layers outside the fused kernels' range (one width in {64,128}): values pre-pass and loss forward/backward run layer by
   // layer (ppo_layered.hip) and leave ONE slab; GAE scan, moments, reduction, metrics and AdamW are shared
   bool layered;
+  // the benchmark networks (64 x 3, swish, u = 1): k_ppo_lean (ppo_lean.hip) — one workgroup and ONE slab per CU
+  bool lean;
 };
+
+// Measurement / test hook (not part of include/mbpo_hip.h): 0 = always the generic k_ppo_fwd_bwd, 1 = k_ppo_lean where it applies,
+// -1 = the MBPO_PPO_LEAN environment default (on).
+static int g_ppo_lean = -1;
+extern "C" int mbpo_debug_set_ppo_lean(int mode) {
+  g_ppo_lean = mode;
+  return MBPO_OK;
+}
 
 static int ppo_same_hidden(const int *dims, int n_layers) {
   if (n_layers < 2) return -1;
@@ -698,11 +709,19 @@ static int ppo_plan(const mbpo_ppo_desc *d, PpoPlan *pl, bool need_ptrs) {
     pl->sp2 = (Hp == 64 && !net_is_wide(sp_) && !net_is_wide(sv_) && tiles > ppo_num_cus() && sp2_env != 0) ? 1 : 0;
   }
   long long cap = (pl->sp2 ? 2LL : 1LL) * ppo_num_cus();
+  {
+    static const int lean_env = getenv("MBPO_PPO_LEAN") ? atoi(getenv("MBPO_PPO_LEAN")) : 1;
+    pl->lean = (g_ppo_lean >= 0 ? g_ppo_lean : lean_env) != 0 && !pl->layered &&
+               ppo_lean_supports(d->x_dim, d->u_dim, d->policy_dims, d->policy_layers, d->policy_activation, d->value_dims, d->value_layers,
+                                 d->value_activation);
+    if (pl->lean) cap = ppo_num_cus();
+  }
   pl->n_slabs = (int)(tiles < cap ? tiles : cap);
   if (!pl->layered && (pl->lds_fb > 160 * 1024 || pl->lds_values > 160 * 1024)) pl->layered = true;     // more stored activations than a tile's LDS holds
   if (pl->layered) {
     pl->sp2 = 0;
     pl->n_slabs = 1;
+    pl->lean = false;
   }
   long long o = 0;
   auto take = [&](long long n) { long long at = o; o += (n + 3) & ~3LL; return at; };
@@ -826,6 +845,15 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
   int layered_n_extras = 0;
   if (pl.layered) {
     rc = ppo_layered_fwd_bwd(d, pl.pi, pl.v, ws + pl.off_layered, A.vs, A.adv, A.mom, A.slabs, &layered_extras, &layered_n_extras, st);
+    if (rc != MBPO_OK) return rc;
+  } else if (pl.lean) {
+    PpoLeanArgs L;
+    L.params = d->params; L.data = d->data; L.norm_mean = d->norm_mean; L.norm_std = d->norm_std;
+    L.adv = A.adv; L.vs = A.vs; L.mom = A.mom; L.ent_noise = d->entropy_noise;
+    L.rng_dev = A.rng_dev; L.seed = A.seed; L.offset = A.offset;
+    L.slabs = A.slabs; L.extras = A.extras; L.M = pl.M;
+    L.entropy_cost = d->entropy_cost; L.clip_eps = d->clipping_epsilon; L.normalize_advantage = d->normalize_advantage;
+    rc = ppo_lean_launch(L, d->x_dim, pl.n_slabs, stream);
     if (rc != MBPO_OK) return rc;
   } else if (pl.H == 64) {
     const bool wide = net_is_wide(A.sh_pi) || net_is_wide(A.sh_v);

@@ -1,0 +1,376 @@
+// ppo_lean.hip — k_ppo_lean<X>: PPOLoss.loss forward/backward (ppo/losses.py:56-126) for a minibatch of B x T rows, specialised for the
+// benchmark networks: policy X -> 64 -> 64 -> 64 -> 2, value X -> 64 -> 64 -> 64 -> 1, swish, u = 1 (BASELINE config 3).
+//
+// The generic k_ppo_fwd_bwd (ppo.hip) is a latency chain per 16-row tile on the shared runners: 128 VGPRs with 21-64 spilled, weight
+// images re-requested for every layer of every tile, weight gradients accumulated into the slab by global read-modify-write per tile,
+// two 512-thread workgroups per CU to overlap two tiles' chains — 66 us per launch at C3 (1280 tiles), 13.6 % of the fp32-MFMA roof.
+// Here (round 4, the blocks of csrc/lean_blocks.hpp as in k_sac_lean):
+//  * ONE 8-wave workgroup per CU with 256 VGPRs per wave walks its tiles; chain c = the network (0 policy, 1 value), 4 waves each.
+//  * Every weight image a wave needs — thin column, two hidden forward images, output image, two input-gradient images — is loaded ONCE
+//    per launch and stays in registers for all tiles (the generic kernel issues ~100 requests per wave and tile).
+//  * Weight gradients are summed over the workgroup's tiles IN REGISTERS (each tile's tile-sum formed in fresh accumulators and
+//    added: the order of the generic kernel's read-modify-write, without the traffic) and stored once at the end: no per-tile slab
+//    traffic, and one slab per CU instead of two (the two-stage slab sum reads half the bytes).
+//  * Stored derivative instead of pre-activation (swish'(z) written by the forward pass; the delta tiles overwrite them in place);
+//    all input gradients first, then the weight gradients of both hidden layers and both thin layers with no barrier between them.
+//  * The next tile's rows are requested one tile ahead; its entropy noise is drawn by an idle wave during the output-layer step.
+#include "common.hpp"
+#include "chain_run.hpp"
+#include "lean_blocks.hpp"
+#include "ppo_lean.hpp"
+
+namespace {
+
+#define LOG_SQRT_2PI 0.91893853320467274178f
+#define LOG_2 0.69314718055994530942f
+
+__device__ __forceinline__ float pl_fexp(float x) { return __builtin_amdgcn_exp2f(1.44269504088896340736f * x); }
+__device__ __forceinline__ float pl_flog(float x) { return 0.69314718055994530942f * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float pl_fsoftplus(float x) { return fmaxf(x, 0.0f) + pl_flog(1.0f + pl_fexp(-fabsf(x))); }
+__device__ __forceinline__ float pl_ftanh(float x) {
+  const float e = pl_fexp(2.0f * fminf(fmaxf(x, -15.0f), 15.0f));
+  return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+template <int X>
+struct PNet {
+  static constexpr int D = 2 * X + 6;                                     // obs, action, reward, discount, next_obs, log_prob, raw_action, truncation
+  static constexpr int W1 = X * LH + LH, OUT = W1 + 2 * HID;              // offsets inside a net: layer 1, output layer
+  static constexpr int P = OUT + LH * 2 + 2, V = OUT + LH + 1;
+};
+
+// LDS carve (floats)
+constexpr int P_X = 0;                 // [2][16][8]  normalised observations, double-buffered on the tile parity
+constexpr int P_AUX = 256;             // [2][16][4]  raw_action, behaviour log-prob, advantage, value target
+constexpr int P_EPS = 384;             // [2][16]     entropy-sample noise
+constexpr int P_DY = 416;              // [2][16][4]  output gradients: policy (d/dloc, d/draw), value (d/dV)
+constexpr int P_LOSS = 544;            // [3][16]     loss partials at the end
+constexpr int P_TILES = 592;           // 12 tiles: net c at + 6 c: d0 d1 d2 (swish'(z), then the deltas in place) | h0 h1 h2
+constexpr size_t PPO_LEAN_LDS_BYTES = (size_t)(P_TILES + 12 * LT) * sizeof(float);
+
+// weight gradient of a hidden layer for this wave's 16 columns, tile sum in fresh accumulators (hid_wgrad of lean_blocks.hpp without
+// the store): acc[a] lane (j, g) reg i = dW[4 j + a][c0 + 4 g + i], accb lane (0, g) reg i = db[c0 + 4 g + i]
+__device__ __forceinline__ void hid_wgrad_regs(const float *hin, const float *delta, int c0, int lane, f32x4 (&acc)[4], f32x4 &accb) {
+  const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float hv[4][4], dv[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int row = 4 * g + s;
+    load_vec_lds<4>(hin + row * LDH + 4 * r, hv[s]);
+    dv[s] = delta[row * LDH + c0 + r];
+  }
+  const float one0 = (r == 0) ? 1.f : 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = MFMA(dv[s], hv[s][a], acc[a]);
+    accb = MFMA(dv[s], one0, accb);
+  }
+}
+
+}  // namespace
+
+template <int X>
+__global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  using N = PNet<X>;
+  constexpr int D = N::D;
+  static_assert(16 * D + 32 <= 512 && X <= LDX, "tile rows + advantage / target lanes must fit the workgroup");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = wave >> 2, sub = wave & 3, c0 = sub * 16;        // chain c = network: 0 policy, 1 value
+  const long long M = A.M;
+  const long long n_tiles = (M + 15) >> 4;
+  const float invM = 1.0f / (float)M;
+  const float *const net_p = A.params + (c ? N::P : 0);
+  float *const tiles = smem + P_TILES + c * 6 * LT;
+#define PT(n) (tiles + (n) * LT)      /* 0..2: stored derivatives / deltas of layers 0..2, 3..5: activations h0..h2 */
+
+  // ---- every weight image this wave will use, once per launch ----
+  float tw[X + 1];
+  ImgF I1, I2;
+  float wo[16];
+  float bo0 = 0.f, bo1 = 0.f;
+  float two[2] = {0.f, 0.f};
+  float G2[16], G1[16];
+  thin_col_request<X>(tw, net_p, lane);
+  img_fwd_request(I1, net_p + N::W1, c0, lane);
+  img_fwd_request(I2, net_p + N::W1 + HID, c0, lane);
+  const bool out_wave = sub == c;                                 // wave 0 (policy) and wave 5 (value): different SIMDs
+  if (out_wave) {
+    if (c == 0) {
+      img_out_request<2>(wo, net_p + N::OUT, lane);
+      bo0 = net_p[N::OUT + LH * 2];
+      bo1 = net_p[N::OUT + LH * 2 + 1];
+    } else {
+      img_out_request<1>(wo, net_p + N::OUT, lane);
+      bo0 = net_p[N::OUT + LH];
+    }
+  }
+  if (c == 0) {
+    two[0] = net_p[N::OUT + lane * 2];
+    two[1] = net_p[N::OUT + lane * 2 + 1];
+  } else {
+    two[0] = net_p[N::OUT + lane];
+  }
+  img_dgrad_request(G2, net_p + N::W1 + HID, c0, lane);
+  img_dgrad_request(G1, net_p + N::W1, c0, lane);
+
+  // ---- per-thread role in the tile load: one dword of the tile's 16 x D block, or an advantage / value-target element ----
+  const bool has_elem = tid < 16 * D;
+  const int r_t = tid / D, cc_t = tid - r_t * D;
+  const bool is_obs = has_elem && cc_t < X;
+  const bool is_adv = tid >= 16 * D && tid < 16 * D + 16, is_vs = tid >= 16 * D + 16 && tid < 16 * D + 32;
+  float mu_t = 0.f, sd_t = 1.f;
+  if (is_obs && A.norm_mean) {
+    mu_t = A.norm_mean[cc_t];
+    sd_t = A.norm_std[cc_t];
+  }
+  const float adv_mean = A.normalize_advantage ? A.mom[0] : 0.f;
+  const float adv_istd = A.normalize_advantage ? 1.0f / (A.mom[1] + 1e-8f) : 1.f;          // losses.py:101-102
+  const RngKey rk = rng_resolve(A.seed, A.offset, A.rng_dev);
+  auto tile_request = [&](long long tile) __attribute__((always_inline)) -> float {
+    const long long r0 = tile * 16;
+    float v = 0.f;
+    if (tile < n_tiles) {
+      if (has_elem) {
+        const long long nvalid = (M - r0 < 16 ? M - r0 : 16) * D;
+        if (tid < nvalid) v = A.data[r0 * D + tid];
+      } else if (is_adv || is_vs) {
+        const long long i = r0 + (tid & 15);
+        if (i < M) v = is_adv ? A.adv[i] : A.vs[i];
+      }
+    }
+    return v;
+  };
+  auto draw_noise = [&](long long tile, int par) __attribute__((always_inline)) {
+    if (lane < 16 && tile < n_tiles) {
+      const long long i = tile * 16 + lane;
+      float e = 0.f;
+      if (i < M) e = A.ent_noise ? A.ent_noise[i] : philox_normal(rk.seed, rk.offset, MBPO_STREAM_ENTROPY, (unsigned long long)i);
+      smem[P_EPS + 16 * par + lane] = e;
+    }
+  };
+
+  // ---- running sums over this workgroup's tiles (registers) ----
+  f32x4 S2[4], S2b, S1[4], S1b;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) S2[a] = S1[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  S2b = S1b = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float s_first0 = 0.f, s_first1 = 0.f;         // layer 0: jobs `sub` and `sub + 4` of X rows + the bias (column = lane)
+  float s_last = 0.f, s_lastb = 0.f;            // output layer: dWout[lane][sub] (sub < outputs), db[lane] (wave sub 0)
+  float loss_a = 0.f, loss_b = 0.f;             // out waves, lanes 0..15: policy: surrogate, entropy; value: squared error
+  bool first = true;
+
+  float v_next = tile_request(blockIdx.x);
+  if (wave == 7) draw_noise(blockIdx.x, 0);
+  int par = 0;
+#pragma nounroll
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
+    const long long r0 = tile * 16;
+    float *const s_x = smem + P_X + 128 * par, *const s_aux = smem + P_AUX + 64 * par, *const s_dy = smem + P_DY + 64 * c;
+    // ---- the tile's rows (requested one tile ago) to LDS; the next tile's are requested now ----
+    {
+      const float v = v_next;
+      if (is_obs) s_x[r_t * LDX + cc_t] = A.norm_mean ? (v - mu_t) / sd_t : v;
+      else if (has_elem && cc_t == 2 * X + 4) s_aux[r_t * 4 + 0] = v;              // raw_action
+      else if (has_elem && cc_t == 2 * X + 3) s_aux[r_t * 4 + 1] = v;              // behaviour log-prob (policy_extras.log_prob)
+      else if (is_adv) s_aux[(tid & 15) * 4 + 2] = v;
+      else if (is_vs) s_aux[(tid & 15) * 4 + 3] = v;
+      v_next = tile_request(tile + gridDim.x);
+    }
+    __syncthreads();
+    // ---- forward: policy logits (:80) and value baseline (:82); swish'(z) stored for the backward pass ----
+    thin_first<X, true, false>(tw, s_x, PT(3), PT(0), nullptr, sub, lane);
+    __syncthreads();
+    hid_fwd<true>(I1, PT(3), PT(4), PT(1), c0, lane);
+    __syncthreads();
+    hid_fwd<true>(I2, PT(4), PT(5), PT(2), c0, lane);
+    __syncthreads();
+    // ---- output layers and the loss terms on the waves that hold them (:84-126) ----
+    if (out_wave) {
+      const f32x4 y = out_fwd(wo, PT(5), lane);
+      const int r = lane & 15;
+      const bool ok = r0 + r < M;
+      if (c == 0) {
+        const float loc = y[0] + bo0, raw = y[1] + bo1;
+        const float z = s_aux[r * 4 + 0], lp_b = s_aux[r * 4 + 1];
+        const float eps = smem[P_EPS + 16 * par + r];
+        const float adv = ok ? (s_aux[r * 4 + 2] - adv_mean) * adv_istd : 0.f;
+        const float sg = pl_fsoftplus(raw) + 0.001f;
+        const float q = (z - loc) / sg;
+        const float lsg = pl_flog(sg);
+        const float lpt = -0.5f * q * q - lsg - LOG_SQRT_2PI - 2.0f * (LOG_2 - z - pl_fsoftplus(-2.0f * z));      // log_prob (:91-92)
+        const float zf = loc + sg * eps;
+        const float ent_d = 0.5f + LOG_SQRT_2PI + lsg + 2.0f * (LOG_2 - zf - pl_fsoftplus(-2.0f * zf));          // entropy (:117)
+        float lp_t = 0.f, ent = 0.f;
+        lp_t += lpt;
+        ent += ent_d;
+        const float rho = pl_fexp(lp_t - lp_b);                                                                   // :103
+        const float lo = 1.f - A.clip_eps, hi = 1.f + A.clip_eps;
+        const float s1 = rho * adv, s2 = fminf(fmaxf(rho, lo), hi) * adv;
+        const bool inside = (rho >= lo) && (rho <= hi);
+        const float w = inside ? 1.f : (s1 < s2 ? 1.f : 0.f);
+        const float g_lp = ok ? -invM * rho * adv * w : 0.f;
+        const float g_ent = ok ? -A.entropy_cost * invM : 0.f;
+        const float th = pl_ftanh(loc + sg * eps);
+        const float g_loc = g_lp * (q / sg) + g_ent * (-2.f * th);
+        const float g_sig = g_lp * ((q * q - 1.f) / sg) + g_ent * (1.f / sg - 2.f * th * eps);
+        if (lane < 16) {
+          if (ok) {
+            loss_a += -fminf(s1, s2);
+            loss_b += ent;
+          }
+          s_dy[r * 4 + 0] = g_loc;
+          s_dy[r * 4 + 1] = g_sig * fast_sigmoid(raw);
+        }
+      } else {
+        const float v = y[0] + bo0;
+        const float vs = ok ? s_aux[r * 4 + 3] : 0.f;
+        if (lane < 16) {
+          if (ok) loss_a += 0.5f * (vs - v) * (vs - v);
+          s_dy[r * 4 + 0] = ok ? -(vs - v) * invM : 0.f;            // d (0.5 * mean((vs - V)^2)) / dV   (:112-114)
+        }
+      }
+    } else if (wave == 7) {
+      draw_noise(tile + gridDim.x, par ^ 1);        // the next tile's entropy noise, on a wave that has nothing to do in this step
+    }
+    __syncthreads();
+    // ---- backward, input gradients first: delta_2, delta_1, delta_0 overwrite the stored derivatives in place ----
+    {
+      float zq[4];
+      thin_z_preload(zq, PT(2), sub, lane);
+      if (c == 0) thin_dgrad_last<2>(two, s_dy, zq, PT(2), sub, lane);
+      else thin_dgrad_last<1>(*reinterpret_cast<float(*)[1]>(&two[0]), s_dy, zq, PT(2), sub, lane);
+    }
+    __syncthreads();
+    hid_dgrad(G2, PT(2), PT(1), PT(1), c0, lane);
+    __syncthreads();
+    hid_dgrad(G1, PT(1), PT(0), PT(0), c0, lane);
+    __syncthreads();
+    // ---- weight gradients of the four layers: nothing depends on them inside the tile, no barrier between them ----
+    {
+      f32x4 acc[4], accb;
+      hid_wgrad_regs(PT(4), PT(2), c0, lane, acc, accb);          // dW2 = h1^T delta_2
+#pragma unroll
+      for (int a = 0; a < 4; ++a) S2[a] = first ? acc[a] : S2[a] + acc[a];
+      S2b = first ? accb : S2b + accb;
+      hid_wgrad_regs(PT(3), PT(1), c0, lane, acc, accb);          // dW1 = h0^T delta_1
+#pragma unroll
+      for (int a = 0; a < 4; ++a) S1[a] = first ? acc[a] : S1[a] + acc[a];
+      S1b = first ? accb : S1b + accb;
+    }
+    {
+      // layer 0: dW0[k][col] = sum_r x[r][k] delta_0[r][col] for k = sub (and k = sub + 4: a row or, at k = X, the bias)
+      float dv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dv[r] = PT(0)[r * LDH + lane];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int k = sub + 4 * jj;
+        if (k <= X) {
+          float acc = 0.f;
+          if (k < X) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc = fmaf(s_x[r * LDX + k], dv[r], acc);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc += dv[r];
+          }
+          if (jj == 0) s_first0 = first ? acc : s_first0 + acc;
+          else s_first1 = first ? acc : s_first1 + acc;
+        }
+      }
+      // output layer: dWout[col][o] = sum_r h2[r][col] dY[r][o] on wave sub = o; db[o] on wave sub 0, lane o
+      const int NO = c == 0 ? 2 : 1;
+      if (sub < NO) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc = fmaf(PT(5)[r * LDH + lane], s_dy[r * 4 + sub], acc);
+        s_last = first ? acc : s_last + acc;
+      }
+      if (sub == 0 && lane < NO) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += s_dy[r * 4 + lane];
+        s_lastb = first ? acc : s_lastb + acc;
+      }
+    }
+    first = false;
+    // (no barrier here: the next tile's rows go to the other parity of s_x / s_aux, and nobody overwrites this tile's tiles before
+    //  the barrier behind that store, which every wave reaches only after its weight gradients)
+  }
+
+  // ---- this workgroup's slab [policy | value] and loss partials ----
+  float *const slab = A.slabs + (long long)blockIdx.x * (N::P + N::V) + (c ? N::P : 0);
+  {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float o2[4] = {S2[a][0], S2[a][1], S2[a][2], S2[a][3]}, o1[4] = {S1[a][0], S1[a][1], S1[a][2], S1[a][3]};
+      store_vec_global<4>(slab + N::W1 + HID + (4 * r + a) * LH + c0 + 4 * g, o2);
+      store_vec_global<4>(slab + N::W1 + (4 * r + a) * LH + c0 + 4 * g, o1);
+    }
+    if (r == 0) {
+      const float o2[4] = {S2b[0], S2b[1], S2b[2], S2b[3]}, o1[4] = {S1b[0], S1b[1], S1b[2], S1b[3]};
+      store_vec_global<4>(slab + N::W1 + HID + LH * LH + c0 + 4 * g, o2);
+      store_vec_global<4>(slab + N::W1 + LH * LH + c0 + 4 * g, o1);
+    }
+    if (sub <= X) slab[sub * LH + lane] = s_first0;                    // rows 0..3 (or the bias when X < 4 and sub == X)
+    if (sub + 4 <= X) slab[(sub + 4) * LH + lane] = s_first1;
+    const int NO = c == 0 ? 2 : 1;
+    if (sub < NO) slab[N::OUT + lane * NO + sub] = s_last;
+    if (sub == 0 && lane < NO) slab[N::OUT + LH * NO + lane] = s_lastb;
+  }
+  __syncthreads();
+  if (out_wave && lane < 16) {
+    if (c == 0) {
+      smem[P_LOSS + lane] = loss_a;
+      smem[P_LOSS + 32 + lane] = loss_b;
+    } else {
+      smem[P_LOSS + 16 + lane] = loss_a;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, b = 0.f, e = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      a += smem[P_LOSS + i];
+      b += smem[P_LOSS + 16 + i];
+      e += smem[P_LOSS + 32 + i];
+    }
+    A.extras[blockIdx.x * 4 + 0] = a;
+    A.extras[blockIdx.x * 4 + 1] = b;
+    A.extras[blockIdx.x * 4 + 2] = e;
+  }
+}
+
+bool ppo_lean_supports(int x_dim, int u_dim, const int *policy_dims, int policy_layers, int policy_act, const int *value_dims, int value_layers,
+                       int value_act) {
+  if (u_dim != 1 || (x_dim != 3 && x_dim != 4)) return false;
+  if (policy_layers != 4 || value_layers != 4 || policy_act != MBPO_ACT_SWISH || value_act != MBPO_ACT_SWISH) return false;
+  for (int l = 1; l <= 3; ++l)
+    if (policy_dims[l] != LH || value_dims[l] != LH) return false;
+  return policy_dims[0] == x_dim && policy_dims[4] == 2 && value_dims[0] == x_dim && value_dims[4] == 1;
+}
+
+int ppo_lean_launch(const PpoLeanArgs &A, int x_dim, int n_wgs, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (x_dim == 3) {
+    rc = mbpo_ensure_lds<k_ppo_lean<3>>(PPO_LEAN_LDS_BYTES, "ppo_lean");
+    if (rc != MBPO_OK) return rc;
+    hipLaunchKernelGGL(k_ppo_lean<3>, dim3(n_wgs), dim3(512), PPO_LEAN_LDS_BYTES, st, A);
+  } else if (x_dim == 4) {
+    rc = mbpo_ensure_lds<k_ppo_lean<4>>(PPO_LEAN_LDS_BYTES, "ppo_lean");
+    if (rc != MBPO_OK) return rc;
+    hipLaunchKernelGGL(k_ppo_lean<4>, dim3(n_wgs), dim3(512), PPO_LEAN_LDS_BYTES, st, A);
+  } else {
+    mbpo_set_error("ppo_lean: x_dim %d has no instantiation", x_dim);
+    return MBPO_ERR_UNSUPPORTED;
+  }
+  return MBPO_OK;
+}

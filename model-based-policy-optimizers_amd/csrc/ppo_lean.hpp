@@ -1,0 +1,23 @@
+// ppo_lean.hpp — host interface of the PPO loss forward/backward kernel specialised for the benchmark networks (ppo_lean.hip).
+#pragma once
+#include "common.hpp"
+
+struct PpoLeanArgs {
+  const float *params;                  // [policy | value]
+  const float *data;                    // [M][2x + 2u + 4] rows of the shuffled minibatch (ppo.py:142-156)
+  const float *norm_mean, *norm_std;
+  const float *adv, *vs, *mom;          // per-row GAE advantages / value targets (compute_gae), mom = {mean, std} of the advantages
+  const float *ent_noise;               // given entropy-sample noise, or NULL (Philox)
+  const unsigned long long *rng_dev;
+  unsigned long long seed, offset;
+  float *slabs, *extras;                // per workgroup: gradient slab [policy | value], 4 loss partials
+  long long M;
+  float entropy_cost, clip_eps;
+  int normalize_advantage;
+};
+
+// policy x -> 64^3 -> 2, value x -> 64^3 -> 1, swish, u = 1, x in {3, 4}
+bool ppo_lean_supports(int x_dim, int u_dim, const int *policy_dims, int policy_layers, int policy_act, const int *value_dims, int value_layers,
+                       int value_act);
+// one workgroup per CU (n_wgs <= tiles), each walks tiles blockIdx.x, + n_wgs, ... and leaves ONE slab
+int ppo_lean_launch(const PpoLeanArgs &A, int x_dim, int n_wgs, void *stream);

@@ -195,3 +195,46 @@ def test_ppo_fused_step_equals_grads_plus_apply(dev):
         assert float(a.step_count) == float(b.step_count) == 4
         for name in ("params", "adam_m", "adam_v", "grads", "metrics"):
             assert torch.equal(getattr(a, name), getattr(b, name)), (B, T, name)
+
+
+@pytest.mark.parametrize("X,B,T,normalize,norm_adv,given_noise", [
+    (3, 512, 40, True, True, True),       # BASELINE configs[2] at full size: 1280 tiles, 5 per workgroup
+    (4, 512, 5, True, True, False),       # horizon-5 unrolls, in-kernel Philox entropy noise, one tile per workgroup
+    (4, 37, 3, False, False, True),       # ragged: M = 111 rows, the last tile holds 15
+])
+def test_ppo_lean_kernel_matches_generic_kernel(dev, X, B, T, normalize, norm_adv, given_noise):
+    """k_ppo_lean (csrc/ppo_lean.hip: the loss forward/backward specialised for the 64x3 benchmark networks — weights resident in
+    registers for all of a workgroup's tiles, weight gradients summed in registers, one slab per CU) against the generic k_ppo_fwd_bwd.
+    Every per-tile number is formed by the same MFMA / FMA sequences; what differs is which tiles a slab sums (256 slabs instead of 512)
+    — the cross-tile summation order — so gradients agree to fp32 summation-order accuracy, not bit for bit.  Oracle parity of the lean
+    kernel itself: test_ppo_gradients_and_step above runs on it for these shapes."""
+    import ctypes as C
+    from mbpo import _hip
+    lib = _hip.load()
+    lib.mbpo_debug_set_ppo_lean.argtypes = [C.c_int]
+    cfg, st, data, noise, nm, ns = _make(X, 1, (64, 64, 64), B, T, 2, normalize, entropy_cost=1e-2, discounting=0.99, reward_scaling=0.5,
+                                          gae_lambda=0.95, clipping_epsilon=0.3, normalize_advantage=norm_adv, lr=3e-4, wd=1e-5)
+    d = lambda t: None if t is None else t.to(dev)
+    outs = []
+    try:
+        for lean in (0, 1):
+            lib.mbpo_debug_set_ppo_lean(lean)
+            up = _updater(dev, cfg, B, T)
+            up.load_state(st.params.to(dev))
+            from mbpo import ops
+            rng = ops.make_rng(dev, 3)
+            if given_noise:
+                up.minibatch_step(data.to(dev), d(nm), d(ns), noise.to(dev))
+            else:
+                up.minibatch_step(data.to(dev), d(nm), d(ns), seed=5, offset=9 << 32, rng_dev=rng)
+            torch.cuda.synchronize()
+            outs.append((up.grads.cpu().clone(), up.metrics.cpu().clone(), up.params.cpu().clone()))
+    finally:
+        lib.mbpo_debug_set_ppo_lean(-1)
+    (g0, m0, p0), (g1, m1, p1) = outs
+    assert float(g0.abs().sum()) > 0 and not torch.equal(g0, torch.zeros_like(g0))
+    P = cfg.P
+    for name, sl in (("policy", slice(0, P)), ("value", slice(P, None))):
+        scale = float(g0[sl].abs().max())
+        torch.testing.assert_close(g1[sl], g0[sl], atol=2e-6 * max(scale, 1e-3), rtol=2e-5, msg=lambda m: f"{name}: {m}")
+    np.testing.assert_allclose(m1.numpy(), m0.numpy(), rtol=2e-5, atol=1e-6)
