@@ -635,6 +635,12 @@ struct PpoPlan {
 // Measurement / test hook (not part of include/mbpo_hip.h): 0 = always the generic k_ppo_fwd_bwd, 1 = k_ppo_lean where it applies,
 // -1 = the MBPO_PPO_LEAN environment default (on).
 static int g_ppo_lean = -1;
+static unsigned long long *g_ppo_stamps = nullptr;
+// measurement hook: device buffer of >= 64 uint64 that k_ppo_lean fills with s_memtime stamps (workgroup 0, 12 per tile); NULL = off
+extern "C" int mbpo_debug_set_ppo_stamps(void *buf) {
+  g_ppo_stamps = (unsigned long long *)buf;
+  return MBPO_OK;
+}
 extern "C" int mbpo_debug_set_ppo_lean(int mode) {
   g_ppo_lean = mode;
   return MBPO_OK;
@@ -853,6 +859,7 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
     L.rng_dev = A.rng_dev; L.seed = A.seed; L.offset = A.offset;
     L.slabs = A.slabs; L.extras = A.extras; L.M = pl.M;
     L.entropy_cost = d->entropy_cost; L.clip_eps = d->clipping_epsilon; L.normalize_advantage = d->normalize_advantage;
+    L.stamps = g_ppo_stamps;
     rc = ppo_lean_launch(L, d->x_dim, pl.n_slabs, stream);
     if (rc != MBPO_OK) return rc;
   } else if (pl.H == 64) {

@@ -14,6 +14,12 @@
 //  * Stored derivative instead of pre-activation (swish'(z) written by the forward pass; the delta tiles overwrite them in place);
 //    all input gradients first, then the weight gradients of both hidden layers and both thin layers with no barrier between them.
 //  * The next tile's rows are requested one tile ahead; its entropy noise is drawn by an idle wave during the output-layer step.
+// Measured and NOT kept (round 4, scripts/ppo_lean_dev.py stamps; 15 k cycles per tile, 4.5 k of them the weight gradients): forming a
+// tile's weight gradients inside the next tile's thin / tile-load steps (double-buffered tile sets) — those steps have no idle
+// waves, the work just moves (15.1 -> 16.0 k); giving the six waves that idle during the output-layer step the previous tile's
+// hidden-layer gradients — the output wave they share a SIMD with slows down by what the phase at the end gains (15.4 k); the thin
+// layers' gradients as 4-MFMA tiles instead of FMA loops (-0.65 k) with the input-gradient images re-requested per tile to pay for
+// their 16 accumulator registers (+1.3 k: the requests are not back in two steps).
 #include "common.hpp"
 #include "chain_run.hpp"
 #include "lean_blocks.hpp"
@@ -73,8 +79,16 @@ __device__ __forceinline__ void hid_wgrad_regs(const float *hin, const float *de
 
 }  // namespace
 
+#define PPO_STAMP(i)                                                                    \
+  if (A.stamps && blockIdx.x == 0 && tid == 0 && stamp_base + (i) < 64) {               \
+    unsigned long long t_;                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+    A.stamps[stamp_base + (i)] = t_;                                                    \
+  }
+
 template <int X>
 __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
+  int stamp_base = 0;
   extern __shared__ __align__(16) float smem[];
   using N = PNet<X>;
   constexpr int D = N::D;
@@ -82,42 +96,13 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = wave >> 2, sub = wave & 3, c0 = sub * 16;        // chain c = network: 0 policy, 1 value
+  PPO_STAMP(0);
   const long long M = A.M;
   const long long n_tiles = (M + 15) >> 4;
   const float invM = 1.0f / (float)M;
   const float *const net_p = A.params + (c ? N::P : 0);
   float *const tiles = smem + P_TILES + c * 6 * LT;
 #define PT(n) (tiles + (n) * LT)      /* 0..2: stored derivatives / deltas of layers 0..2, 3..5: activations h0..h2 */
-
-  // ---- every weight image this wave will use, once per launch ----
-  float tw[X + 1];
-  ImgF I1, I2;
-  float wo[16];
-  float bo0 = 0.f, bo1 = 0.f;
-  float two[2] = {0.f, 0.f};
-  float G2[16], G1[16];
-  thin_col_request<X>(tw, net_p, lane);
-  img_fwd_request(I1, net_p + N::W1, c0, lane);
-  img_fwd_request(I2, net_p + N::W1 + HID, c0, lane);
-  const bool out_wave = sub == c;                                 // wave 0 (policy) and wave 5 (value): different SIMDs
-  if (out_wave) {
-    if (c == 0) {
-      img_out_request<2>(wo, net_p + N::OUT, lane);
-      bo0 = net_p[N::OUT + LH * 2];
-      bo1 = net_p[N::OUT + LH * 2 + 1];
-    } else {
-      img_out_request<1>(wo, net_p + N::OUT, lane);
-      bo0 = net_p[N::OUT + LH];
-    }
-  }
-  if (c == 0) {
-    two[0] = net_p[N::OUT + lane * 2];
-    two[1] = net_p[N::OUT + lane * 2 + 1];
-  } else {
-    two[0] = net_p[N::OUT + lane];
-  }
-  img_dgrad_request(G2, net_p + N::W1 + HID, c0, lane);
-  img_dgrad_request(G1, net_p + N::W1, c0, lane);
 
   // ---- per-thread role in the tile load: one dword of the tile's 16 x D block, or an advantage / value-target element ----
   const bool has_elem = tid < 16 * D;
@@ -154,6 +139,38 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
       smem[P_EPS + 16 * par + lane] = e;
     }
   };
+  float v_next = tile_request(blockIdx.x);      // FIRST in the vector-memory queue (results return in order), before ~70 weight requests
+  if (wave == 7) draw_noise(blockIdx.x, 0);     // (and the first tile's noise before this wave's requests: the first barrier waits for the last wave)
+
+  // ---- every weight image this wave will use, once per launch ----
+  float tw[X + 1];
+  ImgF I1, I2;
+  float wo[16];
+  float bo0 = 0.f, bo1 = 0.f;
+  float two[2] = {0.f, 0.f};
+  float G2[16], G1[16];
+  thin_col_request<X>(tw, net_p, lane);
+  img_fwd_request(I1, net_p + N::W1, c0, lane);
+  img_fwd_request(I2, net_p + N::W1 + HID, c0, lane);
+  const bool out_wave = sub == c;                                 // wave 0 (policy) and wave 5 (value): different SIMDs
+  if (out_wave) {
+    if (c == 0) {
+      img_out_request<2>(wo, net_p + N::OUT, lane);
+      bo0 = net_p[N::OUT + LH * 2];
+      bo1 = net_p[N::OUT + LH * 2 + 1];
+    } else {
+      img_out_request<1>(wo, net_p + N::OUT, lane);
+      bo0 = net_p[N::OUT + LH];
+    }
+  }
+  if (c == 0) {
+    two[0] = net_p[N::OUT + lane * 2];
+    two[1] = net_p[N::OUT + lane * 2 + 1];
+  } else {
+    two[0] = net_p[N::OUT + lane];
+  }
+  img_dgrad_request(G2, net_p + N::W1 + HID, c0, lane);
+  img_dgrad_request(G1, net_p + N::W1, c0, lane);
 
   // ---- running sums over this workgroup's tiles (registers) ----
   f32x4 S2[4], S2b, S1[4], S1b;
@@ -165,8 +182,6 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
   float loss_a = 0.f, loss_b = 0.f;             // out waves, lanes 0..15: policy: surrogate, entropy; value: squared error
   bool first = true;
 
-  float v_next = tile_request(blockIdx.x);
-  if (wave == 7) draw_noise(blockIdx.x, 0);
   int par = 0;
 #pragma nounroll
   for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
@@ -182,14 +197,19 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
       else if (is_vs) s_aux[(tid & 15) * 4 + 3] = v;
       v_next = tile_request(tile + gridDim.x);
     }
+    PPO_STAMP(1);
     __syncthreads();
+    PPO_STAMP(2);
     // ---- forward: policy logits (:80) and value baseline (:82); swish'(z) stored for the backward pass ----
     thin_first<X, true, false>(tw, s_x, PT(3), PT(0), nullptr, sub, lane);
     __syncthreads();
+    PPO_STAMP(3);
     hid_fwd<true>(I1, PT(3), PT(4), PT(1), c0, lane);
     __syncthreads();
+    PPO_STAMP(4);
     hid_fwd<true>(I2, PT(4), PT(5), PT(2), c0, lane);
     __syncthreads();
+    PPO_STAMP(5);
     // ---- output layers and the loss terms on the waves that hold them (:84-126) ----
     if (out_wave) {
       const f32x4 y = out_fwd(wo, PT(5), lane);
@@ -238,7 +258,9 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
     } else if (wave == 7) {
       draw_noise(tile + gridDim.x, par ^ 1);        // the next tile's entropy noise, on a wave that has nothing to do in this step
     }
+    PPO_STAMP(6);
     __syncthreads();
+    PPO_STAMP(7);
     // ---- backward, input gradients first: delta_2, delta_1, delta_0 overwrite the stored derivatives in place ----
     {
       float zq[4];
@@ -247,10 +269,13 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
       else thin_dgrad_last<1>(*reinterpret_cast<float(*)[1]>(&two[0]), s_dy, zq, PT(2), sub, lane);
     }
     __syncthreads();
+    PPO_STAMP(8);
     hid_dgrad(G2, PT(2), PT(1), PT(1), c0, lane);
     __syncthreads();
+    PPO_STAMP(9);
     hid_dgrad(G1, PT(1), PT(0), PT(0), c0, lane);
     __syncthreads();
+    PPO_STAMP(10);
     // ---- weight gradients of the four layers: nothing depends on them inside the tile, no barrier between them ----
     {
       f32x4 acc[4], accb;
@@ -299,6 +324,8 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
         s_lastb = first ? acc : s_lastb + acc;
       }
     }
+    PPO_STAMP(11);
+    stamp_base += 12;
     first = false;
     // (no barrier here: the next tile's rows go to the other parity of s_x / s_aux, and nobody overwrites this tile's tiles before
     //  the barrier behind that store, which every wave reaches only after its weight gradients)

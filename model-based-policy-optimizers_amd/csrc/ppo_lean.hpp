@@ -14,6 +14,7 @@ struct PpoLeanArgs {
   long long M;
   float entropy_cost, clip_eps;
   int normalize_advantage;
+  unsigned long long *stamps;           // measurement hook (mbpo_debug_set_ppo_stamps): s_memtime per section of workgroup 0's first tiles, or NULL
 };
 
 // policy x -> 64^3 -> 2, value x -> 64^3 -> 1, swish, u = 1, x in {3, 4}

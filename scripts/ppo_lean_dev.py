@@ -49,3 +49,33 @@ for T in (40, 5):
     print("T=%d  minibatch_step us: generic %s  lean %s   max |dg| %.3e (max |g| %.3e)  finite %s" %
           (T, " ".join("%.1f" % t for t, _ in res[0]), " ".join("%.1f" % t for t, _ in res[1]), float((g0 - g1).abs().max()),
            float(g0.abs().max()), bool(torch.isfinite(g1).all())), flush=True)
+
+# ---- per-section timeline of k_ppo_lean (workgroup 0, its first 5 tiles): s_memtime stamps
+lib.mbpo_debug_set_ppo_stamps.argtypes = [C.c_void_p]
+T = 40
+data = torch.randn(512, T, D, generator=g) * 0.5
+data[..., X + U + 1] = 1.0
+data[..., -1] = 0.0
+data = data.to(dev)
+lib.mbpo_debug_set_ppo_lean(1)
+up = ops.PpoUpdater(x_dim=X, u_dim=U, policy_dims=pd, value_dims=vd, batch_size=512, unroll_length=T, device=dev)
+up.load_state(p0)
+stamps = torch.zeros(64, dtype=torch.int64, device=dev)
+acc = torch.zeros(64, dtype=torch.float64)
+for it in range(30):
+    if it == 10:
+        lib.mbpo_debug_set_ppo_stamps(C.c_void_p(stamps.data_ptr()))
+    up.minibatch_step(data, seed=1, offset=5 << 32)
+    torch.cuda.synchronize()
+    if it >= 10:
+        acc += stamps.cpu().double()
+lib.mbpo_debug_set_ppo_stamps(C.c_void_p(0))
+acc /= 20
+names = ["(top / previous tile end)", "tile -> LDS", "barrier", "thin 0", "hidden 1", "hidden 2", "out + loss (+ noise)", "barrier", "thin dgrad",
+         "dgrad L2", "dgrad L1", "weight gradients"]
+for t in range(5):
+    b = 12 * t
+    if b + 11 >= 64:
+        break
+    row = [float(acc[b + i] - (acc[b + i - 1] if (i > 0 or t > 0) else acc[0])) for i in range(12)]
+    print("tile %d: " % t + "  ".join("%s %.0f" % (n, v) for n, v in zip(names, row)) + "   | total %.0f" % (float(acc[b + 11] - (acc[b - 1] if t else acc[0]))))
