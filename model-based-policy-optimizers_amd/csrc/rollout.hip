@@ -9,6 +9,7 @@
 // Per (env, step) HBM traffic is one row write (row_len*4 B) — the kernel is MFMA/latency bound by design.
 #include "common.hpp"
 #include "chain_run.hpp"
+#include "ens_lean.hpp"
 #include <string.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -96,6 +97,14 @@ static int num_cus() {
   return n;
 }
 
+// Measurement / test hook (not part of include/mbpo_hip.h): 0 = always the generic k_ensemble_forward, 1 = k_ens_fwd_lean where it applies,
+// -1 = the MBPO_ENS_LEAN environment default (on).
+static int g_ens_lean = -1;
+extern "C" int mbpo_debug_set_ens_lean(int mode) {
+  g_ens_lean = mode;
+  return MBPO_OK;
+}
+
 extern "C" int mbpo_ensemble_mlp_forward(const mbpo_mlp_desc *mlp, const float *x, int32_t shared_input, float *y,
                                          int64_t n_rows, void *stream) {
   MBPO_REQUIRE(mlp && x && y, MBPO_ERR_ARG, "ensemble_mlp_forward: null pointer");
@@ -104,6 +113,25 @@ extern "C" int mbpo_ensemble_mlp_forward(const mbpo_mlp_desc *mlp, const float *
   int rc = mbpo_make_mlp_dev(mlp, &A.mlp, "ensemble_mlp_forward");
   if (rc != MBPO_OK) return rc;
   if (n_rows == 0) return MBPO_OK;
+  {
+    // 64-wide member networks with 4 or 5 inputs: the throughput kernel (ens_lean.hip) — weights resident per workgroup, two tiles in
+    // flight per workgroup, two workgroups per CU.  MBPO_ENS_LEAN=0 / mbpo_debug_set_ens_lean(0) keeps the generic kernel.
+    static const int lean_env = getenv("MBPO_ENS_LEAN") ? atoi(getenv("MBPO_ENS_LEAN")) : 1;
+    if ((g_ens_lean >= 0 ? g_ens_lean : lean_env) != 0 && ens_lean_supports(A.mlp.dims, A.mlp.n_layers, A.mlp.act)) {
+      EnsLeanArgs L;
+      L.params = mlp->params; L.net_stride = mlp->n_nets > 1 ? mlp->net_stride : A.mlp.n_params;
+      L.x = x; L.y = y; L.n_rows = n_rows; L.E = mlp->n_nets; L.N = A.mlp.dims[A.mlp.n_layers]; L.shared_input = shared_input ? 1 : 0;
+      const long long pairs = (((n_rows + 15) >> 4) + 1) >> 1;
+      long long wpm = (2LL * num_cus()) / L.E;
+      if (wpm < 1) wpm = 1;
+      if (wpm > pairs) wpm = pairs;
+      L.wgs_per_member = (int)wpm;
+      rc = ens_lean_launch(L, A.mlp.dims[0], num_cus(), stream);
+      if (rc != MBPO_OK) return rc;
+      MBPO_CHECK_LAUNCH("ensemble_mlp_forward");
+      return MBPO_OK;
+    }
+  }
   const int H = hidden_width(A.mlp);
   MBPO_REQUIRE(H == 64 || H == 128 || H == 256, MBPO_ERR_UNSUPPORTED,
                "ensemble_mlp_forward: hidden layers must share one width in {64,128,256}");

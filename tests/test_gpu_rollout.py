@@ -37,6 +37,12 @@ def _ens_params(dims, E, seed):
     ([4, 256, 256, 6], 2, 50, "tanh"),
     ([7, 3], 2, 20, "swish"),          # single Dense layer
     ([5, 64, 64, 64, 8], 5, 1, "swish"),
+    # the lean throughput kernel's shapes (csrc/ens_lean.hip: 4 or 5 inputs, 64 x 3): ragged last tile, odd tile count, 6 outputs (partial
+    # 16-byte output store), more tile pairs than workgroups per member
+    ([4, 64, 64, 64, 6], 3, 1000 * 16 + 7, "swish"),
+    ([5, 64, 64, 64, 8], 7, 3 * 16, "swish"),
+    ([5, 64, 64, 64, 16], 2, 33, "swish"),
+    ([5, 64, 64, 64, 8], 5, 32768, "swish"),       # C4's global env count on one GPU
 ])
 def test_ensemble_forward_parity(dev, dims, E, N, act):
     from mbpo import ops
@@ -57,6 +63,13 @@ def test_ensemble_forward_per_member_input(dev):
     dims, E, N = [5, 64, 64, 8], 4, 70
     params = _ens_params(dims, E, 3)
     x = torch.randn(E, N, dims[0], generator=torch.Generator().manual_seed(2))
+    y_ref = onets.ensemble_forward(params, dims, E, x, "swish", shared_input=False)
+    y = ops.ensemble_mlp_forward(params.to(dev), ops.MlpSpec(dims, "swish", E), x.to(dev), shared_input=False).cpu()
+    torch.testing.assert_close(y, y_ref, atol=2e-5, rtol=2e-5)
+    # the lean kernel's shape with a per-member input
+    dims, E, N = [5, 64, 64, 64, 8], 3, 1234
+    params = _ens_params(dims, E, 4)
+    x = torch.randn(E, N, dims[0], generator=torch.Generator().manual_seed(5))
     y_ref = onets.ensemble_forward(params, dims, E, x, "swish", shared_input=False)
     y = ops.ensemble_mlp_forward(params.to(dev), ops.MlpSpec(dims, "swish", E), x.to(dev), shared_input=False).cpu()
     torch.testing.assert_close(y, y_ref, atol=2e-5, rtol=2e-5)
