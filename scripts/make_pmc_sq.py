@@ -15,7 +15,7 @@ from collections import defaultdict
 from pathlib import Path
 
 
-def main(src: str, out: str) -> None:
+def main(src: str, out: str, what: str = "python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph") -> None:
     f = max(Path(src).rglob("*counter_collection.csv"), key=lambda q: q.stat().st_mtime)
     acc = defaultdict(lambda: defaultdict(list))
     grid = {}
@@ -43,13 +43,12 @@ def main(src: str, out: str) -> None:
         kernels[k] = e
     Path(out).write_text(json.dumps({
         "source": "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES "
-                  "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU (scripts/collect_pmc_sq.sh) of `python3 bench.py --steps 6 --warmup 2 "
-                  "--no-cpu-baseline --no-graph`; averages per dispatch",
+                  "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU (scripts/collect_pmc_sq.sh, scripts/collect_round_extras.sh) of `" + what + "`; averages per dispatch",
         "file": f.name, "kernels": kernels}, indent=1))
     for k in kernels:
-        if any(s in k for s in ("sac_fwd", "reduce_apply", "rollout64")):
+        if any(s in k for s in ("sac_fwd", "sac_lean", "reduce_apply", "rollout64", "ppo_lean", "ppo_values", "bptt_actor", "critic_fwd")):
             print(k, json.dumps(kernels[k]))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])

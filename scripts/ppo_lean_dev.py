@@ -71,11 +71,14 @@ for it in range(30):
         acc += stamps.cpu().double()
 lib.mbpo_debug_set_ppo_stamps(C.c_void_p(0))
 acc /= 20
-names = ["(top / previous tile end)", "tile -> LDS", "barrier", "thin 0", "hidden 1", "hidden 2", "out + loss (+ noise)", "barrier", "thin dgrad",
-         "dgrad L2", "dgrad L1", "weight gradients"]
+names = ["tile -> LDS", "barrier", "thin 0", "hidden 1", "hidden 2", "out + loss (+ noise)", "barrier", "thin dgrad", "dgrad L2", "dgrad L1",
+         "weight gradients"]
+# slot 0 = kernel top; tile t stamps slots 12 t + 1 .. 12 t + 11 (the end of each section); a tile starts where the previous one ended
 for t in range(5):
     b = 12 * t
-    if b + 11 >= 64:
-        break
-    row = [float(acc[b + i] - (acc[b + i - 1] if (i > 0 or t > 0) else acc[0])) for i in range(12)]
-    print("tile %d: " % t + "  ".join("%s %.0f" % (n, v) for n, v in zip(names, row)) + "   | total %.0f" % (float(acc[b + 11] - (acc[b - 1] if t else acc[0]))))
+    start = float(acc[0] if t == 0 else acc[b - 1])
+    row, prev = [], start
+    for i in range(1, 12):
+        row.append(float(acc[b + i]) - prev)
+        prev = float(acc[b + i])
+    print("tile %d: " % t + "  ".join("%s %.0f" % (n, v) for n, v in zip(names, row)) + "   | total %.0f" % (prev - start))

@@ -1,4 +1,5 @@
-"""Phase timeline of k_sac_fwd_bwd (tile 0, both roles) from in-kernel s_memtime stamps; bench-shaped SAC step."""
+"""Phase timeline of the generic k_sac_fwd_bwd (tile 0, both roles) from in-kernel s_memtime stamps; bench-shaped SAC step.
+The 64x3 benchmark shape runs k_sac_lean by default (its timeline: scripts/lean_dev.py); this script pins the generic kernel."""
 import ctypes as C, sys, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'model-based-policy-optimizers_amd')
 from mbpo import ops, _hip
@@ -11,6 +12,8 @@ up.load_state((torch.randn(up.params.numel(), generator=g) * 0.1).to(dev))
 D = 2 * X + U + 3
 batch = torch.randn(B, D, generator=g).to(dev)
 lib = _hip.load()
+lib.mbpo_debug_set_sac_lean.argtypes = [C.c_int]
+lib.mbpo_debug_set_sac_lean(0)
 stamps = torch.zeros(64, dtype=torch.int64, device=dev)
 names = {0: ["start", "setup", "E load tile", "F0 pi(s')||Q1||Q2 fwd", "E sample a'", "F1 Qtgt fwd", "E targets", "B2 Q dgrad||wgrad", "E partials"],
          1: ["start", "setup", "E load tile", "F0 pi(s) fwd", "E sample a", "F1 Q1||Q2 fwd", "E dL/dq", "B2 Q input-grad", "E dL/dlogits",
