@@ -15,7 +15,7 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-KERNEL_SOURCES = ["sac.hip", "sac_lean.hip", "sac_lean.hpp", "sac_shared.hpp", "chain_run.hpp", "wave_mlp.hpp", "common.hpp", "p2p.hpp"]
+KERNEL_SOURCES = ["sac.hip", "sac_lean.hip", "sac_lean.hpp", "sac_shared.hpp", "lean_blocks.hpp", "chain_run.hpp", "wave_mlp.hpp", "common.hpp", "p2p.hpp"]
 
 
 def source_sha16() -> str:
