@@ -13,14 +13,21 @@ constexpr int LDK = BK + 4;
 // T = 1 unless the problem is huge (layered_gemm) — fp32 MFMA is 256 FLOP/cycle/CU, so a 256 x 256 x 256 layer on sixteen 64 x 64
 // tiles is 8 k cycles on 16 CUs; on sixty-four 32 x 32 tiles 2 k cycles on 64.  K walks through LDS in chunks of 64;
 // the NEXT chunk's global loads are issued (into registers) before the current chunk's MFMAs.
-template <int MODE, int T>
-__global__ void __launch_bounds__(256) k_layered_gemm(GemmArgs G) {
-  constexpr int BM = 32 * T, LDT = BM + 16, PER_T = BM * BK / 256;
-  constexpr int TILE_F = (BK * LDT > BM * LDK) ? BK * LDT : BM * LDK;
-  __shared__ float sA[TILE_F], sB[TILE_F];
+template <int T>
+struct GemmTile {
+  static constexpr int BM = 32 * T, LDT = BM + 16, PER_T = BM * BK / 256;
+  static constexpr int TILE_F = (BK * LDT > BM * LDK) ? BK * LDT : BM * LDK;
+};
+
+// One output tile of one problem.  MODE is the epilogue (a compile-time constant in k_layered_gemm<MODE, T>, a uniform run-time value in
+// k_layered_group<T>); (bx, by, bz) = the tile's position in that problem's grid.
+template <int T>
+__device__ __forceinline__ void gemm_tile(const GemmArgs &G, const int MODE, float *__restrict__ sA, float *__restrict__ sB, const int bx,
+                                          const int by, const int bz) {
+  constexpr int BM = GemmTile<T>::BM, LDT = GemmTile<T>::LDT, PER_T = GemmTile<T>::PER_T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int zb = blockIdx.z / G.n_split, sp = blockIdx.z - zb * G.n_split;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BM;
+  const int zb = bz / G.n_split, sp = bz - zb * G.n_split;
+  const int m0 = by * BM, n0 = bx * BM;
   const float *A = G.A + (long long)zb * G.zA, *B = G.B + (long long)zb * G.zB;
   const int k_begin = sp * G.k_chunk;
   const int k_end = (k_begin + G.k_chunk < G.K) ? k_begin + G.k_chunk : G.K;
@@ -96,7 +103,7 @@ __global__ void __launch_bounds__(256) k_layered_gemm(GemmArgs G) {
     __syncthreads();
   }
   // lane holds D[row = 4 * (lane >> 4) + r][col = lane & 15] of each 16 x 16 block
-  float *C = G.C ? G.C + (G.n_split > 1 ? (long long)blockIdx.z * G.zSplit : (long long)zb * G.zC) : nullptr;
+  float *C = G.C ? G.C + (G.n_split > 1 ? (long long)bz * G.zSplit : (long long)zb * G.zC) : nullptr;
   float *C2 = G.C2 ? G.C2 + (long long)zb * G.zC : nullptr;
   const float *bias = (MODE == 0 && G.bias) ? G.bias + (long long)zb * G.zBias : nullptr;
   const float *Zp = (MODE == 1 && G.Zprev) ? G.Zprev + (long long)zb * G.zZ : nullptr;
@@ -126,6 +133,41 @@ __global__ void __launch_bounds__(256) k_layered_gemm(GemmArgs G) {
     }
 }
 
+template <int MODE, int T>
+__global__ void __launch_bounds__(256) k_layered_gemm(GemmArgs G) {
+  __shared__ float sA[GemmTile<T>::TILE_F], sB[GemmTile<T>::TILE_F];
+  gemm_tile<T>(G, MODE, sA, sB, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent problems of one dependency level as ONE launch (round 4): the layered step is launch-bound below ~256-wide
+// layers (one Dense layer of one pass per launch: 46 launches per SAC update), and the passes of a level — policy(obs) / policy(next
+// obs); the critics on (s, a), (s, a~pi), the target critics on (s', a'); a layer's weight gradient and the input gradient below it —
+// depend on the previous level only.  A workgroup finds its problem from the tile prefix sums (uniform scalar work) and runs that
+// problem's tile; the epilogue kind is a run-time value here.
+constexpr int GROUP_MAX = 6;
+struct GemmGroupArgs {
+  int n;
+  int start[GROUP_MAX + 1];          // first workgroup of problem p; start[n] = grid size
+  int mode[GROUP_MAX];
+  GemmArgs g[GROUP_MAX];
+};
+
+template <int T>
+__global__ void __launch_bounds__(256) k_layered_group(const GemmGroupArgs GG) {
+  __shared__ float sA[GemmTile<T>::TILE_F], sB[GemmTile<T>::TILE_F];
+  constexpr int BM = GemmTile<T>::BM;
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < GROUP_MAX; ++q)
+    if (q < GG.n && (int)blockIdx.x >= GG.start[q]) p = q;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const GemmArgs &G = GG.g[p];
+  const int local = (int)blockIdx.x - GG.start[p];
+  const int tx = (G.N + BM - 1) / BM, ty = (G.M + BM - 1) / BM;
+  const int bx = local % tx, r = local / tx;
+  gemm_tile<T>(G, GG.mode[p], sA, sB, bx, r % ty, r / ty);
+}
+
 __global__ void __launch_bounds__(256) k_layered_split_sum(const float *part, long long stride, int n_split, float *out, long long out_stride,
                                                            long long n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -135,18 +177,30 @@ __global__ void __launch_bounds__(256) k_layered_split_sum(const float *part, lo
 }
 }  // namespace
 
-int layered_gemm(int mode, const GemmArgs &G, hipStream_t st) {
+static int gemm_prepare(int mode, const GemmArgs &G, GemmArgs *H, long long *wg64) {
   MBPO_REQUIRE(G.A && G.B && (G.C || (mode == 0 && G.C2)), MBPO_ERR_ARG, "layered_gemm: null operand");
   MBPO_REQUIRE(G.M > 0 && G.N > 0 && G.K > 0 && G.nz >= 1 && G.n_split >= 1, MBPO_ERR_ARG, "layered_gemm: bad shape %d x %d x %d", G.M, G.N, G.K);
   MBPO_REQUIRE(G.n_split == 1 || (G.k_chunk > 0 && G.k_chunk % BK == 0), MBPO_ERR_ARG, "layered_gemm: k_chunk must be a multiple of %d", BK);
-  GemmArgs H = G;
-  if (H.n_split == 1) H.k_chunk = H.K;
-  const long long wg64 = (long long)((G.N + 63) / 64) * ((G.M + 63) / 64) * G.nz * G.n_split;
-  // 32 x 32 tiles until the 64 x 64 grid alone would hold every CU many times over: measured on PPO's C3 minibatch with a 256x5 value
-  // net (M = 20 992 rows: 328 x 4 tiles of 64) 1404 us per minibatch step with 64-tiles, 1298 with 32-tiles; SAC 256x3 at B = 4096
-  // 883 -> 829 us (scripts/layered_ppo_timing.py, layered_timing.py; MBPO_LAYERED_T2_MIN overrides)
+  *H = G;
+  if (H->n_split == 1) H->k_chunk = H->K;
+  *wg64 = (long long)((G.N + 63) / 64) * ((G.M + 63) / 64) * G.nz * G.n_split;
+  return MBPO_OK;
+}
+
+// 32 x 32 tiles until the 64 x 64 grid alone would hold every CU many times over: measured on PPO's C3 minibatch with a 256x5 value
+// net (M = 20 992 rows: 328 x 4 tiles of 64) 1404 us per minibatch step with 64-tiles, 1298 with 32-tiles; SAC 256x3 at B = 4096
+// 883 -> 829 us (scripts/layered_ppo_timing.py, layered_timing.py; MBPO_LAYERED_T2_MIN overrides)
+static int tile_factor(long long wg64) {
   static const long long t2_min = getenv("MBPO_LAYERED_T2_MIN") ? atoll(getenv("MBPO_LAYERED_T2_MIN")) : 4096;
-  const int T = wg64 >= t2_min ? 2 : 1;
+  return wg64 >= t2_min ? 2 : 1;
+}
+
+int layered_gemm(int mode, const GemmArgs &G, hipStream_t st) {
+  GemmArgs H;
+  long long wg64;
+  int rc = gemm_prepare(mode, G, &H, &wg64);
+  if (rc != MBPO_OK) return rc;
+  const int T = tile_factor(wg64);
   const int bm = 32 * T;
   const dim3 grid((unsigned)((G.N + bm - 1) / bm), (unsigned)((G.M + bm - 1) / bm), (unsigned)(G.nz * G.n_split));
 #define LG(MODE_, T_) hipLaunchKernelGGL((k_layered_gemm<MODE_, T_>), grid, dim3(256), 0, st, H)
@@ -159,6 +213,55 @@ int layered_gemm(int mode, const GemmArgs &G, hipStream_t st) {
   MBPO_CHECK_LAUNCH("layered_gemm");
   return MBPO_OK;
 }
+
+// The problems of one dependency level, issued as one launch (k_layered_group); one problem alone takes the plain kernel.
+// MBPO_LAYERED_GROUP=0: every problem its own launch (the round-3 behaviour, for A/B timing).
+namespace {
+struct GemmBatch {
+  GemmGroupArgs a;
+  long long wg64;
+  GemmBatch() : wg64(0) { a.n = 0; }
+  int add(int mode, const GemmArgs &G) {
+    MBPO_REQUIRE(a.n < GROUP_MAX, MBPO_ERR_ARG, "layered: more than %d problems in one level", GROUP_MAX);
+    long long w;
+    int rc = gemm_prepare(mode, G, &a.g[a.n], &w);
+    if (rc != MBPO_OK) return rc;
+    a.mode[a.n++] = mode;
+    wg64 += w;
+    return MBPO_OK;
+  }
+  int flush(hipStream_t st) {
+    static const bool grouped = !(getenv("MBPO_LAYERED_GROUP") && atoi(getenv("MBPO_LAYERED_GROUP")) == 0);
+    const int n = a.n;
+    a.n = 0;
+    const long long w = wg64;
+    wg64 = 0;
+    if (n == 0) return MBPO_OK;
+    if (n == 1 || !grouped) {
+      for (int p = 0; p < n; ++p) {
+        int rc = layered_gemm(a.mode[p], a.g[p], st);
+        if (rc != MBPO_OK) return rc;
+      }
+      return MBPO_OK;
+    }
+    const int T = tile_factor(w), bm = 32 * T;
+    long long total = 0;
+    for (int p = 0; p < n; ++p) {
+      const GemmArgs &G = a.g[p];
+      a.start[p] = (int)total;
+      total += (long long)((G.N + bm - 1) / bm) * ((G.M + bm - 1) / bm) * G.nz * G.n_split;
+    }
+    MBPO_REQUIRE(total < (1LL << 31), MBPO_ERR_ARG, "layered: level too large (%lld tiles)", total);
+    for (int p = n; p <= GROUP_MAX; ++p) a.start[p] = (int)total;
+    a.n = n;
+    if (T == 2) hipLaunchKernelGGL((k_layered_group<2>), dim3((unsigned)total), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_layered_group<1>), dim3((unsigned)total), dim3(256), 0, st, a);
+    a.n = 0;
+    MBPO_CHECK_LAUNCH("layered_group");
+    return MBPO_OK;
+  }
+};
+}  // namespace
 
 int layered_split_sum(const float *part, long long stride, int n_split, int nz, float *out, long long out_stride, long long n, hipStream_t st) {
   hipLaunchKernelGGL(k_layered_split_sum, dim3((unsigned)((n + 255) / 256), (unsigned)nz), dim3(256), 0, st, part, stride, n_split, out,
@@ -205,77 +308,131 @@ long long layered_part_floats(const LayeredNet &n, int rows) {
   return mx * s * n.nz;
 }
 
-int layered_forward(const LayeredNet &n, const float *x, long long zx, int rows, float *const *Z, float *const *H, float *y, hipStream_t st) {
-  const float *in = x;
-  long long zin = zx;
-  for (int l = 0; l < n.L; ++l) {
-    const int K = n.dims[l], N = n.dims[l + 1];
-    const bool last = l == n.L - 1;
-    GemmArgs G = {};
-    G.A = in; G.sam = K; G.sak = 1; G.zA = zin;
-    G.B = n.params + n.w_off[l]; G.sbk = N; G.sbn = 1; G.zB = n.net_stride;
-    G.bias = n.params + n.b_off[l]; G.zBias = n.net_stride;
-    G.M = rows; G.N = N; G.K = K; G.nz = n.nz; G.n_split = 1;
-    G.ldc = N; G.zC = (long long)rows * N;
-    if (last) {
-      G.C = y; G.C2 = nullptr; G.act = -1;
-    } else {
-      G.C = Z ? Z[l + 1] : nullptr; G.C2 = H[l + 1]; G.act = n.act;
+static GemmArgs forward_args(const LayeredFwd &p, int l, const float *in, long long zin) {
+  const LayeredNet &n = p.net;
+  const int K = n.dims[l], N = n.dims[l + 1];
+  const bool last = l == n.L - 1;
+  GemmArgs G = {};
+  G.A = in; G.sam = K; G.sak = 1; G.zA = zin;
+  G.B = n.params + n.w_off[l]; G.sbk = N; G.sbn = 1; G.zB = n.net_stride;
+  G.bias = n.params + n.b_off[l]; G.zBias = n.net_stride;
+  G.M = p.rows; G.N = N; G.K = K; G.nz = n.nz; G.n_split = 1;
+  G.ldc = N; G.zC = (long long)p.rows * N;
+  if (last) {
+    G.C = p.y; G.C2 = nullptr; G.act = -1;
+  } else {
+    G.C = p.Z ? p.Z[l + 1] : nullptr; G.C2 = p.H[l + 1]; G.act = n.act;
+  }
+  return G;
+}
+
+int layered_forward_multi(const LayeredFwd *passes, int n_pass, hipStream_t st) {
+  MBPO_REQUIRE(n_pass >= 1 && n_pass <= GROUP_MAX, MBPO_ERR_ARG, "layered_forward_multi: 1..%d passes", GROUP_MAX);
+  int maxL = 0;
+  for (int i = 0; i < n_pass; ++i) maxL = passes[i].net.L > maxL ? passes[i].net.L : maxL;
+  GemmBatch batch;
+  for (int l = 0; l < maxL; ++l) {
+    for (int i = 0; i < n_pass; ++i) {
+      const LayeredFwd &p = passes[i];
+      if (l >= p.net.L) continue;
+      const float *in = l == 0 ? p.x : p.H[l];
+      const long long zin = l == 0 ? p.zx : (long long)p.rows * p.net.dims[l];
+      int rc = batch.add(0, forward_args(p, l, in, zin));
+      if (rc != MBPO_OK) return rc;
     }
-    int rc = layered_gemm(0, G, st);
+    int rc = batch.flush(st);
     if (rc != MBPO_OK) return rc;
-    if (!last) { in = H[l + 1]; zin = (long long)rows * N; }
+  }
+  return MBPO_OK;
+}
+
+int layered_forward(const LayeredNet &n, const float *x, long long zx, int rows, float *const *Z, float *const *H, float *y, hipStream_t st) {
+  const LayeredFwd p = {n, x, zx, rows, Z, H, y};
+  return layered_forward_multi(&p, 1, st);
+}
+
+// Level s of the backward passes = layer l = L-1-s of each: its weight gradient and the input gradient below it both read dz_l only.
+int layered_backward_multi(const LayeredBwd *passes, int n_pass, hipStream_t st) {
+  MBPO_REQUIRE(n_pass >= 1 && 2 * n_pass <= GROUP_MAX, MBPO_ERR_ARG, "layered_backward_multi: 1..%d passes", GROUP_MAX / 2);
+  int maxL = 0;
+  const float *dz[GROUP_MAX];
+  int flip[GROUP_MAX];
+  for (int i = 0; i < n_pass; ++i) {
+    maxL = passes[i].net.L > maxL ? passes[i].net.L : maxL;
+    dz[i] = passes[i].dy;
+    flip[i] = 0;
+  }
+  GemmBatch batch;
+  for (int s = 0; s < maxL; ++s) {
+    bool any_split = false;
+    for (int i = 0; i < n_pass; ++i) {
+      const LayeredBwd &p = passes[i];
+      const LayeredNet &n = p.net;
+      const int l = n.L - 1 - s;
+      if (l < 0) continue;
+      const int K = n.dims[l], N = n.dims[l + 1], rows = p.rows;
+      int n_split, k_chunk;
+      split_of(rows, &n_split, &k_chunk);
+      if (p.dw) {
+        const float *in = l == 0 ? p.x : p.H[l];
+        const long long zin = l == 0 ? p.zx : (long long)rows * K;
+        // [dW; db](k, n) = sum_rows [in, 1](row, k) * dz(row, n): the GEMM's m = k (K + 1 rows, the last all ones), its k = minibatch rows
+        GemmArgs G = {};
+        G.A = in; G.sam = 1; G.sak = K; G.zA = zin; G.ones_row = 1;
+        G.B = dz[i]; G.sbk = N; G.sbn = 1; G.zB = (long long)rows * N;
+        G.M = K + 1; G.N = N; G.K = rows; G.nz = n.nz;
+        G.ldc = N;
+        if (n_split == 1) {
+          G.n_split = 1; G.C = p.dw + n.w_off[l]; G.zC = p.dw_stride;
+        } else {
+          G.n_split = n_split; G.k_chunk = k_chunk; G.C = p.part; G.zSplit = (long long)(K + 1) * N;
+          any_split = true;
+        }
+        int rc = batch.add(2, G);
+        if (rc != MBPO_OK) return rc;
+      }
+      if (l == 0 && !p.dx) continue;
+      // d in(row, k) = sum_n dz(row, n) * W(k, n), times act'(Z[l]) for a hidden layer's input
+      GemmArgs G = {};
+      G.A = dz[i]; G.sam = N; G.sak = 1; G.zA = (long long)rows * N;
+      G.B = n.params + n.w_off[l]; G.sbk = 1; G.sbn = N; G.zB = n.net_stride;
+      G.M = rows; G.N = K; G.K = N; G.nz = n.nz; G.n_split = 1;
+      G.ldc = K; G.zC = (long long)rows * K;
+      float *const out = flip[i] ? p.tmp1 : p.tmp0;
+      if (l == 0) {
+        G.C = p.dx; G.Zprev = nullptr; G.act = -1;
+      } else {
+        G.C = out; G.Zprev = p.Z[l]; G.ldz = K; G.zZ = (long long)rows * K; G.act = n.act;
+      }
+      int rc = batch.add(1, G);
+      if (rc != MBPO_OK) return rc;
+      if (l > 0) { dz[i] = out; flip[i] ^= 1; }
+    }
+    int rc = batch.flush(st);
+    if (rc != MBPO_OK) return rc;
+    if (any_split) {
+      // beyond 1024 rows a weight gradient's row range is split over workgroups: add this level's partials (fixed order) before the
+      // next level reuses the partial buffers
+      for (int i = 0; i < n_pass; ++i) {
+        const LayeredBwd &p = passes[i];
+        const int l = p.net.L - 1 - s;
+        if (l < 0 || !p.dw) continue;
+        int n_split, k_chunk;
+        split_of(p.rows, &n_split, &k_chunk);
+        if (n_split == 1) continue;
+        const long long sz = (long long)(p.net.dims[l] + 1) * p.net.dims[l + 1];
+        rc = layered_split_sum(p.part, sz, n_split, p.net.nz, p.dw + p.net.w_off[l], p.dw_stride, sz, st);
+        if (rc != MBPO_OK) return rc;
+      }
+    }
   }
   return MBPO_OK;
 }
 
 int layered_backward(const LayeredNet &n, const float *x, long long zx, int rows, float *const *Z, float *const *H, const float *dy,
                      float *dw, long long dw_stride, float *dx, float *tmp0, float *tmp1, float *part, hipStream_t st) {
-  const float *dz = dy;      // [nz][rows][dims[l+1]]
-  float *pp[2] = {tmp0, tmp1};
-  int flip = 0;
-  int n_split, k_chunk;
-  split_of(rows, &n_split, &k_chunk);
-  for (int l = n.L - 1; l >= 0; --l) {
-    const int K = n.dims[l], N = n.dims[l + 1];
-    if (dw) {
-      const float *in = l == 0 ? x : H[l];
-      const long long zin = l == 0 ? zx : (long long)rows * K;
-      // [dW; db](k, n) = sum_rows [in, 1](row, k) * dz(row, n): the GEMM's m = k (K + 1 rows, the last all ones), its k = minibatch rows
-      GemmArgs G = {};
-      G.A = in; G.sam = 1; G.sak = K; G.zA = zin; G.ones_row = 1;
-      G.B = dz; G.sbk = N; G.sbn = 1; G.zB = (long long)rows * N;
-      G.M = K + 1; G.N = N; G.K = rows; G.nz = n.nz;
-      G.ldc = N;
-      if (n_split == 1) {
-        G.n_split = 1; G.C = dw + n.w_off[l]; G.zC = dw_stride;
-      } else {
-        G.n_split = n_split; G.k_chunk = k_chunk; G.C = part; G.zSplit = (long long)(K + 1) * N;
-      }
-      int rc = layered_gemm(2, G, st);
-      if (rc != MBPO_OK) return rc;
-      if (n_split > 1) {
-        rc = layered_split_sum(part, (long long)(K + 1) * N, n_split, n.nz, dw + n.w_off[l], dw_stride, (long long)(K + 1) * N, st);
-        if (rc != MBPO_OK) return rc;
-      }
-    }
-    if (l == 0 && !dx) break;
-    // d in(row, k) = sum_n dz(row, n) * W(k, n), times act'(Z[l]) for a hidden layer's input
-    GemmArgs G = {};
-    G.A = dz; G.sam = N; G.sak = 1; G.zA = (long long)rows * N;
-    G.B = n.params + n.w_off[l]; G.sbk = 1; G.sbn = N; G.zB = n.net_stride;
-    G.M = rows; G.N = K; G.K = N; G.nz = n.nz; G.n_split = 1;
-    G.ldc = K; G.zC = (long long)rows * K;
-    if (l == 0) {
-      G.C = dx; G.Zprev = nullptr; G.act = -1;
-    } else {
-      G.C = pp[flip]; G.Zprev = Z[l]; G.ldz = K; G.zZ = (long long)rows * K; G.act = n.act;
-    }
-    int rc = layered_gemm(1, G, st);
-    if (rc != MBPO_OK) return rc;
-    if (l > 0) { dz = pp[flip]; flip ^= 1; }
-  }
-  return MBPO_OK;
+  const LayeredBwd p = {n, x, zx, rows, Z, H, dy, dw, dw_stride, dx, tmp0, tmp1, part};
+  return layered_backward_multi(&p, 1, st);
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI: any-shape MLP forward / VJP

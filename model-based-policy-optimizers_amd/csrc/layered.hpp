@@ -43,4 +43,19 @@ int layered_forward(const LayeredNet &n, const float *x, long long zx, int rows,
 int layered_backward(const LayeredNet &n, const float *x, long long zx, int rows, float *const *Z, float *const *H, const float *dy,
                      float *dw, long long dw_stride, float *dx, float *tmp0, float *tmp1, float *part, hipStream_t st);
 long long layered_part_floats(const LayeredNet &n, int rows);
+// Several passes advanced level by level, the problems of a level in ONE launch (round 4: the path is launch-bound).  Passes of one call
+// must not share output / scratch buffers (Z, H, y; tmp0, tmp1, part): they run side by side.
+struct LayeredFwd {
+  LayeredNet net;
+  const float *x; long long zx; int rows;
+  float *const *Z; float *const *H; float *y;
+};
+struct LayeredBwd {
+  LayeredNet net;
+  const float *x; long long zx; int rows;
+  float *const *Z; float *const *H; const float *dy;
+  float *dw; long long dw_stride; float *dx; float *tmp0, *tmp1, *part;
+};
+int layered_forward_multi(const LayeredFwd *passes, int n_pass, hipStream_t st);
+int layered_backward_multi(const LayeredBwd *passes, int n_pass, hipStream_t st);
 int layered_max_hidden(const LayeredNet &n);

@@ -128,7 +128,7 @@ struct Carve {
   }
 };
 struct Bufs {
-  float *x_all, *values, *outp, *dy_pi, *dy_v, *pp[2], *part, *extras;
+  float *x_all, *values, *outp, *dy_pi, *dy_v, *pp[2], *pq[2], *part, *part2, *extras;   // pp/part: policy pass, pq/part2: value pass
   int n_heads;
   float *Zv[MBPO_MAX_LAYERS + 1], *Hv[MBPO_MAX_LAYERS + 1], *Zp[MBPO_MAX_LAYERS + 1], *Hp[MBPO_MAX_LAYERS + 1];
 };
@@ -141,9 +141,10 @@ long long carve_all(float *base, const mbpo_ppo_desc *d, const LayeredNet &pi, c
   int mh = layered_max_hidden(pi);
   const int mv = layered_max_hidden(v);
   mh = mv > mh ? mv : mh;
-  b->pp[0] = c.take(R * mh); b->pp[1] = c.take(R * mh);
-  const long long pa = layered_part_floats(pi, (int)M), pb = layered_part_floats(v, (int)R);
-  b->part = c.take(pa > pb ? pa : pb);
+  b->pp[0] = c.take(M * mh); b->pp[1] = c.take(M * mh);
+  b->pq[0] = c.take(R * mh); b->pq[1] = c.take(R * mh);
+  b->part = c.take(layered_part_floats(pi, (int)M));
+  b->part2 = c.take(layered_part_floats(v, (int)R));
   b->n_heads = (int)((R + 255) / 256);
   b->extras = c.take(4LL * b->n_heads);
   return c.off;
@@ -164,7 +165,10 @@ int ppo_layered_values(const mbpo_ppo_desc *d, const MlpDev &pi, const MlpDev &v
   PrepArgs A = {d->data, d->norm_mean, d->norm_std, d->batch_size, d->unroll_length, d->row_len, d->x_dim, d->u_dim, d->reward_scaling,
                 b.x_all, trunc, term, rew, d->step_count};
   hipLaunchKernelGGL(k_ppol_prep, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, A);
-  int rc = layered_forward(nv, b.x_all, 0, (int)R, b.Zv, b.Hv, b.values, st);
+  // the value net on all R rows and — it depends on nothing the GAE / moments launches produce — the policy on the M loss rows, level by
+  // level in one launch each (ppo_layered_fwd_bwd of the same step finds outp / Zp / Hp in the workspace)
+  const LayeredFwd f[2] = {{nv, b.x_all, 0, (int)R, b.Zv, b.Hv, b.values}, {npi, b.x_all, 0, (int)M, b.Zp, b.Hp, b.outp}};
+  int rc = layered_forward_multi(f, 2, st);
   if (rc != MBPO_OK) return rc;
   *values_out = b.values;
   MBPO_CHECK_LAUNCH("ppo_layered_values");
@@ -177,17 +181,16 @@ int ppo_layered_fwd_bwd(const mbpo_ppo_desc *d, const MlpDev &pi, const MlpDev &
   Bufs b;
   carve_all(ws, d, npi, nv, &b);
   const long long M = (long long)d->batch_size * d->unroll_length, R = M + d->batch_size;
-  int rc = layered_forward(npi, b.x_all, 0, (int)M, b.Zp, b.Hp, b.outp, st);
-  if (rc != MBPO_OK) return rc;
+  int rc;       // the policy's forward pass ran beside the value net's in ppo_layered_values
   HeadArgs A = {d->data, b.outp, b.values, vs, adv, mom, d->entropy_noise, d->seed, d->offset, (const unsigned long long *)d->rng_dev,
                 d->batch_size, d->unroll_length, d->row_len, d->x_dim, d->u_dim, d->normalize_advantage, d->entropy_cost,
                 d->clipping_epsilon, b.dy_pi, b.dy_v, b.extras};
   hipLaunchKernelGGL(k_ppol_heads, dim3(b.n_heads), dim3(256), 0, st, A);
   *extras_out = b.extras;
   *n_extras_out = b.n_heads;
-  if ((rc = layered_backward(npi, b.x_all, 0, (int)M, b.Zp, b.Hp, b.dy_pi, slab, 0, nullptr, b.pp[0], b.pp[1], b.part, st)) != MBPO_OK) return rc;
-  if ((rc = layered_backward(nv, b.x_all, 0, (int)R, b.Zv, b.Hv, b.dy_v, slab + pi.n_params, 0, nullptr, b.pp[0], b.pp[1], b.part, st)) != MBPO_OK)
-    return rc;
+  const LayeredBwd g[2] = {{npi, b.x_all, 0, (int)M, b.Zp, b.Hp, b.dy_pi, slab, 0, nullptr, b.pp[0], b.pp[1], b.part},
+                           {nv, b.x_all, 0, (int)R, b.Zv, b.Hv, b.dy_v, slab + pi.n_params, 0, nullptr, b.pq[0], b.pq[1], b.part2}};
+  if ((rc = layered_backward_multi(g, 2, st)) != MBPO_OK) return rc;
   MBPO_CHECK_LAUNCH("ppo_layered_fwd_bwd");
   return MBPO_OK;
 }

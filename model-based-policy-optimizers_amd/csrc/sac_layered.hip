@@ -201,8 +201,8 @@ struct Bufs {
   float *xo, *xn, *qin_d, *qin_p, *qin_n, *outp, *outn;
   float *Zp[MBPO_MAX_LAYERS + 1], *Hp[MBPO_MAX_LAYERS + 1];
   float *Zqd[MBPO_MAX_LAYERS + 1], *Hqd[MBPO_MAX_LAYERS + 1], *Zqp[MBPO_MAX_LAYERS + 1];
-  float *pp[2];
-  float *qd, *qp, *qn, *lp_alpha, *lp_next, *lp_actor, *eps_actor, *dqd, *dqp, *dqin, *doutp, *part;
+  float *pp[2], *pq[2], *pr[2];      // per-pass scratch: passes of one level run side by side in one launch
+  float *qd, *qp, *qn, *lp_alpha, *lp_next, *lp_actor, *eps_actor, *dqd, *dqp, *dqin, *doutp, *part, *part2;
 };
 
 long long carve_all(float *base, const mbpo_sac_desc *d, const LayeredNet &pi, const LayeredNet &q, Bufs *b) {
@@ -219,11 +219,14 @@ long long carve_all(float *base, const mbpo_sac_desc *d, const LayeredNet &pi, c
   const int mq = layered_max_hidden(q);
   mh = mq > mh ? mq : mh;
   b->pp[0] = c.take(2 * B * mh); b->pp[1] = c.take(2 * B * mh);
+  b->pq[0] = c.take(2 * B * mh); b->pq[1] = c.take(2 * B * mh);
+  b->pr[0] = c.take(2 * B * mh); b->pr[1] = c.take(2 * B * mh);
   b->qd = c.take(2 * B); b->qp = c.take(2 * B); b->qn = c.take(2 * B);
   b->lp_alpha = c.take(B); b->lp_next = c.take(B); b->lp_actor = c.take(B); b->eps_actor = c.take(B * U);
   b->dqd = c.take(2 * B); b->dqp = c.take(2 * B); b->dqin = c.take(2 * B * XU); b->doutp = c.take(B * 2 * U);
   const long long pa = layered_part_floats(pi, (int)B), pb = layered_part_floats(q, (int)B);
   b->part = c.take(pa > pb ? pa : pb);
+  b->part2 = c.take(pb);
   return c.off;
 }
 }  // namespace
@@ -247,30 +250,36 @@ int sac_layered_fwd_bwd(const mbpo_sac_desc *d, const MlpDev &pi, const MlpDev &
     PrepArgs A = {d->batch, d->norm_mean, d->norm_std, B, d->row_len, X, U, b.xo, b.xn, b.qin_d, b.qin_p, b.qin_n, bg};
     hipLaunchKernelGGL(k_sacl_prep, dim3(rb), dim3(256), 0, st, A);
   }
-  // policy(obs) with stored activations, policy(next_obs) without
-  float *ping[MBPO_MAX_LAYERS + 1];
-  for (int l = 0; l <= MBPO_MAX_LAYERS; ++l) ping[l] = b.pp[l & 1];
-  if ((rc = layered_forward(npi, b.xo, 0, B, b.Zp, b.Hp, b.outp, st)) != MBPO_OK) return rc;
-  if ((rc = layered_forward(npi, b.xn, 0, B, nullptr, ping, b.outn, st)) != MBPO_OK) return rc;
+  // policy(obs) with stored activations and policy(next_obs) without: the two passes of a level in one launch
+  float *ping[MBPO_MAX_LAYERS + 1], *pinq[MBPO_MAX_LAYERS + 1], *pinr[MBPO_MAX_LAYERS + 1];
+  for (int l = 0; l <= MBPO_MAX_LAYERS; ++l) { ping[l] = b.pp[l & 1]; pinq[l] = b.pq[l & 1]; pinr[l] = b.pr[l & 1]; }
+  {
+    const LayeredFwd f[2] = {{npi, b.xo, 0, B, b.Zp, b.Hp, b.outp}, {npi, b.xn, 0, B, nullptr, ping, b.outn}};
+    if ((rc = layered_forward_multi(f, 2, st)) != MBPO_OK) return rc;
+  }
   {
     SampleArgs A = {b.outp, b.outn, d->noise_alpha, d->noise_critic, d->noise_actor, d->seed, d->offset,
                     (const unsigned long long *)d->rng_dev, B, X, U, b.qin_p, b.qin_n, b.lp_alpha, b.lp_next, b.lp_actor, b.eps_actor};
     hipLaunchKernelGGL(k_sacl_sample, dim3(rb), dim3(256), 0, st, A);
   }
-  // the two critics on (s, a) [stored], on (s, a~pi) [pre-activations stored], the two target critics on (s', a')
-  if ((rc = layered_forward(nq, b.qin_d, 0, B, b.Zqd, b.Hqd, b.qd, st)) != MBPO_OK) return rc;
-  if ((rc = layered_forward(nq, b.qin_p, 0, B, b.Zqp, ping, b.qp, st)) != MBPO_OK) return rc;
-  if ((rc = layered_forward(nqt, b.qin_n, 0, B, nullptr, ping, b.qn, st)) != MBPO_OK) return rc;
+  // the two critics on (s, a) [stored], on (s, a~pi) [pre-activations stored], the two target critics on (s', a'): three passes per level
+  {
+    const LayeredFwd f[3] = {{nq, b.qin_d, 0, B, b.Zqd, b.Hqd, b.qd}, {nq, b.qin_p, 0, B, b.Zqp, pinq, b.qp}, {nqt, b.qin_n, 0, B, nullptr, pinr, b.qn}};
+    if ((rc = layered_forward_multi(f, 3, st)) != MBPO_OK) return rc;
+  }
   {
     LossArgs A = {d->batch, b.qd, b.qp, b.qn, b.lp_alpha, b.lp_next, b.lp_actor, d->params + P + 2 * Q, B, d->row_len, X, U,
                   d->discounting, d->reward_scaling, d->target_entropy, d->non_equidistant_time, d->continuous_discounting,
                   d->min_time_between_switches, d->max_time_between_switches, d->env_dt, b.dqd, b.dqp, slab_ex};
     hipLaunchKernelGGL(k_sacl_losses, dim3(1), dim3(1024), 0, st, A);
   }
-  // critic loss -> critic parameters
-  if ((rc = layered_backward(nq, b.qin_d, 0, B, b.Zqd, b.Hqd, b.dqd, slab_q, Q, nullptr, b.pp[0], b.pp[1], b.part, st)) != MBPO_OK) return rc;
-  // actor loss -> the action through the (old) critics -> the policy's outputs -> policy parameters
-  if ((rc = layered_backward(nq, b.qin_p, 0, B, b.Zqp, nullptr, b.dqp, nullptr, 0, b.dqin, b.pp[0], b.pp[1], b.part, st)) != MBPO_OK) return rc;
+  // critic loss -> critic parameters, and (side by side) actor loss -> the action through the (old) critics
+  {
+    const LayeredBwd g[2] = {{nq, b.qin_d, 0, B, b.Zqd, b.Hqd, b.dqd, slab_q, Q, nullptr, b.pp[0], b.pp[1], b.part},
+                             {nq, b.qin_p, 0, B, b.Zqp, nullptr, b.dqp, nullptr, 0, b.dqin, b.pq[0], b.pq[1], b.part2}};
+    if ((rc = layered_backward_multi(g, 2, st)) != MBPO_OK) return rc;
+  }
+  // -> the policy's outputs -> policy parameters
   {
     ActorHeadArgs A = {b.dqin, b.outp, b.eps_actor, d->params + P + 2 * Q, B, X, U, b.doutp};
     hipLaunchKernelGGL(k_sacl_actor_head, dim3(rb), dim3(256), 0, st, A);
