@@ -15,6 +15,7 @@
 // Algorithmic FLOP per (trajectory, step): 3*(2P) + 2*(2*E*M) + 2*(2*2V)  (SURVEY §8d).
 #include "common.hpp"
 #include "chain_run.hpp"
+#include <stdlib.h>
 #include <string.h>
 
 #define LOG_SQRT_2PI_B 0.91893853320467274178f
@@ -31,6 +32,7 @@ struct BpttArgs {
   float c0, discount, lambda_, ent_coef;
   float *transitions, *lambda_values;
   float *w_xs, *w_as, *w_eps, *w_rs, *w_vs, *w_km;
+  float *w_z;                    // member pre-activations of the forward sweep, [tile][t][member][hidden layer][16][64], or NULL (recompute)
   float *slabs, *extras;
   int ld_x, ld_xu, ld_h, ld_y, ld_ye, LH, EC;
   NetShape sh_pi, sh_cr, sh_dyn;
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
           else if (op == 1) { run = R_RECOMP; elem = E_DV; }
           else if (op == 2) { run = R_CR_DG; elem = E_GXACC; }
           else if (op < nB - 2) {
-            if (ens) { rr = om >> 1; run = (om & 1) ? R_ENS_DG : R_ENS_REFWD; elem = (om & 1) ? E_DXUACC : E_DYE; }
+            if (ens) { rr = om >> 1; run = (om & 1) ? R_ENS_DG : (A.w_z ? R_NONE : R_ENS_REFWD); elem = (om & 1) ? E_DXUACC : E_DYE; }
             else { elem = E_PENDVJP; }
           } else if (op == nB - 2) { elem = E_LOGITS; }
           else { run = R_PI_BWD; elem = E_GXFINAL; }
@@ -272,12 +274,12 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
             sh = A.sh_dyn;
             cparams = A.dyn.params + (long long)e * A.dyn.net_stride;
             cldy = ld_ye;
-            if (run == R_ENS_FWD) {
+            if (run == R_ENS_FWD && !A.w_z) {
               mode = CH_FWD; cx = o_xu; cldx = ld_xu; cpp0 = o_B + chain2 * 2 * T; cpp1 = cpp0 + T; cy = o_ye + chain2 * 16 * ld_ye;
             } else {
               const int ze = o_B + chain2 * (LH + 2) * T;
               czb = ze; cpp0 = ze + LH * T; cpp1 = cpp0 + T;
-              if (run == R_ENS_REFWD) { mode = CH_FWD; cx = o_xu; cldx = ld_xu; cy = o_ye + chain2 * 16 * ld_ye; }
+              if (run != R_ENS_DG) { mode = CH_FWD; cx = o_xu; cldx = ld_xu; cy = o_ye + chain2 * 16 * ld_ye; }
               else { mode = CH_DGRAD; cy = o_dye + chain2 * 16 * ld_ye; cdx = o_dxe + chain2 * 16 * ld_xu; cld_dx = ld_xu; }
             }
           }
@@ -358,6 +360,19 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
             float acc = 0.f;
             for (int cc = 0; cc < EC && rr * EC + cc < E; ++cc) acc += s_ye[(cc * 16 + r) * ld_ye + c];
             s_xn[r * ld_x + c] += acc / (float)E;
+          }
+          if (A.w_z) {
+            // the round's pre-activation tiles -> global memory: the backward sweep reloads them instead of running the members'
+            // forward pass a second time (round 4: that recompute was 22 % of a horizon step at E = 10)
+            // (tile m = cc * nz + l of the round is 4 KB at round base + 4 KB * m: members are consecutive in the store)
+            const int nz = DL - 1, cnt = (E - rr * EC) < EC ? (E - rr * EC) : EC, total = cnt * nz * 256;
+            float *const zg = A.w_z + ((((tile * HZ + t) * E + rr * EC) * nz) << 10);
+            for (int idx = tid; idx < total; idx += nthreads) {
+              const int m = idx >> 8, q = idx & 255;
+              const int cc = (m >= nz) + (m >= 2 * nz) + (m >= 3 * nz), l = m - cc * nz;
+              *reinterpret_cast<f32x4 *>(zg + 4 * idx) =
+                  *reinterpret_cast<const f32x4 *>(smem + o_B + cc * (LH + 2) * T + l * T + (q >> 4) * ld_h + 4 * (q & 15));
+            }
           }
         } else if (elem == E_PEND) {
           if (tid < 16) {
@@ -469,11 +484,24 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
             s_dxu[r * ld_xu + X + d] = 0.f;
           }
         } else if (elem == E_DYE) {
+          if (A.w_z) {
+            // straight into LDS, one 256-byte tile row per wave instruction (global_load_lds_dword: wave-uniform LDS base + 4 * lane,
+            // so a padded row is exactly one instruction); no data registers, every row of the round in flight at once; the op's
+            // closing __syncthreads() waits for them (vmcnt(0))
+            const int nz = DL - 1, cnt = (E - rr * EC) < EC ? (E - rr * EC) : EC, rows = cnt * nz * 16;
+            const float *const zg = A.w_z + ((((tile * HZ + t) * E + rr * EC) * nz) << 10);
+            for (int rix = wave; rix < rows; rix += (nthreads >> 6)) {
+              const int m = rix >> 4, r = rix & 15;
+              const int cc = (m >= nz) + (m >= 2 * nz) + (m >= 3 * nz), l = m - cc * nz;
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) float *)(zg + rix * 64 + lane),
+                                               (__attribute__((address_space(3))) float *)(smem + o_B + cc * (LH + 2) * T + l * T + r * ld_h), 4, 0, 0);
+            }
+          }
           const int dout = A.dyn.dims[DL];
-          for (int idx = tid; idx < EC * 16 * dout; idx += nthreads) {
-            const int cc = idx / (16 * dout), rem = idx - cc * 16 * dout;
-            const int r = rem / dout, c = rem - r * dout;
-            s_dye[(cc * 16 + r) * ld_ye + c] = c < X ? s_gx[r * ld_x + c] / (float)E : 0.f;   // x' = base + mean_e mu_e
+          for (int idx = tid; idx < 16 * dout; idx += nthreads) {
+            const int r = idx / dout, c = idx - r * dout;
+            const float v = c < X ? s_gx[r * ld_x + c] / (float)E : 0.f;   // x' = base + mean_e mu_e: the same for every member
+            for (int cc = 0; cc < EC; ++cc) s_dye[(cc * 16 + r) * ld_ye + c] = v;
           }
         } else if (elem == E_DXUACC) {
           for (int idx = tid; idx < 16 * (X + U); idx += nthreads) {
@@ -582,7 +610,7 @@ struct BpttPlan {
   int P, C, H, LH, EC, n_slabs;
   int ld_x, ld_xu, ld_h, ld_y, ld_ye;
   size_t lds;
-  long long o_xs, o_as, o_eps, o_rs, o_vs, o_km, o_slabs, o_extras, total;
+  long long o_xs, o_as, o_eps, o_rs, o_vs, o_km, o_z, o_slabs, o_extras, total;
 };
 
 static int bptt_hidden(const int *dims, int n_layers) {
@@ -686,6 +714,15 @@ static int bptt_plan(const mbpo_bptt_desc *d, BpttPlan *pl, bool need_ptrs) {
   pl->o_rs = take(d->n * d->horizon);
   pl->o_vs = take(d->n * d->horizon);
   pl->o_km = take(d->n * d->horizon);
+  // member pre-activations kept from the forward sweep (the backward sweep then skips the members' recompute): 4 KB per (trajectory
+  // tile, step, member, hidden layer) — 1 GB at BASELINE config 5 (n = 4096, H = 32, E = 10); beyond MBPO_BPTT_ZSTORE_MAX_MB (default
+  // 16384) the kernel recomputes instead
+  pl->o_z = -1;
+  if (E > 0) {
+    static const long long max_mb = getenv("MBPO_BPTT_ZSTORE_MAX_MB") ? atoll(getenv("MBPO_BPTT_ZSTORE_MAX_MB")) : 16384;
+    const long long zf = tiles * d->horizon * E * (pl->dyn.n_layers - 1) * 1024;
+    if (zf * 4 <= max_mb * (1LL << 20)) pl->o_z = take(zf);
+  }
   pl->o_slabs = take((long long)pl->n_slabs * pl->P);
   pl->o_extras = take((long long)pl->n_slabs * 2);
   pl->total = o;
@@ -720,7 +757,7 @@ extern "C" int mbpo_bptt_actor_grads(const mbpo_bptt_desc *d, void *stream) {
   A.transitions = d->transitions; A.lambda_values = d->lambda_values;
   float *ws = d->workspace;
   A.w_xs = ws + pl.o_xs; A.w_as = ws + pl.o_as; A.w_eps = ws + pl.o_eps; A.w_rs = ws + pl.o_rs; A.w_vs = ws + pl.o_vs;
-  A.w_km = ws + pl.o_km; A.slabs = ws + pl.o_slabs; A.extras = ws + pl.o_extras;
+  A.w_km = ws + pl.o_km; A.w_z = pl.o_z >= 0 ? ws + pl.o_z : nullptr; A.slabs = ws + pl.o_slabs; A.extras = ws + pl.o_extras;
   A.ld_x = pl.ld_x; A.ld_xu = pl.ld_xu; A.ld_h = pl.ld_h; A.ld_y = pl.ld_y; A.ld_ye = pl.ld_ye; A.LH = pl.LH; A.EC = pl.EC;
   A.stamps = g_bptt_stamps;
   A.sh_pi = NetShape{A.pi.dims[0], A.pi.n_layers, A.pi.dims[A.pi.n_layers], A.pi.act};
