@@ -288,3 +288,35 @@ def test_rollout_philox_noise_matches_oracle(dev):
                                  policy_noise=noise.to(dev) if use_explicit else None, seed=seed, offset=offset)
         outs.append(rows.cpu())
     torch.testing.assert_close(outs[0], outs[1], atol=1e-5, rtol=1e-5)
+
+
+def _set_rollout_lean(mode: int) -> None:
+    import ctypes as C
+    from mbpo import _hip
+    lib = _hip.load()
+    lib.mbpo_debug_set_rollout_lean.argtypes = [C.c_int]
+    lib.mbpo_debug_set_rollout_lean.restype = C.c_int
+    assert lib.mbpo_debug_set_rollout_lean(mode) == 0
+
+
+@pytest.mark.parametrize("kw", [
+    dict(N=512, S=5, L=5, X=4, system="ensemble", E=5, mode="mean", normalize=True),            # BASELINE configs[1]
+    dict(N=4800, S=5, L=3, X=4, system="ensemble", E=5, mode="mean"),                           # more tiles than CUs, episode wrap
+    dict(N=77, S=6, L=4, X=4, system="ensemble", E=5, mode="ts1", sample_noise=True),           # ragged tile, sampled member + noise
+    dict(N=130, S=5, L=5, X=3, system="ensemble", E=3, mode="tsinf", ppo=True, env_major=True, normalize=True),
+    dict(N=100, S=7, L=5, X=3, system="pendulum"),
+    dict(N=128, S=40, L=40, X=3, system="pendulum", ppo=True, env_major=True, normalize=True, atol=2e-3),   # BASELINE configs[2] layout
+    dict(N=33, S=4, L=9, X=4, system="ensemble", E=1, mode="mean", deterministic=True),
+])
+def test_rollout_lean_equals_generic_kernel(dev, kw):
+    """k_rollout_lean (csrc/rollout_lean.hip: weights resident in registers, 16-byte activation stores, one bookkeeping section per
+    step) forms every dot product with the generic k_model_rollout64's MFMA sequence and every elementwise value with its expressions:
+    rows identical bit for bit (each run is also checked against the oracle inside _run_rollout_case)."""
+    try:
+        _set_rollout_lean(0)
+        rows_g = _run_rollout_case(dev, AR=1, U=1, **kw)
+        _set_rollout_lean(1)
+        rows_l = _run_rollout_case(dev, AR=1, U=1, **kw)
+    finally:
+        _set_rollout_lean(-1)
+    assert torch.equal(rows_g, rows_l)
