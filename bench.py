@@ -585,7 +585,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_us": t_kernel * 1e6, "algorithmic_flop_per_launch": BATCH * flop_per_sample,
                          "launches_per_step": GRAD_UPDATES},
-            "rollout_kernel": {"kernel": "k_model_rollout64", "avg_launch_us": t_roll * 1e6,
+            "rollout_kernel": {"kernel": "k_rollout_lean<4,false>", "avg_launch_us": t_roll * 1e6,
                                "transitions_per_s_alone": N_ENVS * S_STEPS / t_roll,
                                "achieved_tflops": N_ENVS * S_STEPS * flop_per_transition / t_roll / 1e12,
                                "frac_of_fp32_mfma_peak": N_ENVS * S_STEPS * flop_per_transition / t_roll / 1e12 / FP32_MFMA_PEAK_TFLOPS},

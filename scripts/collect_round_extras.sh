@@ -23,5 +23,9 @@ timeout -k 10 200 python scripts/lean_dev.py > gpurun_out/${T}_sac_lean_stamps.t
 timeout -k 10 200 python scripts/ppo_lean_dev.py > gpurun_out/${T}_ppo_lean_stamps.txt 2>&1
 timeout -k 10 200 python scripts/step_flavours.py > gpurun_out/${T}_step_flavours.txt 2>&1
 timeout -k 10 200 python scripts/sac_phase_stamps.py 128,128,128 > gpurun_out/${T}_sac_stamps_128.txt 2>&1
+timeout -k 10 200 python scripts/rollout_lean_dev.py > gpurun_out/${T}_rollout_lean_stamps.txt 2>&1
 timeout -k 10 200 python scripts/rollout_phase_stamps.py > gpurun_out/${T}_rollout_stamps.txt 2>&1
+timeout -k 10 200 python scripts/bptt_op_stamps.py > gpurun_out/${T}_bptt_op_stamps.txt 2>&1
+timeout -k 10 200 python scripts/layered_timing.py > gpurun_out/${T}_layered_timing.txt 2>&1
+timeout -k 10 200 python scripts/layered_ppo_timing.py > gpurun_out/${T}_layered_ppo_timing.txt 2>&1
 tail -3 gpurun_out/${T}_sac_lean_stamps.txt

@@ -46,7 +46,7 @@ def main(src: str, out: str, what: str = "python3 bench.py --steps 6 --warmup 2 
                   "SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU (scripts/collect_pmc_sq.sh, scripts/collect_round_extras.sh) of `" + what + "`; averages per dispatch",
         "file": f.name, "kernels": kernels}, indent=1))
     for k in kernels:
-        if any(s in k for s in ("sac_fwd", "sac_lean", "reduce_apply", "rollout64", "ppo_lean", "ppo_values", "bptt_actor", "critic_fwd")):
+        if any(s in k for s in ("sac_fwd", "sac_lean", "reduce_apply", "rollout64", "rollout_lean", "ppo_lean", "ppo_values", "bptt_actor", "critic_fwd")):
             print(k, json.dumps(kernels[k]))
 
 

@@ -21,7 +21,12 @@ cp $(ls -t gpurun_out/pmc_sq/runc/*counter_collection.csv | head -1) profiles/pm
 (echo "== scripts/lean_dev.py: k_sac_lean<4> against the generic k_sac_fwd_bwd<64,4,false,2,true> (bit identity, device time per launch / per two-launch update, s_memtime timeline of tile 0)"; grep -v amdgpu.ids gpurun_out/${T}_sac_lean_stamps.txt
  echo; echo "== scripts/ppo_lean_dev.py: k_ppo_lean<4> against the generic k_ppo_fwd_bwd<64,2> (BASELINE config 3 minibatch; per-tile timeline of workgroup 0)"; grep -v amdgpu.ids gpurun_out/${T}_ppo_lean_stamps.txt
  echo; echo "== scripts/sac_phase_stamps.py 128,128,128 (k_sac_fwd_bwd<128,4,false,2>)"; tail -22 gpurun_out/${T}_sac_stamps_128.txt
- echo; echo "== scripts/rollout_phase_stamps.py"; grep -v amdgpu.ids gpurun_out/${T}_rollout_stamps.txt) > profiles/${T}_phase_stamps.txt
+ echo; echo "== scripts/rollout_lean_dev.py: k_rollout_lean<4,false> against the generic k_model_rollout64 (device time per launch, bit identity, timeline of env step 1)"; grep -v amdgpu.ids gpurun_out/${T}_rollout_lean_stamps.txt
+ echo; echo "== scripts/rollout_phase_stamps.py (the generic k_model_rollout64)"; grep -v amdgpu.ids gpurun_out/${T}_rollout_stamps.txt
+ echo; echo "== scripts/bptt_op_stamps.py (k_bptt_actor, cycles per op kind)"; grep -v amdgpu.ids gpurun_out/${T}_bptt_op_stamps.txt
+ echo; echo "== scripts/step_flavours.py (SAC update, one rank, per step flavour)"; grep -v amdgpu.ids gpurun_out/${T}_step_flavours.txt
+ echo; echo "== scripts/layered_timing.py (SAC sgd_step per network shape; fused kernels and the layered path)"; grep -v amdgpu.ids gpurun_out/${T}_layered_timing.txt
+ echo; echo "== scripts/layered_ppo_timing.py"; grep -v amdgpu.ids gpurun_out/${T}_layered_ppo_timing.txt) > profiles/${T}_phase_stamps.txt
 tail -2 gpurun_out/tests_gpu.log
 python - <<PY
 import json

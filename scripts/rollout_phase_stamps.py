@@ -1,4 +1,5 @@
-"""Section timeline of k_model_rollout64 (tile 0, env step 1) from in-kernel s_memtime stamps; bench-shaped rollout."""
+"""Section timeline of the generic k_model_rollout64 (tile 0, env step 1) from in-kernel s_memtime stamps; bench-shaped rollout.
+The benchmark networks run k_rollout_lean by default (its timeline: scripts/rollout_lean_dev.py); this script pins the generic kernel."""
 import ctypes as C, sys, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'model-based-policy-optimizers_amd')
 from mbpo import ops, _hip
@@ -11,6 +12,8 @@ pp = (torch.randn(pol.total_params, generator=g) * 0.1).to(dev)
 dp = (torch.randn(dyn.total_params, generator=g) * 0.05).to(dev)
 rp = torch.cat([torch.zeros(X), torch.ones(X), 0.1 * torch.ones(U)]).to(dev)
 lib = _hip.load()
+lib.mbpo_debug_set_rollout_lean.argtypes = [C.c_int]
+lib.mbpo_debug_set_rollout_lean(0)
 stamps = torch.zeros(16, dtype=torch.int64, device=dev)
 names = ["A: inputs (normalise, first-layer request)", "policy chain", "B: sample action, member first-layer request", "model chains (all members, one round)",
          "C: member mean, reward, next state", "D: episode bookkeeping, auto-reset", "row write-out"]
