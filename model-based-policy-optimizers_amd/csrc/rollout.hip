@@ -434,7 +434,8 @@ struct RolloutArgs64 {
 
 static unsigned long long *g_ro_stamps = nullptr;
 static int g_ro_lean = -1;
-// Diagnostic switch (not part of include/mbpo_hip.h): 1 / 0 force the specialised / the generic 64-wide rollout kernel, -1 = default.
+// Diagnostic switch (not part of include/mbpo_hip.h): 0 the generic 64-wide rollout kernel, 1 the specialised one, 2 / 3 the specialised one
+// with two tiles in flight per workgroup forced on / off, -1 = default.
 extern "C" int mbpo_debug_set_rollout_lean(int mode) {
   g_ro_lean = mode;
   return MBPO_OK;
@@ -848,14 +849,20 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
     // the kernel specialised for the benchmark networks (rollout_lean.hip): MBPO_ROLLOUT_LEAN=0 / mbpo_debug_set_rollout_lean(0) keep the
     // generic one
     static const int env_lean = getenv("MBPO_ROLLOUT_LEAN") ? atoi(getenv("MBPO_ROLLOUT_LEAN")) : 1;
-    if ((g_ro_lean >= 0 ? g_ro_lean : env_lean) && rollout_lean_supports(A, has_policy, E)) {
+    const int lean_mode = g_ro_lean >= 0 ? g_ro_lean : env_lean;      // 0 generic, 1 lean, 2 lean + two tiles in flight forced, 3 lean without
+    if (lean_mode && rollout_lean_supports(A, has_policy, E)) {
       RoLeanArgs L;
       L.a = A;
       L.E = E;
       L.n_dyn_out = dyn_out;
       L.stamps = g_ro_stamps;
-      const int lgrid = (int)(n_tiles < (long long)num_cus() ? n_tiles : (long long)num_cus());
-      rc = rollout_lean_launch(L, lgrid, stream);
+      // two tiles in flight per workgroup once every CU has at least two (MBPO_ROLLOUT_PIPE=0/1 forces it off / on)
+      static const int env_pipe = getenv("MBPO_ROLLOUT_PIPE") ? atoi(getenv("MBPO_ROLLOUT_PIPE")) : -1;
+      const int pipe_force = lean_mode == 2 ? 1 : (lean_mode == 3 ? 0 : env_pipe);
+      const bool pipe = E > 0 && (pipe_force >= 0 ? pipe_force != 0 : n_tiles >= 2LL * num_cus());
+      const long long units = pipe ? (n_tiles + 1) / 2 : n_tiles;
+      const int lgrid = (int)(units < (long long)num_cus() ? units : (long long)num_cus());
+      rc = rollout_lean_launch(L, lgrid, pipe, stream);
       if (rc != MBPO_OK) return rc;
       MBPO_CHECK_LAUNCH("model_rollout");
       return MBPO_OK;

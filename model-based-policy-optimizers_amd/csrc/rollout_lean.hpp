@@ -13,4 +13,5 @@ struct RoLeanArgs {
 // policy x -> 64 -> 64 -> 64 -> 2 (swish), u = 1, x in {3, 4}; Pendulum system, or <= 5 members (x + 1) -> 64 -> 64 -> 64 -> (x | 2x)
 // (swish); action_repeat 1; closed loop (no open-loop actions)
 bool rollout_lean_supports(const RolloutArgs &A, bool has_policy, int E);
-int rollout_lean_launch(const RoLeanArgs &A, int grid, void *stream);
+// pipe: two tiles in flight per workgroup (members only; grid = workgroups, each walking PAIRS of tiles)
+int rollout_lean_launch(const RoLeanArgs &A, int grid, bool pipe, void *stream);

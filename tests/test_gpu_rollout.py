@@ -307,6 +307,8 @@ def _set_rollout_lean(mode: int) -> None:
     dict(N=100, S=7, L=5, X=3, system="pendulum"),
     dict(N=128, S=40, L=40, X=3, system="pendulum", ppo=True, env_major=True, normalize=True, atol=2e-3),   # BASELINE configs[2] layout
     dict(N=33, S=4, L=9, X=4, system="ensemble", E=1, mode="mean", deterministic=True),
+    dict(N=9000, S=3, L=2, X=4, system="ensemble", E=5, mode="mean", normalize=True),          # 563 tiles: the default picks two in flight
+    dict(N=16, S=1, L=5, X=4, system="ensemble", E=2, mode="mean"),                           # one tile, one step
 ])
 def test_rollout_lean_equals_generic_kernel(dev, kw):
     """k_rollout_lean (csrc/rollout_lean.hip: weights resident in registers, 16-byte activation stores, one bookkeeping section per
@@ -315,8 +317,11 @@ def test_rollout_lean_equals_generic_kernel(dev, kw):
     try:
         _set_rollout_lean(0)
         rows_g = _run_rollout_case(dev, AR=1, U=1, **kw)
-        _set_rollout_lean(1)
+        _set_rollout_lean(3)                      # one tile per workgroup at a time
         rows_l = _run_rollout_case(dev, AR=1, U=1, **kw)
+        _set_rollout_lean(2)                      # two tiles in flight per workgroup (policy of one beside the members of the other)
+        rows_p = _run_rollout_case(dev, AR=1, U=1, **kw)
     finally:
         _set_rollout_lean(-1)
     assert torch.equal(rows_g, rows_l)
+    assert torch.equal(rows_g, rows_p)
