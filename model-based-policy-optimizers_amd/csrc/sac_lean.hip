@@ -26,6 +26,15 @@
 //
 // Roles as in the generic kernel's `split` launch: 3 workgroups per 16-sample tile — critic 0, actor(+alpha), critic 1; 8 waves =
 // 2 chains x 4 waves; forward-mode dQ/da in the actor role (the tangent rides along the critics' forward pass).
+//
+// Measured and NOT kept (round 4, scripts/lean_dev.py, same box): the hidden-layer images staged through LDS instead of requested by
+// every chain wave as strided dwords — (a) by the two idle auxiliary waves with global_load_lds_dwordx4 (33 x 1 KB per network, raw
+// barriers around the copies in flight): 13.6 us per launch against 11.3 — the LDS-DMA copies of 66 KB take > 4 k cycles on a CU and
+// the barrier behind them waits; (b) by all eleven waves, six coalesced 16-byte requests per thread, stored to LDS behind the first
+// barrier: 12.0 us — the thin-layer step then ends 9 k cycles after the kernel's start.  Caveat for both: the critics' blocks start at
+// odd float offsets of the flat layout (P = 8770, Q = 8769 at x = 4), so half of the 16-byte requests were 4- or 8-byte aligned; a
+// dword-granular copy (4 x the instructions) was not tried.  The kernel costs the same back to back on L2-warm parameters as behind
+// the optimizer launch (11.3 us both), so the prologue is not a cold-miss problem either; the per-wave strided requests stay.
 #include "common.hpp"
 #include "chain_run.hpp"
 #include "lean_blocks.hpp"
