@@ -248,7 +248,13 @@ def bptt_c5_extra(device, steps=(6, 26)):
     tb = UniformSamplingQueue(rows, dummy, 1, device=device)
     tbs = tb.insert_rows(tb.init(0), torch.cat([obs, torch.zeros(rows, U), torch.zeros(rows, 1), torch.ones(rows, 1), obs], dim=1).to(device))
     times = {k: float("inf") for k in steps}
-    for k in (*steps, *steps):       # each length twice, the faster run counts: one slow first call (page-in, allocator) once gave 0.8 ms
+    # Each length three times, the fastest run counts, and every run starts from the same allocator state: the actor kernel's workspace
+    # is 1 GB at this shape (the members' pre-activations), and a run that has to hipMalloc it while the other length reuses a cached
+    # block biased the difference (one bench run printed 2.96 ms per step against 4.0 ms for the actor gradient alone).
+    import gc
+    for k in (*steps, *steps, *steps):
+        gc.collect()
+        torch.cuda.empty_cache()
         opt = BPTTOptimizer(action_dim=U, obs_dim=X, horizon=H, num_samples_per_gradient_update=n, train_steps=k,
                             critic_updates_per_policy_update=1, sampling_buffer_size=rows + (max(steps) + 2) * n * H)
         opt.set_system(system)
