@@ -38,11 +38,16 @@ __device__ __forceinline__ void p2p_push(const P2pDev &P, unsigned epoch, long l
   if (i < n) {
     for (int p = 0; p < P.world; ++p) __builtin_nontemporal_store(v, P.slots[p] + off);
   }
-  __threadfence_system();
+  // Publish: every wave drains its own stores (the barrier's s_waitcnt vmcnt(0)), then ONE release at system scope by the first wave
+  // covers the workgroup's stores, and lanes 0..world-1 of that wave add the arrival to THEIR peer's counter side by side — relaxed,
+  // results unused.  (Rounds 1-3 fenced in every thread and then let one thread issue `world` release-ordered adds one after the
+  // other: each of those waits for the previous remote add to complete before its own fence retires — `world` xGMI round trips in a
+  // row per workgroup, invisible with two ranks on one GPU and an order of magnitude over the latency budget of DESIGN section 6.)
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int p = 0; p < P.world; ++p)
-      __hip_atomic_fetch_add(P.flags[p] + P.rank * P2P_FLAG_STRIDE, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x < 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if ((int)threadIdx.x < P.world)
+      __hip_atomic_fetch_add(P.flags[threadIdx.x] + P.rank * P2P_FLAG_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -50,24 +55,31 @@ __device__ __forceinline__ void p2p_push(const P2pDev &P, unsigned epoch, long l
 // rank have arrived here.  Returns false on timeout (block-uniform).
 __device__ __forceinline__ bool p2p_wait(const P2pDev &P, unsigned want) {
   __shared__ int s_p2p_ok;
-  if (threadIdx.x == 0) {
-    // a timeout is sticky: once this rank has given up on an exchange every later wait fails at once (the host sees the
-    // status word and raises) instead of spending the full bounded wait per launch
+  if (threadIdx.x < 64) {
+    // Lane r of the first wave polls rank r's arrival counter — all ranks at once, relaxed system-scope loads (they do not come from
+    // this CU's caches) — and ONE acquire behind the loop covers the slot reads of every wave behind the barrier.  (Rounds 1-3: one
+    // thread, rank after rank, an acquire-ordered load per poll — a cache invalidate each.)
+    // A timeout is sticky: once this rank has given up on an exchange every later wait fails at once (the host sees the status
+    // word and raises) instead of spending the full bounded wait per launch.
+    const int r = (int)threadIdx.x;
+    const bool mine = r < P.world;
+    bool done = !mine;
     int ok = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u;
-    for (int r = 0; r < P.world && ok; ++r) {
-      ok = 0;
+    if (ok) {
+      const unsigned int *flag = P.flags[P.rank] + (mine ? r : 0) * P2P_FLAG_STRIDE;
       for (int spin = 0; spin < P2P_SPIN_MAX; ++spin) {
-        const unsigned have = __hip_atomic_load(P.flags[P.rank] + r * P2P_FLAG_STRIDE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((int)(have - want) >= 0) {
-          ok = 1;
-          break;
+        if (!done) {
+          const unsigned have = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          done = (int)(have - want) >= 0;
         }
+        if (__all(done)) break;
         __builtin_amdgcn_s_sleep(4);
       }
+      ok = __all(done);
     }
-    if (!ok) __hip_atomic_store(P.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
-    s_p2p_ok = ok;
+    if (!ok && threadIdx.x == 0) __hip_atomic_store(P.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (threadIdx.x == 0) s_p2p_ok = ok;
   }
   __syncthreads();
   return s_p2p_ok != 0;
