@@ -130,6 +130,39 @@ __global__ void __launch_bounds__(256) k_icem_values(const float *rows, int row_
   values[c] = value;
 }
 
+// One wave per candidate: lane p sums particle p's rewards over the horizon (in step order), lane 0 then combines the particles in
+// particle order — the arithmetic of the one-thread-per-candidate form (kept below for more than 64 particles), 10 x the loads in flight.
+__global__ void __launch_bounds__(256) k_icem_values_wave(const float *rows, int row_len, int reward_col, int NC, int P, int H, int use_max,
+                                                           float *values, const float *particle_cost, float lambda_c, int cost_use_max) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= NC) return;
+  const long long N = (long long)NC * P;
+  float m = 0.f;
+  if (lane < P) {
+    float acc = 0.f;
+    for (int t = 0; t < H; ++t) acc += rows[((long long)t * N + (long long)c * P + lane) * row_len + reward_col];
+    m = acc / (float)H;                                               // jnp.mean(transitions.reward, axis=-1)
+  }
+  float agg = 0.f;
+  for (int p = 0; p < P; ++p) {
+    const float mp = __shfl(m, p, 64);
+    agg = (p == 0) ? mp : (use_max ? fmaxf(agg, mp) : agg + mp);
+  }
+  if (lane != 0) return;
+  float value = use_max ? agg : agg / (float)P;                        // summarize_raw_samples: mean (or max under optimism)
+  if (particle_cost) {
+    float cagg = 0.f;
+    for (int p = 0; p < P; ++p) {
+      const float cp = particle_cost[(long long)c * P + p];
+      cagg = (p == 0) ? cp : (cost_use_max ? fmaxf(cagg, cp) : cagg + cp);
+    }
+    const float cost = cost_use_max ? cagg : cagg / (float)P;
+    value = value - lambda_c * fmaxf(cost, 0.f);
+  }
+  values[c] = value;
+}
+
 struct IcemUpdateArgs {
   const float *values, *candidates;
   int NC, H, U, n_elites, n_prev;
@@ -191,6 +224,77 @@ __global__ void __launch_bounds__(1024) k_icem_update(IcemUpdateArgs A) {
   if (tid == 0 && take) A.best_value[0] = best_elite;
 }
 
+// The same update with everything small in LDS (values, ranks, the elites' indices in candidate order, the elites' sequences):
+// ranks from LDS-resident values, the elite list built once, the elites' H x U sequences fetched by all threads at once, and the
+// per-element sums then walk LDS in the SAME order as k_icem_update (ascending candidate index) — identical results; the one-workgroup
+// form above spent its time in 2 x NC dependent global round trips per element on H x U threads (144 us at the reference's test sizes).
+// LDS floats: 2 NC + n_elites + n_elites * H * U.
+__global__ void __launch_bounds__(1024) k_icem_update_lds(IcemUpdateArgs A) {
+  extern __shared__ float sm[];
+  const int tid = threadIdx.x, NC = A.NC, HU = A.H * A.U, NE = A.n_elites;
+  float *s_val = sm;
+  int *s_rank = reinterpret_cast<int *>(sm + NC);
+  int *s_el = s_rank + NC;
+  float *s_seq = reinterpret_cast<float *>(s_el + NE);      // [NE][HU]
+  __shared__ int s_best;
+  for (int c = tid; c < NC; c += 1024) s_val[c] = A.values[c];
+  __syncthreads();
+  for (int c = tid; c < NC; c += 1024) {
+    const float v = s_val[c];
+    int r = 0;
+    for (int j = 0; j < NC; ++j) {
+      const float w = s_val[j];
+      r += (w < v || (w == v && j < c)) ? 1 : 0;
+    }
+    s_rank[c] = r;
+    A.rank[c] = r;
+    if (r == NC - 1) s_best = c;
+  }
+  __syncthreads();
+  const int first = NC - NE;      // elites = sorted positions [first, NC)
+  for (int c = tid; c < NC; c += 1024) {
+    if (s_rank[c] >= first) {
+      int pos = 0;
+      for (int j = 0; j < c; ++j) pos += (s_rank[j] >= first) ? 1 : 0;
+      s_el[pos] = c;              // the elites in ascending candidate order: the order k_icem_update adds them in
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < NE * HU; idx += 1024) {
+    const int k = idx / HU, i = idx - k * HU;
+    s_seq[idx] = A.candidates[(long long)s_el[k] * HU + i];
+  }
+  const int cb = s_best;
+  const float best_elite = s_val[cb];
+  const bool take = A.best_value[0] <= best_elite;
+  __syncthreads();
+  for (int i = tid; i < HU; i += 1024) {
+    float m = 0.f;
+    for (int k = 0; k < NE; ++k) m += s_seq[k * HU + i];
+    m /= (float)NE;
+    float v = 0.f;
+    for (int k = 0; k < NE; ++k) {
+      const float dlt = s_seq[k * HU + i] - m;
+      v += dlt * dlt;
+    }
+    v /= (float)NE;
+    const float sd = A.std[i];
+    const float nm = A.mean[i] * A.alpha + (1.f - A.alpha) * m;          // :205
+    const float nv = sd * sd * A.alpha + (1.f - A.alpha) * v;            // :206
+    A.mean[i] = nm;
+    A.std[i] = sqrtf(nv);                                                // :209
+    if (take) A.best_sequence[i] = A.candidates[(long long)cb * HU + i];
+  }
+  // elites[-n_prev:] in sorted order -> next iteration's prev_elites (:227)
+  for (int idx = tid; idx < NE * HU; idx += 1024) {
+    const int k = idx / HU, i = idx - k * HU;
+    const int pos = s_rank[s_el[k]] - (NC - A.n_prev);
+    if (pos >= 0) A.prev_elites[(long long)pos * HU + i] = s_seq[idx];
+  }
+  __syncthreads();
+  if (tid == 0 && take) A.best_value[0] = best_elite;
+}
+
 extern "C" int mbpo_icem_update_constrained(const float *rows, int32_t row_len, int32_t reward_col, int32_t n_candidates, int32_t n_particles,
                                             int32_t horizon, int32_t u_dim, const float *candidates, int32_t n_elites, int32_t n_prev,
                                             float alpha, int32_t use_max, const float *particle_cost, float lambda_constraint,
@@ -202,11 +306,17 @@ extern "C" int mbpo_icem_update_constrained(const float *rows, int32_t row_len, 
   MBPO_REQUIRE(n_prev == 0 || prev_elites, MBPO_ERR_ARG, "icem_update: prev_elites is NULL");
   MBPO_REQUIRE(reward_col >= 0 && reward_col < row_len, MBPO_ERR_ARG, "icem_update: bad reward column");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_icem_values, dim3((n_candidates + 255) / 256), dim3(256), 0, st, rows, row_len, reward_col, n_candidates, n_particles,
-                     horizon, use_max, values, particle_cost, lambda_constraint, cost_use_max);
+  if (n_particles <= 64)
+    hipLaunchKernelGGL(k_icem_values_wave, dim3((n_candidates + 3) / 4), dim3(256), 0, st, rows, row_len, reward_col, n_candidates, n_particles,
+                       horizon, use_max, values, particle_cost, lambda_constraint, cost_use_max);
+  else
+    hipLaunchKernelGGL(k_icem_values, dim3((n_candidates + 255) / 256), dim3(256), 0, st, rows, row_len, reward_col, n_candidates, n_particles,
+                       horizon, use_max, values, particle_cost, lambda_constraint, cost_use_max);
   IcemUpdateArgs A{values, candidates, n_candidates, horizon, u_dim, n_elites, n_prev, alpha, mean, std, best_value, best_sequence,
                    prev_elites, workspace};
-  hipLaunchKernelGGL(k_icem_update, dim3(1), dim3(1024), 0, st, A);
+  const size_t lds = (2ull * n_candidates + n_elites + (size_t)n_elites * horizon * u_dim) * sizeof(float);
+  if (lds <= 60 * 1024) hipLaunchKernelGGL(k_icem_update_lds, dim3(1), dim3(1024), lds, st, A);
+  else hipLaunchKernelGGL(k_icem_update, dim3(1), dim3(1024), 0, st, A);
   MBPO_CHECK_LAUNCH("icem_update");
   return MBPO_OK;
 }

@@ -751,6 +751,63 @@ __global__ void __launch_bounds__(64 * RO64_WAVES) k_model_rollout64(RolloutArgs
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Open-loop rollout of the analytic Pendulum system (rollout_actions, utils/optimizer_utils.py:26-38 — the iCEM planner's candidate
+// evaluation, icem_optimizer.py:146-160): no network, so a 16-env tile on a 768-thread workgroup has 16 busy lanes per step (the
+// tile kernels spent 130 us on 5500 envs x 20 steps).  Here one THREAD owns an env for all steps: the sections of k_model_rollout64 —
+// reward on the pre-step (x, u), the step, EpisodeWrapper / AutoReset bookkeeping, the Transition row — with the same device functions
+// in the same order: the same rows bit for bit (tests/test_gpu_icem.py).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_openloop_pendulum(RolloutArgs A) {
+  const long long env = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long N = A.n_envs;
+  if (env >= N) return;
+  constexpr int X = 3, U = 1;
+  const int D = A.row_len, AR = A.action_repeat;
+  float o[3], f[3];
+#pragma unroll
+  for (int c = 0; c < X; ++c) {
+    o[c] = A.obs[env * X + c];
+    f[c] = A.first_obs[env * X + c];
+  }
+  float steps = A.steps[env], done = A.done[env];
+  const float rp[3] = {A.reward_params[0], A.reward_params[1], A.reward_params[2]};
+  for (int s = 0; s < A.n_steps; ++s) {
+    float *row = A.transitions + (A.env_major ? (env * A.n_steps + s) : ((long long)s * N + env)) * D;
+    const float a = A.actions[((long long)s * N + env) * U];
+#pragma unroll
+    for (int c = 0; c < X; ++c) row[c] = o[c];
+    row[X] = a;
+    if (done != 0.f) steps = 0.f;      // AutoReset pre-step (training.py:119-124)
+    done = 0.f;
+    float rew = 0.f;
+    float xu[4] = {o[0], o[1], o[2], a};
+    for (int ar = 0; ar < AR; ++ar) {   // EpisodeWrapper inner scan over action_repeat (training.py:91-97)
+      rew += (A.reward_kind == MBPO_REWARD_PENDULUM) ? pendulum_reward(xu, a, rp) : 0.f;
+      float xn[3];
+      pendulum_step(xu, a, A.sys_params, xn);
+      xu[0] = xn[0]; xu[1] = xn[1]; xu[2] = xn[2];
+    }
+    const float st = steps + (float)AR;
+    const bool dn = st >= (float)A.episode_length;
+#pragma unroll
+    for (int c = 0; c < X; ++c) {
+      const float v = dn ? f[c] : xu[c];
+      o[c] = v;
+      row[X + U + 2 + c] = v;          // next_observation = nstate.obs (post auto-reset)
+    }
+    row[X + U] = rew;
+    row[X + U + 1] = 1.f - (dn ? 1.f : 0.f);
+    row[D - 1] = dn ? 1.f : 0.f;       // truncation
+    steps = st;
+    done = dn ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < X; ++c) A.obs[env * X + c] = o[c];
+  A.steps[env] = steps;
+  A.done[env] = done;
+}
+
 extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   MBPO_REQUIRE(d, MBPO_ERR_ARG, "model_rollout: null descriptor");
   MBPO_REQUIRE(d->x_dim > 0 && d->u_dim > 0, MBPO_ERR_ARG, "model_rollout: x_dim/u_dim must be positive");
@@ -839,6 +896,12 @@ extern "C" int mbpo_model_rollout(const mbpo_rollout_desc *d, void *stream) {
   long long n_tiles = (d->n_envs + 15) >> 4;
   int grid = (int)(n_tiles < 4LL * num_cus() ? n_tiles : 4LL * num_cus());
   hipStream_t st = (hipStream_t)stream;
+  if (!has_policy && d->system_kind == MBPO_SYS_PENDULUM && d->reward_kind == MBPO_REWARD_PENDULUM && !d->ppo_extras &&
+      !(g_ro_lean == 0)) {      // (mbpo_debug_set_rollout_lean(0): the tile kernel, for the A/B test)
+    hipLaunchKernelGGL(k_openloop_pendulum, dim3((unsigned)((d->n_envs + 255) / 256)), dim3(256), 0, st, A);
+    MBPO_CHECK_LAUNCH("model_rollout");
+    return MBPO_OK;
+  }
 #define LAUNCH_RO(HH)                                                        \
   {                                                                          \
     rc = mbpo_ensure_lds<k_model_rollout<HH>>(lds, "model_rollout");                 \

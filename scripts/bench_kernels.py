@@ -104,7 +104,9 @@ def mfma_entry(name, entry, cfg, t, flop, unit_note, extra=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
+    ap.add_argument("--only", default=None, help="run only the cases whose function name contains this (rollout, ens_fwd, sac, ppo, bptt, icem, ...)")
     args = ap.parse_args()
+    want = lambda name: args.only is None or args.only in name
     if not torch.cuda.is_available():
         raise SystemExit("needs a GPU: the HIP path has no CPU fallback")
     from mbpo import _hip, ops
@@ -211,11 +213,11 @@ def main():
             out.append({"kernel": fn.__name__, "config": [list(x) if isinstance(x, tuple) else x for x in a], "error": str(e)[:300]})
             log(f"{fn.__name__}{a}: {e}")
 
-    rollout_case(4096, 4, 1, 5, 5, (64, 64, 64), (64, 64, 64), 50)       # C2
-    rollout_case(32768, 4, 1, 5, 5, (64, 64, 64), (64, 64, 64), 20)      # C4's global env count on one GPU
-    attempt(rollout_case, 4096, 4, 1, 5, 5, (64, 64, 64), (256, 256), 20)   # "also report 256x2" members
-    attempt(rollout_case, 4096, 4, 1, 5, 5, (256, 256), (256, 256), 20)
-    attempt(rollout_case, 4096, 17, 6, 10, 5, (64, 64, 64), (64, 64, 64), 20)     # C5 shape through the rollout kernel
+    if want("rollout_case"): rollout_case(4096, 4, 1, 5, 5, (64, 64, 64), (64, 64, 64), 50)       # C2
+    if want("rollout_case"): rollout_case(32768, 4, 1, 5, 5, (64, 64, 64), (64, 64, 64), 20)      # C4's global env count on one GPU
+    if want("rollout_case"): attempt(rollout_case, 4096, 4, 1, 5, 5, (64, 64, 64), (256, 256), 20)   # "also report 256x2" members
+    if want("rollout_case"): attempt(rollout_case, 4096, 4, 1, 5, 5, (256, 256), (256, 256), 20)
+    if want("rollout_case"): attempt(rollout_case, 4096, 17, 6, 10, 5, (64, 64, 64), (64, 64, 64), 20)     # C5 shape through the rollout kernel
 
     # ---------------------------------------------------------------- R2: vmapped ensemble forward (System.step outside the fused rollout)
     def ens_fwd_case(N, X, U, E, hid, reps):
@@ -228,8 +230,8 @@ def main():
                               N * 2 * E * mlp_macs(dd), "2*E*M FLOP per row (shared input)", {"rows_per_s": N / t}))
         log(f"ensemble forward N={N} E={E} {hid}: {t * 1e6:.1f} us")
 
-    attempt(ens_fwd_case, 4096, 4, 1, 5, (64, 64, 64), 100)
-    attempt(ens_fwd_case, 32768, 4, 1, 5, (64, 64, 64), 50)
+    if want("ens_fwd_case"): attempt(ens_fwd_case, 4096, 4, 1, 5, (64, 64, 64), 100)
+    if want("ens_fwd_case"): attempt(ens_fwd_case, 32768, 4, 1, 5, (64, 64, 64), 50)
 
     # ---------------------------------------------------------------- S3-S8: SAC sgd_step
     def sac_case(X, U, hidden, B, reps):
@@ -253,12 +255,12 @@ def main():
                               {"updates_per_s": 1.0 / t}))
         log(f"sac sgd_step x={X} {hidden} B={B}: {t * 1e6:.1f} us")
 
-    sac_case(4, 1, (64, 64, 64), 256, 200)
-    sac_case(3, 1, (128, 128, 128), 256, 200)      # the reference tests' width (tests/test_sac.py)
-    attempt(sac_case, 4, 1, (64, 64, 64), 2048, 100)        # C4's global batch on one GPU
-    attempt(sac_case, 17, 6, (64, 64, 64), 256, 200)
-    attempt(sac_case, 4, 1, (256, 256, 256), 256, 50)        # wider than the fused kernels take: one GEMM launch per Dense layer
-    attempt(sac_case, 4, 1, (256, 256, 256), 4096, 20)
+    if want("sac_case"): sac_case(4, 1, (64, 64, 64), 256, 200)
+    if want("sac_case"): sac_case(3, 1, (128, 128, 128), 256, 200)      # the reference tests' width (tests/test_sac.py)
+    if want("sac_case"): attempt(sac_case, 4, 1, (64, 64, 64), 2048, 100)        # C4's global batch on one GPU
+    if want("sac_case"): attempt(sac_case, 17, 6, (64, 64, 64), 256, 200)
+    if want("sac_case"): attempt(sac_case, 4, 1, (256, 256, 256), 256, 50)        # wider than the fused kernels take: one GEMM launch per Dense layer
+    if want("sac_case"): attempt(sac_case, 4, 1, (256, 256, 256), 4096, 20)
 
     # ---------------------------------------------------------------- P3-P6: PPO minibatch_step (C3)
     def ppo_case(X, U, hidden, B, T, reps):
@@ -278,8 +280,8 @@ def main():
                               {"gae_elements_per_s": B * T / t}))
         log(f"ppo minibatch_step B={B} T={T}: {t * 1e6:.1f} us")
 
-    ppo_case(4, 1, (64, 64, 64), 512, 5, 100)
-    attempt(ppo_case, 4, 1, (64, 64, 64), 512, 40, 50)
+    if want("ppo_case"): ppo_case(4, 1, (64, 64, 64), 512, 5, 100)
+    if want("ppo_case"): attempt(ppo_case, 4, 1, (64, 64, 64), 512, 40, 50)
 
     # ---------------------------------------------------------------- B1-B5: BPTT actor gradient (C5)
     def bptt_case(X, U, E, H, n, reps):
@@ -302,8 +304,8 @@ def main():
                               {"state_steps_per_s": n * H / t, "grads_finite": bool(torch.isfinite(op.grads).all())}))
         log(f"bptt x={X} u={U} E={E} H={H} n={n}: {t * 1e3:.2f} ms  {n * H / t / 1e6:.2f} M state-steps/s")
 
-    attempt(bptt_case, 17, 6, 10, 32, 4096, 5)          # C5, one GPU's share
-    bptt_case(4, 1, 5, 5, 4096, 20)            # north-star shape
+    if want("bptt_case"): attempt(bptt_case, 17, 6, 10, 32, 4096, 5)          # C5, one GPU's share
+    if want("bptt_case"): bptt_case(4, 1, 5, 5, 4096, 20)            # north-star shape
 
     # ---------------------------------------------------------------- N3: ensemble NLL fwd+bwd
     X, U, E, Bn = 4, 1, 5, 256
@@ -375,7 +377,7 @@ def main():
                     "note": "num_steps iterations of sample -> open-loop rollout -> update, host loop as icem_optimizer.py:135-252"})
         log(f"icem optimize: {t * 1e6:.1f} us (eager {te * 1e6:.1f})")
 
-    attempt(icem_case, 20, 100)
+    if want("icem_case"): attempt(icem_case, 20, 100)
 
     res = {"device": torch.cuda.get_device_name(0), "roofs": {"hbm_GBs": HBM_PEAK_GBS, "mfma_f32_TFLOPs": MFMA_F32_PEAK_TF},
            "note": "device_us = HIP-event average per call with the calls captured into a hipGraph and replayed (device time, inputs resident in HBM; multi-launch ops timed whole); eager_us = the same call issued from Python",

@@ -4,6 +4,8 @@ summed reward >= -400).
 
 Tolerances: coloured noise / candidates 2e-5 (fp32 sums of <= 65 harmonics against the fp64 irfft); values 1e-5; the
 optimize() comparison uses loose tolerances because an elite set can flip on rounding-level ties."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -225,3 +227,38 @@ def test_icem_cost_fn_steers_the_plan(dev):
         mean, std, best_v, best_s, prev = oicem.update(vals, cand, mean, std, best_v, best_s, params.num_elites, nprev, params.alpha)
     assert abs(float(con.best_reward) - best_v) <= 2e-3 * max(1.0, abs(best_v))
     np.testing.assert_allclose(con.best_sequence.cpu().numpy(), best_s, atol=5e-3)
+
+
+@pytest.mark.parametrize("N,S,L,AR,env_major", [(5500, 20, 2 ** 30, 1, False), (333, 12, 5, 1, True), (100, 6, 4, 2, False)])
+def test_open_loop_pendulum_thread_kernel_equals_tile_kernel(dev, N, S, L, AR, env_major):
+    """The planner's candidate evaluation on the analytic Pendulum (rollout_actions) runs one THREAD per env (k_openloop_pendulum) instead
+    of a 768-thread workgroup per 16 envs: same device functions in the same order — the tile kernel's rows, obs, steps, done bit for bit
+    (incl. auto-reset at a short episode length and action_repeat 2)."""
+    import ctypes as C
+    from mbpo import ops, _hip
+    from mbpo.systems import PendulumSystem
+    lib = _hip.load()
+    lib.mbpo_debug_set_rollout_lean.argtypes = [C.c_int]
+    system = PendulumSystem()
+    spec = system.rollout_spec(system.reset(device=dev).system_params, dev)
+    g = torch.Generator().manual_seed(3)
+    th = (torch.rand(N, generator=g) * 2 - 1) * math.pi
+    obs0 = torch.stack([torch.cos(th), torch.sin(th), (torch.rand(N, generator=g) * 2 - 1) * 8], dim=1)
+    first = torch.tensor([-1.0, 0.0, 0.0]).expand(N, 3).contiguous()
+    actions = (torch.rand(S, N, 1, generator=g) * 2.4 - 1.2).to(dev)           # some outside [-1, 1]: the torque clip
+    steps0 = torch.randint(0, max(1, min(L, 5)), (N,), generator=g).float()
+    done0 = (torch.rand(N, generator=g) < 0.2).float()
+    res = {}
+    try:
+        for mode in (0, -1):
+            lib.mbpo_debug_set_rollout_lean(mode)
+            obs, steps, done = obs0.to(dev), steps0.to(dev), done0.to(dev)
+            rows = ops.model_rollout(x_dim=3, u_dim=1, actions=actions, obs=obs, first_obs=first.to(dev), steps=steps, done=done, n_steps=S,
+                                     episode_length=L, action_repeat=AR, env_major=env_major, seed=5, offset=0, **spec)
+            torch.cuda.synchronize()
+            res[mode] = (rows.clone(), obs.clone(), steps.clone(), done.clone())
+    finally:
+        lib.mbpo_debug_set_rollout_lean(-1)
+    for a, b in zip(res[0], res[-1]):
+        assert torch.equal(a, b)
+    assert float(res[-1][0].abs().sum()) > 0
