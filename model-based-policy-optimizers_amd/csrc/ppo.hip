@@ -799,6 +799,18 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
     if (rc != MBPO_OK) return rc;
     A.baseline = values;
     A.boot = values + pl.M;
+  } else if (pl.vg_G && pl.lean) {
+    // 1-3 in one launch on the value network's resident images (ppo_lean.hip k_ppo_vg_lean: the same bits as k_ppo_values_gae)
+    PpoVgLeanArgs V;
+    V.v_params = d->params + pl.pi.n_params; V.data = d->data; V.norm_mean = d->norm_mean; V.norm_std = d->norm_std;
+    V.B = d->batch_size; V.T = d->unroll_length; V.D = A.D; V.G = pl.vg_G;
+    V.reward_scaling = d->reward_scaling; V.discounting = d->discounting; V.gae_lambda = d->gae_lambda;
+    V.vs = A.vs; V.adv = A.adv; V.mom_part = A.mom_part; V.step_count_rw = A.step_count_rw;
+    const long long GR = (long long)pl.vg_G * (d->unroll_length + 1), GT = (long long)pl.vg_G * d->unroll_length;
+    rc = ppo_vg_lean_launch(V, d->x_dim, pl.n_vg, (size_t)(((GR + 3) & ~3LL) + 4 * ((GT + 3) & ~3LL)), stream);
+    if (rc != MBPO_OK) return rc;
+    if (d->normalize_advantage)
+      hipLaunchKernelGGL(k_ppo_moments_combine, dim3(1), dim3(256), 0, st, (const float *)A.mom_part, pl.n_vg, (float)pl.M, A.mom);
   } else if (pl.vg_G) {
     // 1-3 in one launch: values, GAE, the moments' per-workgroup partials
     const int tiles_wg = (int)(((long long)pl.vg_G * (d->unroll_length + 1) + 15) / 16);

@@ -378,6 +378,195 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_ppo_vg_lean<X>: the values pre-pass (ppo/losses.py:84-86), compute_gae (:128-184) and the advantage moments' per-workgroup partials
+// in one launch — ppo.hip's k_ppo_values_gae with the value network's images resident in registers: a workgroup owns G whole
+// trajectories (T samples + the bootstrap row each), 2 chains x 4 waves walk their row tiles two at a time, one thread per trajectory
+// then walks compute_gae backwards in the reference's order, the first wave leaves {n, mean, M2}.  The input layer is formed with the
+// generic runner's k groups (wset_fwd_hidden<IN>), so the values — and with them vs, adv and the partials — are the generic launch's bits.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int VG_X = 0;                 // [2 chains][16][8] input tiles
+constexpr int VG_TILES = 256;           // [2 chains][2] hidden tiles
+constexpr int VG_ARR = VG_TILES + 4 * LT;     // s_val [G R] | s_tr | s_te | s_rw | s_adv [G T] each (rounded up to 4)
+}  // namespace
+
+template <int X>
+__global__ void __launch_bounds__(512) k_ppo_vg_lean(const PpoVgLeanArgs A) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int U = 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = wave >> 2, sub = wave & 3, c0 = sub * 16;
+  const int T = A.T, R = T + 1, G = A.G, D = A.D;
+  const int i16 = lane & 15, g4 = lane >> 4;
+  float *s_val = smem + VG_ARR;
+  float *s_tr = s_val + ((G * R + 3) & ~3);
+  const int GT4 = (G * T + 3) & ~3;
+  float *s_te = s_tr + GT4, *s_rw = s_te + GT4, *s_adv = s_rw + GT4;
+  const long long b0 = (long long)blockIdx.x * G;
+  const int g_here = (int)((A.B - b0 < G) ? A.B - b0 : G);
+  const int rows = g_here * R;
+  if (blockIdx.x == 0 && tid == 0) A.step_count_rw[0] = A.step_count_rw[0] + 1.0f;     // (nothing in this launch reads it)
+  // ---- the value network's images, once ----
+  const float *const net_p = A.v_params;
+  constexpr int W1 = X * LH + LH, OUT = W1 + 2 * HID;
+  constexpr int kc = (X + 3) >> 2;      // 1 for x in {3, 4}
+  float w0[2], b0v[4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int k = g4 * kc + s;
+    const bool ok = (s < kc) && (k < X);
+    const float v = net_p[(ok ? k : 0) * LH + c0 + i16];
+    w0[s] = ok ? v : 0.f;
+  }
+  {
+    const f4u t = *reinterpret_cast<const f4u *>(net_p + X * LH + c0 + 4 * g4);
+    b0v[0] = t[0]; b0v[1] = t[1]; b0v[2] = t[2]; b0v[3] = t[3];
+  }
+  ImgF I1, I2;
+  img_fwd_request(I1, net_p + W1, c0, lane);
+  img_fwd_request(I2, net_p + W1 + HID, c0, lane);
+  float wo[16];
+  float bo = 0.f;
+  const bool out_wave = sub == c;                                      // waves 0 and 5: different SIMDs
+  if (out_wave) {
+    img_out_request<1>(wo, net_p + OUT, lane);
+    bo = net_p[OUT + LH];
+  }
+  float *const s_x = smem + VG_X + c * 128;
+  float *const tiles = smem + VG_TILES + c * 2 * LT;
+  const int ct = tid & 255;
+  float nm = 0.f, ns = 1.f;
+  const int col_t = ct % X, row_t = ct / X;
+  if (ct < 16 * X && A.norm_mean) {
+    nm = A.norm_mean[col_t];
+    ns = A.norm_std[col_t];
+  }
+#pragma nounroll
+  for (int rr = 0; rr < rows; rr += 32) {
+    const int r0 = rr + 16 * c;
+    const bool live = r0 < rows;             // (wave-uniform: a chain without a tile only keeps the barriers)
+    if (live) {
+      if (ct < 16 * X) {
+        const int lrow = r0 + row_t;
+        float o = 0.f;
+        if (lrow < rows) {
+          const int g = lrow / R, t = lrow - g * R;
+          const long long base = ((b0 + g) * T + (t < T ? t : T - 1)) * D;
+          o = A.data[base + (t < T ? col_t : X + U + 2 + col_t)];                  // observation | next_observation[-1]  (losses.py:84-85)
+          if (A.norm_mean) o = (o - nm) / ns;
+        }
+        s_x[row_t * LDX + col_t] = o;
+      } else if (ct >= 192 && ct < 208) {
+        const int lrow = r0 + (ct - 192);
+        if (lrow < rows) {
+          const int g = lrow / R, t = lrow - g * R;
+          if (t < T) {
+            const float *row = A.data + ((b0 + g) * T + t) * D;
+            const float tr = row[D - 1], disc = row[X + U + 1];
+            s_tr[g * T + t] = tr;
+            s_te[g * T + t] = (1.f - disc) * (1.f - tr);             // termination = (1 - discount) * (1 - truncation)   (:89)
+            s_rw[g * T + t] = row[X + U] * A.reward_scaling;          // rewards = data.reward * reward_scaling             (:87)
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (live) {
+      // input layer on the generic runner's k groups: lane group g takes inputs g * kc .. (one MFMA, the second multiplies zeros)
+      float xs[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int k = g4 * kc + s;
+        const bool ok = (s < kc) && (k < X);
+        const float v = s_x[i16 * LDX + (ok ? k : 0)];
+        xs[s] = ok ? v : 0.f;
+      }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = MFMA(w0[0], xs[0], acc);
+      acc = MFMA(w0[1], xs[1], acc);
+      float zv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) zv[q] = acc[q] + b0v[q];
+      act_apply_vec<4>(zv, MBPO_ACT_SWISH);
+      store_vec_lds<4>(tiles + i16 * LDH + c0 + 4 * g4, zv);
+    }
+    __syncthreads();
+    if (live) hid_fwd<false>(I1, tiles, tiles + LT, nullptr, c0, lane);
+    __syncthreads();
+    if (live) hid_fwd<false>(I2, tiles + LT, tiles, nullptr, c0, lane);
+    __syncthreads();
+    if (live && out_wave) {
+      const f32x4 y = out_fwd(wo, tiles, lane);
+      if (lane < 16 && r0 + lane < rows) s_val[r0 + lane] = y[0] + bo;
+    }
+    // (no barrier: the next round's input tile and the first hidden tile were last read two barriers ago)
+  }
+  __syncthreads();
+  // compute_gae, one thread per trajectory, backwards (losses.py:150-184)
+  if (tid < g_here) {
+    const int g = tid;
+    const float boot = s_val[g * R + T];
+    float acc = 0.f, v_next = boot, vs_next = boot;
+    for (int t = T - 1; t >= 0; --t) {
+      const float tr = s_tr[g * T + t], te = s_te[g * T + t], r = s_rw[g * T + t], v = s_val[g * R + t];
+      const float m = 1.f - tr;
+      const float g1 = A.discounting * (1.f - te);
+      const float delta = (r + g1 * v_next - v) * m;        // :157-158
+      acc = delta + g1 * m * A.gae_lambda * acc;            // :166
+      const float vs = acc + v;                             // :176
+      const float adv = (r + g1 * vs_next - v) * m;         // :181-182
+      const long long i = (b0 + g) * T + t;
+      A.vs[i] = vs;
+      A.adv[i] = adv;
+      s_adv[g * T + t] = adv;
+      v_next = v;
+      vs_next = vs;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int n = g_here * T;
+    float a = 0.f;
+    for (int i = lane; i < n; i += 64) a += s_adv[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    const float mean = __shfl(a, 0, 64) / (float)n;
+    float q = 0.f;
+    for (int i = lane; i < n; i += 64) {
+      const float dd = s_adv[i] - mean;
+      q += dd * dd;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_down(q, o, 64);
+    if (lane == 0) {
+      A.mom_part[4 * blockIdx.x + 0] = (float)n;
+      A.mom_part[4 * blockIdx.x + 1] = mean;
+      A.mom_part[4 * blockIdx.x + 2] = q;
+    }
+  }
+}
+
+int ppo_vg_lean_launch(const PpoVgLeanArgs &A, int x_dim, int n_wgs, size_t arr_floats, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)(VG_ARR + arr_floats) * sizeof(float);
+  int rc;
+  if (x_dim == 3) {
+    rc = mbpo_ensure_lds<k_ppo_vg_lean<3>>(lds, "ppo_vg_lean");
+    if (rc != MBPO_OK) return rc;
+    hipLaunchKernelGGL(k_ppo_vg_lean<3>, dim3(n_wgs), dim3(512), lds, st, A);
+  } else if (x_dim == 4) {
+    rc = mbpo_ensure_lds<k_ppo_vg_lean<4>>(lds, "ppo_vg_lean");
+    if (rc != MBPO_OK) return rc;
+    hipLaunchKernelGGL(k_ppo_vg_lean<4>, dim3(n_wgs), dim3(512), lds, st, A);
+  } else {
+    mbpo_set_error("ppo_vg_lean: x_dim %d has no instantiation", x_dim);
+    return MBPO_ERR_UNSUPPORTED;
+  }
+  return MBPO_OK;
+}
+
 bool ppo_lean_supports(int x_dim, int u_dim, const int *policy_dims, int policy_layers, int policy_act, const int *value_dims, int value_layers,
                        int value_act) {
   if (u_dim != 1 || (x_dim != 3 && x_dim != 4)) return false;

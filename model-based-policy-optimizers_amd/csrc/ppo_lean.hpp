@@ -22,3 +22,16 @@ bool ppo_lean_supports(int x_dim, int u_dim, const int *policy_dims, int policy_
                        int value_act);
 // one workgroup per CU (n_wgs <= tiles), each walks tiles blockIdx.x, + n_wgs, ... and leaves ONE slab
 int ppo_lean_launch(const PpoLeanArgs &A, int x_dim, int n_wgs, void *stream);
+
+// ---- values + GAE + advantage-moment partials in one launch (ppo.hip k_ppo_values_gae) for the same value network ----
+struct PpoVgLeanArgs {
+  const float *v_params;                // the value network
+  const float *data;                    // [B][T][D] rows of the shuffled minibatch
+  const float *norm_mean, *norm_std;
+  int B, T, D, G;                       // G whole trajectories per workgroup (G * (T + 1) <= 1024)
+  float reward_scaling, discounting, gae_lambda;
+  float *vs, *adv;                      // [B][T]
+  float *mom_part;                      // [workgroups][4]: {n, mean, M2, -}
+  float *step_count_rw;
+};
+int ppo_vg_lean_launch(const PpoVgLeanArgs &A, int x_dim, int n_wgs, size_t lds_extra_floats, void *stream);
