@@ -47,70 +47,6 @@ constexpr size_t RL_LDS_BYTES = (size_t)(R_SLOT0 + RL_SLOT_F) * sizeof(float);
 constexpr int SW = 3;                               // the wave that holds the tile's env state
 constexpr int NW = 4;                               // the wave that draws the policy noise
 
-// input layer of this wave's two column blocks: w[t][s] = W0[g * kc + s][c0 + 16 t + i] (zero outside the network's K inputs)
-struct Img0 {
-  float w[2][2];
-};
-
-// layer 0: the generic runner's k groups (wset_fwd_hidden<IN>: lane group g takes inputs g * kc .. g * kc + kc - 1; its MFMAs beyond kc
-// multiply zeros and are skipped here)
-__device__ __forceinline__ void in_fwd2(const Img0 &I, const float *bias, const float *x, int kc, int K, float *h_out, int c0, int lane) {
-  const int j = lane & 15, g = lane >> 4;
-  float xs[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int k = g * kc + s;
-    const bool ok = (s < kc) && (k < K);
-    const float v = x[j * LDX + (ok ? k : 0)];
-    xs[s] = ok ? v : 0.f;
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = MFMA(I.w[t][0], xs[0], acc);
-    acc = MFMA(I.w[t][1], xs[1], acc);
-    float zv[4], bv[4];
-    load_vec_lds<4>(bias + c0 + 16 * t + 4 * g, bv);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) zv[q] = acc[q] + bv[q];
-    act_apply_vec<4>(zv, MBPO_ACT_SWISH);
-    store_vec_lds<4>(h_out + j * LDH + c0 + 16 * t + 4 * g, zv);
-  }
-}
-
-// hidden layer, two column blocks: one set of activation reads, two interleaved accumulation chains
-__device__ __forceinline__ void hid_fwd2(const float (&wa)[16], const float (&wb)[16], const float *bias, const float *xin, float *h_out, int c0,
-                                         int lane) {
-  const int j = lane & 15, g = lane >> 4;
-  float av[16];
-  read_row16(av, xin, lane);
-  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    a = MFMA(wa[s], av[s], a);
-    b = MFMA(wb[s], av[s], b);
-  }
-  float za[4], zb[4], ba[4], bb[4];
-  load_vec_lds<4>(bias + c0 + 4 * g, ba);
-  load_vec_lds<4>(bias + c0 + 16 + 4 * g, bb);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    za[q] = a[q] + ba[q];
-    zb[q] = b[q] + bb[q];
-  }
-  act_apply_vec<4>(za, MBPO_ACT_SWISH);
-  act_apply_vec<4>(zb, MBPO_ACT_SWISH);
-  store_vec_lds<4>(h_out + j * LDH + c0 + 4 * g, za);
-  store_vec_lds<4>(h_out + j * LDH + c0 + 16 + 4 * g, zb);
-}
-// forward image of a hidden layer's 16 columns c0..c0+15 without the bias: w[s] = W[16 g + s][c0 + i]
-__device__ __forceinline__ void img_w_request(float (&w)[16], const float *__restrict__ W, int c0, int lane) {
-  const int i = lane & 15, g = lane >> 4;
-  const float *p = W + (16 * g) * LH + c0 + i;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) w[s] = p[s * LH];
-}
-
 // the policy noise of (step s, env env0 + lane) for lanes 0..15
 __device__ __forceinline__ float rl_noise(const RolloutArgs &A, int s, long long env0, int lane, unsigned long long rng_seed,
                                           unsigned long long rng_off) {
