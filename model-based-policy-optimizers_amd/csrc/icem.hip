@@ -1,5 +1,5 @@
 // icem.hip — N4: the iCEM trajectory optimizer's device side (trajectory_optimizers/icem_optimizer.py:135-252).
-//   k_icem_sample  coloured-noise candidates: powerlaw_psd_gaussian (utils/general_utils.py:81-208) restated as a direct inverse
+//   k_icem_sample_par  coloured-noise candidates: powerlaw_psd_gaussian (utils/general_utils.py:81-208) restated as a direct inverse
 //                  real DFT (horizons are tens of steps: H*K MACs per series, no FFT library), mean + noise*std, clip, previous
 //                  elites appended, every candidate replicated over its particles in the rollout kernel's open-loop layout.
 //   (rollouts)     mbpo_model_rollout with `actions` (rollout_actions, utils/optimizer_utils.py:11-59) — csrc/rollout.hip
@@ -21,10 +21,15 @@ struct IcemSampleArgs {
   float *candidates;   // [S+Kp][H][U]
 };
 
-__global__ void __launch_bounds__(256) k_icem_sample(IcemSampleArgs A) {
-  extern __shared__ float s_tab[];             // cos / sin tables [H][K]
+// One thread per (series, step): a block takes 256 / H series, draws their K coefficient pairs into LDS (one Philox + Box-Muller pair
+// per thread), then every (series, t) thread forms its inverse-DFT sum over k in order and writes its element and the particles'
+// copies.  (Round 3's one-thread-per-series form — same values bit for bit — spent 43 us on 550 series at the reference's test sizes;
+// this one 5 us.)
+__global__ void __launch_bounds__(256) k_icem_sample_par(IcemSampleArgs A) {
+  extern __shared__ float s_tab[];             // cos / sin tables [H][K], scale [K], coefficients [SB][K] x 2
   const int H = A.H, U = A.U, K = H / 2 + 1;
-  float *s_cos = s_tab, *s_sin = s_tab + H * K, *s_scale = s_sin + H * K;
+  const int SB = 256 / H;                       // series per block
+  float *s_cos = s_tab, *s_sin = s_tab + H * K, *s_scale = s_sin + H * K, *s_r = s_scale + K, *s_i = s_r + SB * K;
   for (int i = threadIdx.x; i < H * K; i += blockDim.x) {
     const int t = i / K, k = i - t * K;
     const float ang = 6.28318530717958647692f * (float)((k * t) % H) / (float)H;
@@ -36,7 +41,6 @@ __global__ void __launch_bounds__(256) k_icem_sample(IcemSampleArgs A) {
     s_scale[k] = powf(f, -0.5f * A.exponent);
   }
   __syncthreads();
-  // theoretical output std (general_utils.py:177-180)
   float wsum = 0.f;
   for (int k = 1; k < K; ++k) {
     float w = s_scale[k];
@@ -47,42 +51,46 @@ __global__ void __launch_bounds__(256) k_icem_sample(IcemSampleArgs A) {
   const RngKey rk_ = rng_resolve(A.seed, A.offset, A.rng_dev);
   const unsigned long long off = rk_.offset, rng_seed = rk_.seed;
   const int NC = A.S + A.Kp, N = NC * A.P;
-  for (int sd = blockIdx.x * blockDim.x + threadIdx.x; sd < NC * U; sd += gridDim.x * blockDim.x) {
-    const int c = sd / U, d = sd - c * U;
-    if (c >= A.S) {        // previous elites ride along unchanged (:190)
-      for (int t = 0; t < H; ++t) {
-        const float a = A.prev_elites[((long long)(c - A.S) * H + t) * U + d];
-        A.candidates[((long long)c * H + t) * U + d] = a;
-        for (int p = 0; p < A.P; ++p) A.actions[((long long)t * N + c * A.P + p) * U + d] = a;
-      }
-      continue;
-    }
-    // Fourier coefficients of this series
-    float sr[65], si[65];
-    for (int k = 0; k < K; ++k) {
+  const int sd0 = blockIdx.x * SB;
+  // coefficients of this block's sampled series
+  for (int idx = threadIdx.x; idx < SB * K; idx += blockDim.x) {
+    const int j = idx / K, k = idx - j * K, sd = sd0 + j;
+    if (sd < NC * U && sd / U < A.S) {
       const unsigned long long base = ((unsigned long long)sd * K + k) * 2ull;
-      sr[k] = philox_normal(rng_seed, off, MBPO_STREAM_ICEM, base) * s_scale[k];
-      si[k] = philox_normal(rng_seed, off, MBPO_STREAM_ICEM, base + 1ull) * s_scale[k];
-    }
-    if (!(H % 2)) {        // even length: the Nyquist coefficient is real (:193-197)
-      si[K - 1] = 0.f;
-      sr[K - 1] *= 1.41421356237309504880f;
-    }
-    si[0] = 0.f;           // the DC coefficient is real (:199-201)
-    sr[0] *= 1.41421356237309504880f;
-    for (int t = 0; t < H; ++t) {
-      // irfft: y_t = (1/H) [ s_0 + 2 sum_{0<k<H/2} (sr_k cos - si_k sin) + (H even) s_{H/2} cos(pi t) ]
-      float y = sr[0];
-      const int kmax = (H % 2) ? K : K - 1;
-      for (int k = 1; k < kmax; ++k) y += 2.0f * (sr[k] * s_cos[t * K + k] - si[k] * s_sin[t * K + k]);
-      if (!(H % 2)) y += sr[K - 1] * s_cos[t * K + K - 1];
-      y = y / (float)H / sigma;
-      float a = A.mean[t * U + d] + y * A.std[t * U + d];                      // :186
-      a = fminf(fmaxf(a, A.u_min[d]), A.u_max[d]);                              // :187
-      A.candidates[((long long)c * H + t) * U + d] = a;
-      for (int p = 0; p < A.P; ++p) A.actions[((long long)t * N + c * A.P + p) * U + d] = a;
+      float r = philox_normal(rng_seed, off, MBPO_STREAM_ICEM, base) * s_scale[k];
+      float im = philox_normal(rng_seed, off, MBPO_STREAM_ICEM, base + 1ull) * s_scale[k];
+      if (!(H % 2) && k == K - 1) {      // even length: the Nyquist coefficient is real (:193-197)
+        im = 0.f;
+        r *= 1.41421356237309504880f;
+      }
+      if (k == 0) {                      // the DC coefficient is real (:199-201)
+        im = 0.f;
+        r *= 1.41421356237309504880f;
+      }
+      s_r[idx] = r;
+      s_i[idx] = im;
     }
   }
+  __syncthreads();
+  const int j = threadIdx.x / H, t = threadIdx.x - j * H, sd = sd0 + j;
+  if (j >= SB || sd >= NC * U) return;
+  const int c = sd / U, d = sd - c * U;
+  float a;
+  if (c >= A.S) {        // previous elites ride along unchanged (:190)
+    a = A.prev_elites[((long long)(c - A.S) * H + t) * U + d];
+  } else {
+    const float *sr = s_r + j * K, *si = s_i + j * K;
+    // irfft: y_t = (1/H) [ s_0 + 2 sum_{0<k<H/2} (sr_k cos - si_k sin) + (H even) s_{H/2} cos(pi t) ]
+    float y = sr[0];
+    const int kmax = (H % 2) ? K : K - 1;
+    for (int k = 1; k < kmax; ++k) y += 2.0f * (sr[k] * s_cos[t * K + k] - si[k] * s_sin[t * K + k]);
+    if (!(H % 2)) y += sr[K - 1] * s_cos[t * K + K - 1];
+    y = y / (float)H / sigma;
+    a = A.mean[t * U + d] + y * A.std[t * U + d];                      // :186
+    a = fminf(fmaxf(a, A.u_min[d]), A.u_max[d]);                       // :187
+  }
+  A.candidates[((long long)c * H + t) * U + d] = a;
+  for (int p = 0; p < A.P; ++p) A.actions[((long long)t * N + c * A.P + p) * U + d] = a;
 }
 
 extern "C" int mbpo_icem_sample(const float *mean, const float *std, const float *prev_elites, const float *u_min, const float *u_max,
@@ -95,9 +103,10 @@ extern "C" int mbpo_icem_sample(const float *mean, const float *std, const float
   IcemSampleArgs A{mean, std, prev_elites, u_min, u_max, n_samples, n_prev, horizon, u_dim, n_particles, exponent, seed, offset, (const unsigned long long *)rng_dev,
                    actions, candidates};
   const int K = horizon / 2 + 1;
-  const size_t lds = sizeof(float) * (2ull * horizon * K + K);
   const int work = (n_samples + n_prev) * u_dim;
-  hipLaunchKernelGGL(k_icem_sample, dim3((work + 255) / 256), dim3(256), lds, (hipStream_t)stream, A);
+  const int SB = 256 / horizon;      // series per block of the one-thread-per-(series, step) form (horizon <= 128: SB >= 2)
+  const size_t lds = sizeof(float) * (2ull * horizon * K + K + 2ull * SB * K);
+  hipLaunchKernelGGL(k_icem_sample_par, dim3((work + SB - 1) / SB), dim3(256), lds, (hipStream_t)stream, A);
   MBPO_CHECK_LAUNCH("icem_sample");
   return MBPO_OK;
 }
