@@ -301,7 +301,6 @@ __global__ void __launch_bounds__(LEAN_THREADS) k_sac_lean(const SacLeanArgs A) 
       if (c == 0) {
         thin_col_request<KP>(*reinterpret_cast<float(*)[KP + 1]>(&tw[0]), pi_p, lane);
         img_fwd_request(I1, pi_p + N::P_W1, c0, lane);
-        img_fwd_request(I2, pi_p + N::P_W1 + HID, c0, lane);
         if (sub == 0) {
           img_out_request<2>(wo, pi_p + N::P_OUT, lane);
           bo0 = pi_p[N::P_OUT + LH * 2];
@@ -310,7 +309,6 @@ __global__ void __launch_bounds__(LEAN_THREADS) k_sac_lean(const SacLeanArgs A) 
       } else {
         thin_col_request<KQ>(tw, qk_p, lane);
         img_fwd_request(I1, qk_p + N::Q_W1, c0, lane);
-        img_fwd_request(I2, qk_p + N::Q_W1 + HID, c0, lane);
         if (sub == 1) {
           img_out_request<1>(wo, qk_p + N::Q_OUT, lane);
           bo0 = qk_p[N::Q_OUT + LH];
@@ -325,6 +323,8 @@ __global__ void __launch_bounds__(LEAN_THREADS) k_sac_lean(const SacLeanArgs A) 
       if (c == 0) thin_first<KP, false, false>(*reinterpret_cast<float(*)[KP + 1]>(&tw[0]), s_qin2, TILE(0), nullptr, nullptr, sub, lane);
       else thin_first<KQ, true, false>(tw, s_qin, TILE(7), TILE(4), nullptr, sub, lane);
       thin_col_request<KQ>(tw1, qt_p, lane);
+      // (the second hidden layer's images are requested here, not at the top: eight waves x 17 requests less in the prologue's burst)
+      img_fwd_request(I2, (c == 0 ? pi_p + N::P_W1 : qk_p + N::Q_W1) + HID, c0, lane);
       __syncthreads();
       LEAN_STAMP(2);
       // ---- F0 hidden layers; F1's two images are requested in their MFMA shadows ----
@@ -439,7 +439,6 @@ __global__ void __launch_bounds__(LEAN_THREADS) k_sac_lean(const SacLeanArgs A) 
       if (c == 0) {
         thin_col_request<KP>(tw, pi_p, lane);
         img_fwd_request(I1, pi_p + N::P_W1, c0, lane);
-        img_fwd_request(I2, pi_p + N::P_W1 + HID, c0, lane);
         if (sub == 0) {
           img_out_request<2>(wo, pi_p + N::P_OUT, lane);
           bo0 = pi_p[N::P_OUT + LH * 2];
@@ -448,7 +447,6 @@ __global__ void __launch_bounds__(LEAN_THREADS) k_sac_lean(const SacLeanArgs A) 
       } else {
         thin_col_request<KQ>(tw1, q_p, lane);
         img_fwd_request(J1, q_p + N::Q_W1, c0, lane);
-        img_fwd_request(J2, q_p + N::Q_W1 + HID, c0, lane);
         if (sub == 2) {
           img_out_request<1>(wo1, q_p + N::Q_OUT, lane);
           bq = q_p[N::Q_OUT + LH];
@@ -457,9 +455,13 @@ __global__ void __launch_bounds__(LEAN_THREADS) k_sac_lean(const SacLeanArgs A) 
       tile_to_lds();
       __syncthreads();
       LEAN_STAMP(1);
+      // (the second hidden layer's images are requested here, not at the top: eight waves x 17 requests less in the prologue's burst)
       if (c == 0) {
         thin_first<KP, true, false>(tw, s_qin, TILE(7), TILE(4), nullptr, sub, lane);
         thin_col_request<KQ>(tw1, q_p, lane);
+        img_fwd_request(I2, pi_p + N::P_W1 + HID, c0, lane);
+      } else {
+        img_fwd_request(J2, q_p + N::Q_W1 + HID, c0, lane);
       }
       __syncthreads();
       LEAN_STAMP(2);
