@@ -191,6 +191,18 @@ __global__ void __launch_bounds__(RL_THREADS) k_rollout_lean(const RoLeanArgs AA
   const int kc = (Kr + 3) >> 2;
   const int W1 = Kr * LH + LH, OUT = W1 + 2 * HID;
   const int i16 = lane & 15, g = lane >> 4;
+  // The small vectors that go to LDS are requested FIRST: vector-memory results return in order, so a store of something requested
+  // behind the 84 image requests waits for all of them (the bias table written at the end of the request list held every wave at the
+  // top of the kernel until its whole network had arrived).
+  float bv0 = 0.f, bv1 = 0.f, bv2 = 0.f;
+  if (lane < 32) {
+    bv0 = net_p[Kr * LH + c0 + lane];
+    bv1 = net_p[W1 + LH * LH + c0 + lane];
+    bv2 = net_p[W1 + HID + LH * LH + c0 + lane];
+  } else if (sub2 == 0 && lane < 48) {
+    const int q = lane - 32;
+    bv0 = (q < Nr) ? net_p[OUT + LH * Nr + q] : 0.f;
+  }
   Img0 I0;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -216,12 +228,11 @@ __global__ void __launch_bounds__(RL_THREADS) k_rollout_lean(const RoLeanArgs AA
   // the chain's bias vectors -> LDS
   float *const bias = smem + R_BIAS + chain * RL_NB;
   if (lane < 32) {
-    bias[c0 + lane] = net_p[Kr * LH + c0 + lane];
-    bias[LH + c0 + lane] = net_p[W1 + LH * LH + c0 + lane];
-    bias[2 * LH + c0 + lane] = net_p[W1 + HID + LH * LH + c0 + lane];
+    bias[c0 + lane] = bv0;
+    bias[LH + c0 + lane] = bv1;
+    bias[2 * LH + c0 + lane] = bv2;
   } else if (sub2 == 0 && lane < 48) {
-    const int q = lane - 32;
-    bias[3 * LH + q] = (q < Nr) ? net_p[OUT + LH * Nr + q] : 0.f;
+    bias[3 * LH + (lane - 32)] = bv0;
   }
   float *const tiles = smem + R_TILES + chain * 2 * LT;
   {
