@@ -35,6 +35,12 @@
 // odd float offsets of the flat layout (P = 8770, Q = 8769 at x = 4), so half of the 16-byte requests were 4- or 8-byte aligned; a
 // dword-granular copy (4 x the instructions) was not tried.  The kernel costs the same back to back on L2-warm parameters as behind
 // the optimizer launch (11.3 us both), so the prologue is not a cold-miss problem either; the per-wave strided requests stay.
+// What did pay (same session): WHERE the requests are issued.  A strided 64-lane dword request costs the issuing wave ~45 cycles
+// wherever it sits (F1's two images moved from the hidden steps' MFMA shadows into the thin step: that step +1.6 k cycles, the hidden
+// steps -1.0 k), and a wave's first burst delays the tile load of every wave behind the same address path.  The second hidden
+// layer's images are now requested in the thin-layer step instead of the prologue, and the actor role's idle chain issues all of its
+// requests behind the first barrier: 11.26 -> 10.8 us per launch; moving the output-layer images as well cost 0.3 us (the output
+// wave is the critical one).  A transposed shadow copy of the hidden matrices (4 x fewer, 16-byte requests) is the remaining idea.
 #include "common.hpp"
 #include "chain_run.hpp"
 #include "lean_blocks.hpp"
@@ -444,14 +450,7 @@ __global__ void __launch_bounds__(LEAN_THREADS) k_sac_lean(const SacLeanArgs A) 
           bo0 = pi_p[N::P_OUT + LH * 2];
           bo1 = pi_p[N::P_OUT + LH * 2 + 1];
         }
-      } else {
-        thin_col_request<KQ>(tw1, q_p, lane);
-        img_fwd_request(J1, q_p + N::Q_W1, c0, lane);
-        if (sub == 2) {
-          img_out_request<1>(wo1, q_p + N::Q_OUT, lane);
-          bq = q_p[N::Q_OUT + LH];
-        }
-      }
+      }      // (chain 1 walks nothing before F1: its requests wait behind the first barrier, out of the launch's first burst)
       tile_to_lds();
       __syncthreads();
       LEAN_STAMP(1);
@@ -461,7 +460,13 @@ __global__ void __launch_bounds__(LEAN_THREADS) k_sac_lean(const SacLeanArgs A) 
         thin_col_request<KQ>(tw1, q_p, lane);
         img_fwd_request(I2, pi_p + N::P_W1 + HID, c0, lane);
       } else {
+        thin_col_request<KQ>(tw1, q_p, lane);
+        img_fwd_request(J1, q_p + N::Q_W1, c0, lane);
         img_fwd_request(J2, q_p + N::Q_W1 + HID, c0, lane);
+        if (sub == 2) {
+          img_out_request<1>(wo1, q_p + N::Q_OUT, lane);
+          bq = q_p[N::Q_OUT + LH];
+        }
       }
       __syncthreads();
       LEAN_STAMP(2);
