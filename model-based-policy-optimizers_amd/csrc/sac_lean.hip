@@ -42,7 +42,9 @@
 // requests behind the first barrier: 11.26 -> 10.8 us per launch; moving the output-layer images as well cost 0.3 us (the output
 // wave is the critical one).  A transposed copy of the hidden matrices (4 x fewer, 16-byte requests per lane) was timed with the request
 // pattern alone before building it: 12.7 us — a lane's 64 contiguous bytes sit 256 bytes from its neighbour's, so one request touches
-// 64 separate 64-byte segments where the strided dword request touches four.
+// 64 separate 64-byte segments where the strided dword request touches four.  Image-major copies were timed the same way: 16 fully
+// contiguous dword requests per image 10.8 us (no change), four contiguous 1-KB requests per image 11.2 us (worse).  The request
+// pattern is not the lever; a reordered copy of the weights is not worth keeping.
 #include "common.hpp"
 #include "chain_run.hpp"
 #include "lean_blocks.hpp"
