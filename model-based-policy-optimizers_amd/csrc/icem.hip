@@ -106,6 +106,10 @@ extern "C" int mbpo_icem_sample(const float *mean, const float *std, const float
   const int work = (n_samples + n_prev) * u_dim;
   const int SB = 256 / horizon;      // series per block of the one-thread-per-(series, step) form (horizon <= 128: SB >= 2)
   const size_t lds = sizeof(float) * (2ull * horizon * K + K + 2ull * SB * K);
+  {      // (horizons above ~120 need more than the default 64 KB of dynamic LDS for the cos / sin tables)
+    const int rc = mbpo_ensure_lds<k_icem_sample_par>(lds, "icem_sample");
+    if (rc != MBPO_OK) return rc;
+  }
   hipLaunchKernelGGL(k_icem_sample_par, dim3((work + SB - 1) / SB), dim3(256), lds, (hipStream_t)stream, A);
   MBPO_CHECK_LAUNCH("icem_sample");
   return MBPO_OK;

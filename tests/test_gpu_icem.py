@@ -21,7 +21,7 @@ def _lib():
     return _hip, _hip.load()
 
 
-@pytest.mark.parametrize("H,U,S,Kp,P,beta", [(20, 1, 500, 15, 10, 0.0), (21, 2, 64, 3, 2, 2.0), (8, 3, 17, 1, 1, 0.25), (64, 1, 33, 5, 3, 1.0)])
+@pytest.mark.parametrize("H,U,S,Kp,P,beta", [(20, 1, 500, 15, 10, 0.0), (21, 2, 64, 3, 2, 2.0), (8, 3, 17, 1, 1, 0.25), (64, 1, 33, 5, 3, 1.0), (128, 2, 40, 4, 2, 1.0), (127, 1, 9, 0, 1, 0.5)])
 def test_icem_sample_parity(dev, H, U, S, Kp, P, beta):
     _hip, lib = _lib()
     g = torch.Generator().manual_seed(H + U)
