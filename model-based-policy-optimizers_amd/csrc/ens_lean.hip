@@ -1,5 +1,5 @@
 // ens_lean.hip — k_ens_fwd_lean<K>: mbpo_ensemble_mlp_forward (R2 of SURVEY §8a: the vmapped Dynamics.next_state of a learned ensemble,
-// base_dynamics.py:15-20) for member networks K -> 64 -> 64 -> 64 -> N (K = x + u in {4, 5}, N <= 16, swish), in the THROUGHPUT regime.
+// base_dynamics.py:15-20) for member networks K -> 64 -> 64 -> 64 -> N (K = x + u in 3 .. 7, N <= 16, swish), in the THROUGHPUT regime.
 //
 // The generic k_ensemble_forward (rollout.hip) gives every (16-row tile, member) chain to ONE wave that re-requests each layer's 16 KB
 // of weights for every tile and walks 64 MFMAs per layer alone: 20 % of the fp32-MFMA roof at N = 32768 rows.
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(512, 4) k_ens_fwd_lean(const EnsLeanArgs A) {
 
 bool ens_lean_supports(const int *dims, int n_layers, int act) {
   if (n_layers != 4 || act != MBPO_ACT_SWISH) return false;
-  if (dims[0] != 4 && dims[0] != 5) return false;
+  if (dims[0] < 3 || dims[0] > 7) return false;
   for (int l = 1; l <= 3; ++l)
     if (dims[l] != LH) return false;
   return dims[4] >= 1 && dims[4] <= 16;
@@ -113,15 +113,17 @@ int ens_lean_launch(const EnsLeanArgs &A, int K, int n_cus, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   const int grid = A.E * A.wgs_per_member;
   int rc;
-  if (K == 4) {
-    rc = mbpo_ensure_lds<k_ens_fwd_lean<4>>(ENS_LEAN_LDS_BYTES, "ens_lean");
-    if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL(k_ens_fwd_lean<4>, dim3(grid), dim3(512), ENS_LEAN_LDS_BYTES, st, A);
-  } else if (K == 5) {
-    rc = mbpo_ensure_lds<k_ens_fwd_lean<5>>(ENS_LEAN_LDS_BYTES, "ens_lean");
-    if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL(k_ens_fwd_lean<5>, dim3(grid), dim3(512), ENS_LEAN_LDS_BYTES, st, A);
-  } else {
+#define EL_K_(K_)                                                                                     \
+  if (K == K_) {                                                                                      \
+    rc = mbpo_ensure_lds<k_ens_fwd_lean<K_>>(ENS_LEAN_LDS_BYTES, "ens_lean");                         \
+    if (rc != MBPO_OK) return rc;                                                                     \
+    hipLaunchKernelGGL(k_ens_fwd_lean<K_>, dim3(grid), dim3(512), ENS_LEAN_LDS_BYTES, st, A);         \
+    (void)n_cus;                                                                                      \
+    return MBPO_OK;                                                                                   \
+  }
+  EL_K_(3) EL_K_(4) EL_K_(5) EL_K_(6) EL_K_(7)
+#undef EL_K_
+  {
     mbpo_set_error("ens_lean: %d inputs have no instantiation", K);
     return MBPO_ERR_UNSUPPORTED;
   }

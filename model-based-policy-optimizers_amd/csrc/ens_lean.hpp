@@ -11,6 +11,6 @@ struct EnsLeanArgs {
   int E, N, shared_input, wgs_per_member;
 };
 
-// K inputs in {4, 5}, three 64-wide hidden layers, N <= 16 outputs, swish
+// K = 3 .. 7 inputs, three 64-wide hidden layers, N <= 16 outputs, swish
 bool ens_lean_supports(const int *dims, int n_layers, int act);
 int ens_lean_launch(const EnsLeanArgs &A, int K, int n_cus, void *stream);

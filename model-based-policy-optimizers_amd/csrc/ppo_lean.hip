@@ -554,15 +554,16 @@ int ppo_vg_lean_launch(const PpoVgLeanArgs &A, int x_dim, int n_wgs, size_t arr_
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)(VG_ARR + arr_floats) * sizeof(float);
   int rc;
-  if (x_dim == 3) {
-    rc = mbpo_ensure_lds<k_ppo_vg_lean<3>>(lds, "ppo_vg_lean");
-    if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL(k_ppo_vg_lean<3>, dim3(n_wgs), dim3(512), lds, st, A);
-  } else if (x_dim == 4) {
-    rc = mbpo_ensure_lds<k_ppo_vg_lean<4>>(lds, "ppo_vg_lean");
-    if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL(k_ppo_vg_lean<4>, dim3(n_wgs), dim3(512), lds, st, A);
-  } else {
+#define VG_X_(X_)                                                                       \
+  if (x_dim == X_) {                                                                    \
+    rc = mbpo_ensure_lds<k_ppo_vg_lean<X_>>(lds, "ppo_vg_lean");                        \
+    if (rc != MBPO_OK) return rc;                                                       \
+    hipLaunchKernelGGL(k_ppo_vg_lean<X_>, dim3(n_wgs), dim3(512), lds, st, A);          \
+    return MBPO_OK;                                                                     \
+  }
+  VG_X_(2) VG_X_(3) VG_X_(4) VG_X_(5) VG_X_(6)
+#undef VG_X_
+  {
     mbpo_set_error("ppo_vg_lean: x_dim %d has no instantiation", x_dim);
     return MBPO_ERR_UNSUPPORTED;
   }
@@ -571,7 +572,7 @@ int ppo_vg_lean_launch(const PpoVgLeanArgs &A, int x_dim, int n_wgs, size_t arr_
 
 bool ppo_lean_supports(int x_dim, int u_dim, const int *policy_dims, int policy_layers, int policy_act, const int *value_dims, int value_layers,
                        int value_act) {
-  if (u_dim != 1 || (x_dim != 3 && x_dim != 4)) return false;
+  if (u_dim != 1 || x_dim < 2 || x_dim > 6) return false;
   if (policy_layers != 4 || value_layers != 4 || policy_act != MBPO_ACT_SWISH || value_act != MBPO_ACT_SWISH) return false;
   for (int l = 1; l <= 3; ++l)
     if (policy_dims[l] != LH || value_dims[l] != LH) return false;
@@ -581,15 +582,16 @@ bool ppo_lean_supports(int x_dim, int u_dim, const int *policy_dims, int policy_
 int ppo_lean_launch(const PpoLeanArgs &A, int x_dim, int n_wgs, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (x_dim == 3) {
-    rc = mbpo_ensure_lds<k_ppo_lean<3>>(PPO_LEAN_LDS_BYTES, "ppo_lean");
-    if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL(k_ppo_lean<3>, dim3(n_wgs), dim3(512), PPO_LEAN_LDS_BYTES, st, A);
-  } else if (x_dim == 4) {
-    rc = mbpo_ensure_lds<k_ppo_lean<4>>(PPO_LEAN_LDS_BYTES, "ppo_lean");
-    if (rc != MBPO_OK) return rc;
-    hipLaunchKernelGGL(k_ppo_lean<4>, dim3(n_wgs), dim3(512), PPO_LEAN_LDS_BYTES, st, A);
-  } else {
+#define PL_X_(X_)                                                                                   \
+  if (x_dim == X_) {                                                                                \
+    rc = mbpo_ensure_lds<k_ppo_lean<X_>>(PPO_LEAN_LDS_BYTES, "ppo_lean");                           \
+    if (rc != MBPO_OK) return rc;                                                                   \
+    hipLaunchKernelGGL(k_ppo_lean<X_>, dim3(n_wgs), dim3(512), PPO_LEAN_LDS_BYTES, st, A);          \
+    return MBPO_OK;                                                                                 \
+  }
+  PL_X_(2) PL_X_(3) PL_X_(4) PL_X_(5) PL_X_(6)
+#undef PL_X_
+  {
     mbpo_set_error("ppo_lean: x_dim %d has no instantiation", x_dim);
     return MBPO_ERR_UNSUPPORTED;
   }

@@ -17,7 +17,7 @@ struct PpoLeanArgs {
   unsigned long long *stamps;           // measurement hook (mbpo_debug_set_ppo_stamps): s_memtime per section of workgroup 0's first tiles, or NULL
 };
 
-// policy x -> 64^3 -> 2, value x -> 64^3 -> 1, swish, u = 1, x in {3, 4}
+// policy x -> 64^3 -> 2, value x -> 64^3 -> 1, swish, u = 1, x = 2 .. 6
 bool ppo_lean_supports(int x_dim, int u_dim, const int *policy_dims, int policy_layers, int policy_act, const int *value_dims, int value_layers,
                        int value_act);
 // one workgroup per CU (n_wgs <= tiles), each walks tiles blockIdx.x, + n_wgs, ... and leaves ONE slab

@@ -1,6 +1,6 @@
 // rollout_lean.hip — k_rollout_lean<X>: the fused model rollout (R1-R8 of SURVEY §8a: get_experience / generate_unroll, sac/acting.py:
 // 25-79 over the BraxWrapper step, brax_utils/training.py:85-137) specialised for the benchmark networks: policy X -> 64 -> 64 -> 64 -> 2,
-// members (X + 1) -> 64 -> 64 -> 64 -> (X | 2X), swish, u = 1, at most five members (or the analytic Pendulum system), action_repeat 1.
+// members (X + 1) -> 64 -> 64 -> 64 -> (X | 2X), swish, u = 1, X = 2 .. 4, at most five members (or the analytic Pendulum system), action_repeat 1.
 //
 // The generic k_model_rollout64 (rollout.hip) walks the same 16-env tile per workgroup on the shared runners: every layer of every chain
 // re-requests its weights each env step, activations go to LDS as 4 x b32 per lane, four bookkeeping sections of all 768 threads sit
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(RL_THREADS) k_rollout_lean(const RoLeanArgs AA
 bool rollout_lean_supports(const RolloutArgs &A, bool has_policy, int E) {
   if (!has_policy || A.actions) return false;
   const int X = A.x_dim;
-  if (A.u_dim != 1 || (X != 3 && X != 4) || A.action_repeat != 1) return false;
+  if (A.u_dim != 1 || X < 2 || X > 4 || A.action_repeat != 1) return false;      // (the state wave holds 16 envs x <= 4 obs elements)
   auto net_ok = [](const MlpDev &m, int k_in) {
     if (m.n_layers != 4 || m.act != MBPO_ACT_SWISH || m.dims[0] != k_in) return false;
     for (int l = 1; l <= 3; ++l)
@@ -499,12 +499,16 @@ int rollout_lean_launch(const RoLeanArgs &A, int grid, bool pipe, void *stream) 
   if (pipe) {
     if (A.a.x_dim == 3) {
       if (pend) RL_LAUNCH(3, true, true) else RL_LAUNCH(3, false, true)
+    } else if (A.a.x_dim == 2) {
+      RL_LAUNCH(2, false, true)
     } else {
       RL_LAUNCH(4, false, true)
     }
   } else {
     if (A.a.x_dim == 3) {
       if (pend) RL_LAUNCH(3, true, false) else RL_LAUNCH(3, false, false)
+    } else if (A.a.x_dim == 2) {
+      RL_LAUNCH(2, false, false)
     } else {
       RL_LAUNCH(4, false, false)
     }

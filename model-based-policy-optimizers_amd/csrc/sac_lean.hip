@@ -1,5 +1,5 @@
 // sac_lean.hip — k_sac_lean<X>: the SAC forward/backward launch (S3-S6 of sgd_step, sac/sac.py:227-281, sac/losses.py:61-125)
-// specialised for the benchmark networks: policy X -> 64 -> 64 -> 64 -> 2, critics X+1 -> 64 -> 64 -> 64 -> 1, swish, u = 1.
+// specialised for the benchmark networks: policy X -> 64 -> 64 -> 64 -> 2, critics X+1 -> 64 -> 64 -> 64 -> 1, swish, u = 1, X = 2 .. 6.
 //
 // Why a second kernel (round 4): the generic k_sac_fwd_bwd (sac.hip) serves every shape from kernel-argument tables — chain
 // descriptors, NetShape scalars, one runner per chain kind — and sits at 104 SGPRs with 219 spilled to VGPR lanes, 3.5 KB of
@@ -601,7 +601,7 @@ int launch_x(const SacLeanArgs &A, int n_tiles, hipStream_t st) {
 }  // namespace
 
 bool sac_lean_supports(int x_dim, int u_dim, const int *policy_dims, int policy_layers, int policy_act, const int *q_dims, int q_layers, int q_act) {
-  if (u_dim != 1 || (x_dim != 3 && x_dim != 4)) return false;
+  if (u_dim != 1 || x_dim < 2 || x_dim > 6) return false;      // (layer 0's weight gradient takes x + 2 of the eight chain waves)
   if (policy_layers != 4 || q_layers != 4 || policy_act != MBPO_ACT_SWISH || q_act != MBPO_ACT_SWISH) return false;
   for (int l = 1; l <= 3; ++l)
     if (policy_dims[l] != LH || q_dims[l] != LH) return false;
@@ -612,6 +612,16 @@ int sac_lean_launch(const SacLeanArgs &A, int x_dim, int n_tiles, void *stream) 
   hipStream_t st = (hipStream_t)stream;
   if (x_dim == 3) return launch_x<3>(A, n_tiles, st);
   if (x_dim == 4) return launch_x<4>(A, n_tiles, st);
+  // other observation widths: the plain instantiation only (no in-kernel timeline)
+#define LEAN_X(X_)                                                                                                    \
+  if (x_dim == X_) {                                                                                                  \
+    int rc = mbpo_ensure_lds<k_sac_lean<X_, false>>(LEAN_LDS_BYTES, "sac_lean");                                      \
+    if (rc != MBPO_OK) return rc;                                                                                     \
+    hipLaunchKernelGGL((k_sac_lean<X_, false>), dim3(3 * n_tiles), dim3(LEAN_THREADS), LEAN_LDS_BYTES, st, A);        \
+    return MBPO_OK;                                                                                                   \
+  }
+  LEAN_X(2) LEAN_X(5) LEAN_X(6)
+#undef LEAN_X
   mbpo_set_error("sac_lean: x_dim %d has no instantiation", x_dim);
   return MBPO_ERR_UNSUPPORTED;
 }

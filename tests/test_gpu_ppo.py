@@ -201,6 +201,9 @@ def test_ppo_fused_step_equals_grads_plus_apply(dev):
     (3, 512, 40, True, True, True),       # BASELINE configs[2] at full size: 1280 tiles, 5 per workgroup
     (4, 512, 5, True, True, False),       # horizon-5 unrolls, in-kernel Philox entropy noise, one tile per workgroup
     (4, 37, 3, False, False, True),       # ragged: M = 111 rows, the last tile holds 15
+    (2, 64, 10, True, True, False),       # the other observation widths the kernels are instantiated for
+    (5, 128, 8, True, True, True),
+    (6, 50, 7, False, True, False),
 ])
 def test_ppo_lean_kernel_matches_generic_kernel(dev, X, B, T, normalize, norm_adv, given_noise):
     """k_ppo_lean (csrc/ppo_lean.hip: the loss forward/backward specialised for the 64x3 benchmark networks — weights resident in

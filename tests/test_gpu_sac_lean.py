@@ -66,6 +66,9 @@ def _run(dev, lean, cfg, st, batch, noise, nm, ns, B, steps=1, given_noise=True,
     (3, 40, True, True),         # ragged: the last tile holds 8 rows
     (4, 16, False, True),        # one tile
     (4, 2048, True, False),      # 128 tiles x 3 roles = 384 workgroups: more than the chip holds at once
+    (2, 96, True, False),        # the other observation widths the kernel is instantiated for
+    (5, 256, True, True),
+    (6, 200, False, False),      # x + 2 = all eight chain waves in layer 0's weight gradient; ragged last tile
 ])
 def test_lean_kernel_equals_generic_kernel_bit_for_bit(dev, X, B, normalize, given_noise):
     cfg, st, batch, noise, nm, ns = _make(X, 1, (64, 64, 64), B, 3, normalize, discounting=0.97, reward_scaling=1.5,
