@@ -38,11 +38,13 @@ __device__ __forceinline__ void p2p_push(const P2pDev &P, unsigned epoch, long l
   if (i < n) {
     for (int p = 0; p < P.world; ++p) __builtin_nontemporal_store(v, P.slots[p] + off);
   }
-  // Publish: every wave drains its own stores (the barrier's s_waitcnt vmcnt(0)), then ONE release at system scope by the first wave
+  // Publish: every wave drains its own stores (an EXPLICIT s_waitcnt vmcnt(0): __syncthreads() alone does not wait for a wave's global
+  // stores — a workgroup-scope release needs no vmcnt wait on this target), then ONE release at system scope by the first wave
   // covers the workgroup's stores, and lanes 0..world-1 of that wave add the arrival to THEIR peer's counter side by side — relaxed,
   // results unused.  (Rounds 1-3 fenced in every thread and then let one thread issue `world` release-ordered adds one after the
   // other: each of those waits for the previous remote add to complete before its own fence retires — `world` xGMI round trips in a
   // row per workgroup, invisible with two ranks on one GPU and an order of magnitude over the latency budget of DESIGN section 6.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x < 64) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
