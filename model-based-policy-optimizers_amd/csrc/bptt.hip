@@ -422,6 +422,9 @@ __global__ void __launch_bounds__(512) k_bptt_actor(BpttArgs A) {
           }
         } else if (elem == E_RELOAD) {
           if (t == HZ - 1) {
+            // (the forward sweep's stores of this wave — checkpoints, member pre-activations — have left it before anything of the
+            //  backward sweep is requested; the op's closing barrier then orders them against every wave's reloads)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ===== lambda returns (once per tile, between the sweeps): R_t = r~_t + g(1-l)V_t + g*l*R_{t+1} =====
             if (tid < 16) {
               const long long i = row0 + tid;
