@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(1024) k_icem_update(IcemUpdateArgs A) {
     }
     A.rank[c] = r;
   }
-  __threadfence_block();
+  __threadfence();      // (agent scope: the ranks are re-read from global memory by other waves behind the barrier)
   __syncthreads();
   const int first = NC - A.n_elites;      // elites = sorted positions [first, NC)
   // the best elite (rank NC-1) and the best-so-far sequence (:212-221)
