@@ -31,7 +31,8 @@ __global__ void __launch_bounds__(512, 4) k_ens_fwd_lean(const EnsLeanArgs A) {
   const int N = A.N;
   const long long n_rows = A.n_rows, n_tiles = (n_rows + 15) >> 4;
   const float *const net_p = A.params + (long long)e * A.net_stride;
-  constexpr int W1 = K * LH + LH, OUT = W1 + 2 * HID;
+  constexpr int W1 = K * LH + LH;
+  const int nh = A.n_hid, OUT = W1 + nh * HID;
   float *const tiles = smem + E_TILES + c * 3 * LT;
 
   // ---- this chain's rows of the first pair (requested before the weights: results return in order) ----
@@ -57,7 +58,7 @@ __global__ void __launch_bounds__(512, 4) k_ens_fwd_lean(const EnsLeanArgs A) {
   float wo[16], bo[4];
   thin_col_request<K>(tw, net_p, lane);
   img_fwd_request(I1, net_p + W1, c0, lane);
-  img_fwd_request(I2, net_p + W1 + HID, c0, lane);
+  img_fwd_request(I2, net_p + W1 + (nh - 1) * HID, c0, lane);      // (one 64 x 64 layer: requested again, never used)
   const bool out_wave = sub == c;                                      // waves 0 and 5: different SIMDs
   if (out_wave) {
     const int i = lane & 15, g = lane >> 4;
@@ -79,10 +80,12 @@ __global__ void __launch_bounds__(512, 4) k_ens_fwd_lean(const EnsLeanArgs A) {
     __syncthreads();
     hid_fwd<false>(I1, tiles, tiles + LT, nullptr, c0, lane);
     __syncthreads();
-    hid_fwd<false>(I2, tiles + LT, tiles + 2 * LT, nullptr, c0, lane);
-    __syncthreads();
+    if (nh == 2) {
+      hid_fwd<false>(I2, tiles + LT, tiles + 2 * LT, nullptr, c0, lane);
+      __syncthreads();
+    }
     if (out_wave && tile < n_tiles) {
-      const f32x4 acc = out_fwd(wo, tiles + 2 * LT, lane);
+      const f32x4 acc = out_fwd(wo, tiles + nh * LT, lane);
       const int j = lane & 15, g = lane >> 4;
       const long long row = tile * 16 + j;
       if (row < n_rows && 4 * g < N) {
@@ -102,11 +105,11 @@ __global__ void __launch_bounds__(512, 4) k_ens_fwd_lean(const EnsLeanArgs A) {
 }
 
 bool ens_lean_supports(const int *dims, int n_layers, int act) {
-  if (n_layers != 4 || act != MBPO_ACT_SWISH) return false;
+  if ((n_layers != 4 && n_layers != 3) || act != MBPO_ACT_SWISH) return false;
   if (dims[0] < 3 || dims[0] > 7) return false;
-  for (int l = 1; l <= 3; ++l)
+  for (int l = 1; l < n_layers; ++l)
     if (dims[l] != LH) return false;
-  return dims[4] >= 1 && dims[4] <= 16;
+  return dims[n_layers] >= 1 && dims[n_layers] <= 16;
 }
 
 int ens_lean_launch(const EnsLeanArgs &A, int K, int n_cus, void *stream) {

@@ -129,6 +129,7 @@ extern "C" int mbpo_ensemble_mlp_forward(const mbpo_mlp_desc *mlp, const float *
       if (wpm < 1) wpm = 1;
       if (wpm > pairs) wpm = pairs;
       L.wgs_per_member = (int)wpm;
+      L.n_hid = A.mlp.n_layers - 2;
       rc = ens_lean_launch(L, A.mlp.dims[0], num_cus(), stream);
       if (rc != MBPO_OK) return rc;
       MBPO_CHECK_LAUNCH("ensemble_mlp_forward");

@@ -1,5 +1,6 @@
 // rollout_lean.hip — k_rollout_lean<X>: the fused model rollout (R1-R8 of SURVEY §8a: get_experience / generate_unroll, sac/acting.py:
-// 25-79 over the BraxWrapper step, brax_utils/training.py:85-137) specialised for the benchmark networks: policy X -> 64 -> 64 -> 64 -> 2,
+// 25-79 over the BraxWrapper step, brax_utils/training.py:85-137) specialised for the benchmark networks: policy X -> 64 -> 64 -> 64 -> 2
+// (or the reference experiments' 64 x 2: one hidden-to-hidden layer less, a run-time count per network),
 // members (X + 1) -> 64 -> 64 -> 64 -> (X | 2X), swish, u = 1, X = 2 .. 4, at most five members (or the analytic Pendulum system), action_repeat 1.
 //
 // The generic k_model_rollout64 (rollout.hip) walks the same 16-env tile per workgroup on the shared runners: every layer of every chain
@@ -189,7 +190,8 @@ __global__ void __launch_bounds__(RL_THREADS) k_rollout_lean(const RoLeanArgs AA
   const float *const net_p = member ? A.dyn.params + (long long)(chain - 1) * A.dyn.net_stride : A.policy.params;
   const int Kr = member ? K : X, Nr = member ? AA.n_dyn_out : 2;
   const int kc = (Kr + 3) >> 2;
-  const int W1 = Kr * LH + LH, OUT = W1 + 2 * HID;
+  const int nh = (member ? A.dyn.n_layers : A.policy.n_layers) - 2;      // 64 x 64 layers of this wave's network: 2 (64 x 3 nets) or 1 (64 x 2)
+  const int W1 = Kr * LH + LH, OUT = W1 + nh * HID;
   const int i16 = lane & 15, g = lane >> 4;
   // The small vectors that go to LDS are requested FIRST: vector-memory results return in order, so a store of something requested
   // behind the 84 image requests waits for all of them (the bias table written at the end of the request list held every wave at the
@@ -198,7 +200,7 @@ __global__ void __launch_bounds__(RL_THREADS) k_rollout_lean(const RoLeanArgs AA
   if (lane < 32) {
     bv0 = net_p[Kr * LH + c0 + lane];
     bv1 = net_p[W1 + LH * LH + c0 + lane];
-    bv2 = net_p[W1 + HID + LH * LH + c0 + lane];
+    bv2 = net_p[W1 + (nh - 1) * HID + LH * LH + c0 + lane];
   } else if (sub2 == 0 && lane < 48) {
     const int q = lane - 32;
     bv0 = (q < Nr) ? net_p[OUT + LH * Nr + q] : 0.f;
@@ -217,8 +219,8 @@ __global__ void __launch_bounds__(RL_THREADS) k_rollout_lean(const RoLeanArgs AA
   float w1a[16], w1b[16], w2a[16], w2b[16];
   img_w_request(w1a, net_p + W1, c0, lane);
   img_w_request(w1b, net_p + W1, c0 + 16, lane);
-  img_w_request(w2a, net_p + W1 + HID, c0, lane);
-  img_w_request(w2b, net_p + W1 + HID, c0 + 16, lane);
+  img_w_request(w2a, net_p + W1 + (nh - 1) * HID, c0, lane);      // (a network with one 64 x 64 layer: requested again, never used)
+  img_w_request(w2b, net_p + W1 + (nh - 1) * HID, c0 + 16, lane);
   float wo[16];
   {
     const float *p = net_p + OUT + (16 * g) * Nr + (i16 < Nr ? i16 : 0);      // matrix row i = output column i
@@ -298,10 +300,10 @@ __global__ void __launch_bounds__(RL_THREADS) k_rollout_lean(const RoLeanArgs AA
         __syncthreads();
         if (mine) hid_fwd2(w1a, w1b, bias + LH, tiles, tiles + LT, c0, lane);
         __syncthreads();
-        if (mine) hid_fwd2(w2a, w2b, bias + 2 * LH, tiles + LT, tiles, c0, lane);
+        if (mine && nh == 2) hid_fwd2(w2a, w2b, bias + 2 * LH, tiles + LT, tiles, c0, lane);
         __syncthreads();
         if (mine && sub2 == 0) {
-          const f32x4 acc = out_fwd(wo, tiles, lane);
+          const f32x4 acc = out_fwd(wo, nh == 2 ? tiles : tiles + LT, lane);
           float bo[4];
           load_vec_lds<4>(bias + 3 * LH + 4 * g, bo);
           if (!pol) {
@@ -312,9 +314,9 @@ __global__ void __launch_bounds__(RL_THREADS) k_rollout_lean(const RoLeanArgs AA
           }
         } else if (wave == 1 && lane < 16) {
           // the noise of the NEXT half-step's policy tile (this wave idles through the output layer)
-          const int nh = h + 1, nslot = nh & 1;
-          if (nh < 2 * S && (nslot == 0 || validB))
-            smem[(nslot ? R_SLOT1 : R_SLOT0) + S_EPS + lane] = rl_noise(A, nh >> 1, (2 * pair + nslot) * 16, lane, rng_seed, rng_off);
+          const int nxt = h + 1, nslot = nxt & 1;
+          if (nxt < 2 * S && (nslot == 0 || validB))
+            smem[(nslot ? R_SLOT1 : R_SLOT0) + S_EPS + lane] = rl_noise(A, nxt >> 1, (2 * pair + nslot) * 16, lane, rng_seed, rng_off);
         }
         __syncthreads();
         if (is_sw && my_slot == ms && mv) {
@@ -411,11 +413,11 @@ __global__ void __launch_bounds__(RL_THREADS) k_rollout_lean(const RoLeanArgs AA
         if (mine) hid_fwd2(w1a, w1b, bias + LH, tiles, tiles + LT, c0, lane);
         __syncthreads();
         RL_STAMP(4 * ph + 2);
-        if (mine) hid_fwd2(w2a, w2b, bias + 2 * LH, tiles + LT, tiles, c0, lane);
+        if (mine && nh == 2) hid_fwd2(w2a, w2b, bias + 2 * LH, tiles + LT, tiles, c0, lane);
         __syncthreads();
         RL_STAMP(4 * ph + 3);
         if (mine && sub2 == 0) {
-          const f32x4 acc = out_fwd(wo, tiles, lane);
+          const f32x4 acc = out_fwd(wo, nh == 2 ? tiles : tiles + LT, lane);
           float bo[4];
           load_vec_lds<4>(bias + 3 * LH + 4 * g, bo);
           if (ph == 1) {
@@ -471,15 +473,15 @@ bool rollout_lean_supports(const RolloutArgs &A, bool has_policy, int E) {
   const int X = A.x_dim;
   if (A.u_dim != 1 || X < 2 || X > 4 || A.action_repeat != 1) return false;      // (the state wave holds 16 envs x <= 4 obs elements)
   auto net_ok = [](const MlpDev &m, int k_in) {
-    if (m.n_layers != 4 || m.act != MBPO_ACT_SWISH || m.dims[0] != k_in) return false;
-    for (int l = 1; l <= 3; ++l)
+    if ((m.n_layers != 4 && m.n_layers != 3) || m.act != MBPO_ACT_SWISH || m.dims[0] != k_in) return false;
+    for (int l = 1; l < m.n_layers; ++l)
       if (m.dims[l] != LH) return false;
     return true;
   };
-  if (!net_ok(A.policy, X) || A.policy.dims[4] != 2) return false;
+  if (!net_ok(A.policy, X) || A.policy.dims[A.policy.n_layers] != 2) return false;
   if (A.system_kind == MBPO_SYS_ENSEMBLE) {
     if (E < 1 || E > RL_MAX_E || !net_ok(A.dyn, X + 1)) return false;
-    if (A.dyn.dims[4] != X && A.dyn.dims[4] != 2 * X) return false;
+    if (A.dyn.dims[A.dyn.n_layers] != X && A.dyn.dims[A.dyn.n_layers] != 2 * X) return false;
   } else if (A.system_kind != MBPO_SYS_PENDULUM || X != 3) {
     return false;
   }

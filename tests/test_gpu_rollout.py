@@ -46,6 +46,7 @@ def _ens_params(dims, E, seed):
     ([3, 64, 64, 64, 4], 4, 555, "swish"),         # the other input widths the lean kernel is instantiated for
     ([6, 64, 64, 64, 10], 2, 70, "swish"),
     ([7, 64, 64, 64, 12], 3, 129, "swish"),
+    ([4, 64, 64, 6], 5, 2000, "swish"),            # two hidden layers (the reference experiments' 64 x 2)
 ])
 def test_ensemble_forward_parity(dev, dims, E, N, act):
     from mbpo import ops
@@ -312,7 +313,8 @@ def _set_rollout_lean(mode: int) -> None:
     dict(N=33, S=4, L=9, X=4, system="ensemble", E=1, mode="mean", deterministic=True),
     dict(N=9000, S=3, L=2, X=4, system="ensemble", E=5, mode="mean", normalize=True),          # 563 tiles: the default picks two in flight
     dict(N=16, S=1, L=5, X=4, system="ensemble", E=2, mode="mean"),                           # one tile, one step
-    dict(N=300, S=6, L=4, X=2, system="ensemble", E=4, mode="ts1", sample_noise=True, normalize=True),   # two observation elements
+    dict(N=300, S=6, L=4, X=2, system="ensemble", E=4, mode="ts1", sample_noise=True, normalize=True),   # two observation elements    dict(N=1000, S=5, L=3, X=3, system="pendulum", ppo=True, env_major=True, normalize=True, hidden=(64, 64)),      # tests/test_ppo.py's policy
+    dict(N=9000, S=4, L=3, X=4, system="ensemble", E=5, mode="mean", hidden=(64, 64)),                          # 64 x 2 policy and members, both forms
 ])
 def test_rollout_lean_equals_generic_kernel(dev, kw):
     """k_rollout_lean (csrc/rollout_lean.hip: weights resident in registers, 16-byte activation stores, one bookkeeping section per
