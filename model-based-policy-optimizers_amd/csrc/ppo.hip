@@ -623,6 +623,7 @@ struct PpoPlan {
   // values + GAE + moment partials in one launch (k_ppo_values_gae): vg_G trajectories per workgroup, n_vg workgroups; 0 = the three
   // separate launches (layered shapes; trajectories too long for a workgroup's LDS arrays; MBPO_PPO_VALUES_GAE=0)
   int vg_G, n_vg;
+  bool vg_lean;              // k_ppo_vg_lean instead of k_ppo_values_gae
   size_t lds_vg;
   long long off_mompart;
   // hidden layers outside the fused kernels' range (one width in {64,128}): values pre-pass and loss forward/backward run layer by
@@ -721,6 +722,9 @@ static int ppo_plan(const mbpo_ppo_desc *d, PpoPlan *pl, bool need_ptrs) {
                ppo_lean_supports(d->x_dim, d->u_dim, d->policy_dims, d->policy_layers, d->policy_activation, d->value_dims, d->value_layers,
                                  d->value_activation);
     if (pl->lean) cap = ppo_num_cus();
+    // the values + GAE launch has its own specialised form: the value network alone decides (64 x 2 or 64 x 3)
+    pl->vg_lean = (g_ppo_lean >= 0 ? g_ppo_lean : lean_env) != 0 && !pl->layered && d->u_dim == 1 &&      // (the kernel's row offsets assume u = 1)
+                  ppo_vg_lean_supports(d->x_dim, d->value_dims, d->value_layers, d->value_activation);
   }
   pl->n_slabs = (int)(tiles < cap ? tiles : cap);
   if (!pl->layered && (pl->lds_fb > 160 * 1024 || pl->lds_values > 160 * 1024)) pl->layered = true;     // more stored activations than a tile's LDS holds
@@ -728,6 +732,7 @@ static int ppo_plan(const mbpo_ppo_desc *d, PpoPlan *pl, bool need_ptrs) {
     pl->sp2 = 0;
     pl->n_slabs = 1;
     pl->lean = false;
+    pl->vg_lean = false;
   }
   long long o = 0;
   auto take = [&](long long n) { long long at = o; o += (n + 3) & ~3LL; return at; };
@@ -799,11 +804,11 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
     if (rc != MBPO_OK) return rc;
     A.baseline = values;
     A.boot = values + pl.M;
-  } else if (pl.vg_G && pl.lean) {
+  } else if (pl.vg_G && pl.vg_lean) {
     // 1-3 in one launch on the value network's resident images (ppo_lean.hip k_ppo_vg_lean: the same bits as k_ppo_values_gae)
     PpoVgLeanArgs V;
     V.v_params = d->params + pl.pi.n_params; V.data = d->data; V.norm_mean = d->norm_mean; V.norm_std = d->norm_std;
-    V.B = d->batch_size; V.T = d->unroll_length; V.D = A.D; V.G = pl.vg_G;
+    V.B = d->batch_size; V.T = d->unroll_length; V.D = A.D; V.G = pl.vg_G; V.n_hid = d->value_layers - 2;
     V.reward_scaling = d->reward_scaling; V.discounting = d->discounting; V.gae_lambda = d->gae_lambda;
     V.vs = A.vs; V.adv = A.adv; V.mom_part = A.mom_part; V.step_count_rw = A.step_count_rw;
     const long long GR = (long long)pl.vg_G * (d->unroll_length + 1), GT = (long long)pl.vg_G * d->unroll_length;

@@ -412,7 +412,8 @@ __global__ void __launch_bounds__(512) k_ppo_vg_lean(const PpoVgLeanArgs A) {
   if (blockIdx.x == 0 && tid == 0) A.step_count_rw[0] = A.step_count_rw[0] + 1.0f;     // (nothing in this launch reads it)
   // ---- the value network's images, once ----
   const float *const net_p = A.v_params;
-  constexpr int W1 = X * LH + LH, OUT = W1 + 2 * HID;
+  constexpr int W1 = X * LH + LH;
+  const int nh = A.n_hid, OUT = W1 + nh * HID;
   constexpr int kc = (X + 3) >> 2;      // 1 for x in {3, 4}
   float w0[2], b0v[4];
 #pragma unroll
@@ -428,7 +429,7 @@ __global__ void __launch_bounds__(512) k_ppo_vg_lean(const PpoVgLeanArgs A) {
   }
   ImgF I1, I2;
   img_fwd_request(I1, net_p + W1, c0, lane);
-  img_fwd_request(I2, net_p + W1 + HID, c0, lane);
+  img_fwd_request(I2, net_p + W1 + (nh - 1) * HID, c0, lane);      // (one 64 x 64 layer: requested again, never used)
   float wo[16];
   float bo = 0.f;
   const bool out_wave = sub == c;                                      // waves 0 and 5: different SIMDs
@@ -497,10 +498,12 @@ __global__ void __launch_bounds__(512) k_ppo_vg_lean(const PpoVgLeanArgs A) {
     __syncthreads();
     if (live) hid_fwd<false>(I1, tiles, tiles + LT, nullptr, c0, lane);
     __syncthreads();
-    if (live) hid_fwd<false>(I2, tiles + LT, tiles, nullptr, c0, lane);
-    __syncthreads();
+    if (nh == 2) {
+      if (live) hid_fwd<false>(I2, tiles + LT, tiles, nullptr, c0, lane);
+      __syncthreads();
+    }
     if (live && out_wave) {
-      const f32x4 y = out_fwd(wo, tiles, lane);
+      const f32x4 y = out_fwd(wo, nh == 2 ? tiles : tiles + LT, lane);
       if (lane < 16 && r0 + lane < rows) s_val[r0 + lane] = y[0] + bo;
     }
     // (no barrier: the next round's input tile and the first hidden tile were last read two barriers ago)
@@ -568,6 +571,13 @@ int ppo_vg_lean_launch(const PpoVgLeanArgs &A, int x_dim, int n_wgs, size_t arr_
     return MBPO_ERR_UNSUPPORTED;
   }
   return MBPO_OK;
+}
+
+bool ppo_vg_lean_supports(int x_dim, const int *value_dims, int value_layers, int value_act) {
+  if (x_dim < 2 || x_dim > 6 || (value_layers != 4 && value_layers != 3) || value_act != MBPO_ACT_SWISH) return false;
+  for (int l = 1; l < value_layers; ++l)
+    if (value_dims[l] != LH) return false;
+  return value_dims[0] == x_dim && value_dims[value_layers] == 1;
 }
 
 bool ppo_lean_supports(int x_dim, int u_dim, const int *policy_dims, int policy_layers, int policy_act, const int *value_dims, int value_layers,

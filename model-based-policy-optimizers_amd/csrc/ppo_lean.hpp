@@ -29,9 +29,12 @@ struct PpoVgLeanArgs {
   const float *data;                    // [B][T][D] rows of the shuffled minibatch
   const float *norm_mean, *norm_std;
   int B, T, D, G;                       // G whole trajectories per workgroup (G * (T + 1) <= 1024)
+  int n_hid;                            // 64 x 64 layers of the value network: 2 (three hidden layers) or 1 (two)
   float reward_scaling, discounting, gae_lambda;
   float *vs, *adv;                      // [B][T]
   float *mom_part;                      // [workgroups][4]: {n, mean, M2, -}
   float *step_count_rw;
 };
 int ppo_vg_lean_launch(const PpoVgLeanArgs &A, int x_dim, int n_wgs, size_t lds_extra_floats, void *stream);
+// the value network alone: x -> 64 -> 64 [-> 64] -> 1, swish, x = 2 .. 6
+bool ppo_vg_lean_supports(int x_dim, const int *value_dims, int value_layers, int value_act);

@@ -205,7 +205,7 @@ def test_ppo_fused_step_equals_grads_plus_apply(dev):
     (5, 128, 8, True, True, True),
     (6, 50, 7, False, True, False),
 ])
-def test_ppo_lean_kernel_matches_generic_kernel(dev, X, B, T, normalize, norm_adv, given_noise):
+def test_ppo_lean_kernel_matches_generic_kernel(dev, X, B, T, normalize, norm_adv, given_noise, hidden=(64, 64, 64)):
     """k_ppo_lean (csrc/ppo_lean.hip: the loss forward/backward specialised for the 64x3 benchmark networks — weights resident in
     registers for all of a workgroup's tiles, weight gradients summed in registers, one slab per CU) against the generic k_ppo_fwd_bwd.
     Every per-tile number is formed by the same MFMA / FMA sequences; what differs is which tiles a slab sums (256 slabs instead of 512)
@@ -215,7 +215,7 @@ def test_ppo_lean_kernel_matches_generic_kernel(dev, X, B, T, normalize, norm_ad
     from mbpo import _hip
     lib = _hip.load()
     lib.mbpo_debug_set_ppo_lean.argtypes = [C.c_int]
-    cfg, st, data, noise, nm, ns = _make(X, 1, (64, 64, 64), B, T, 2, normalize, entropy_cost=1e-2, discounting=0.99, reward_scaling=0.5,
+    cfg, st, data, noise, nm, ns = _make(X, 1, hidden, B, T, 2, normalize, entropy_cost=1e-2, discounting=0.99, reward_scaling=0.5,
                                           gae_lambda=0.95, clipping_epsilon=0.3, normalize_advantage=norm_adv, lr=3e-4, wd=1e-5)
     d = lambda t: None if t is None else t.to(dev)
     outs = []
@@ -235,9 +235,20 @@ def test_ppo_lean_kernel_matches_generic_kernel(dev, X, B, T, normalize, norm_ad
     finally:
         lib.mbpo_debug_set_ppo_lean(-1)
     (g0, m0, p0), (g1, m1, p1) = outs
+    if len(hidden) == 2:
+        # 64 x 2 networks (tests/test_ppo.py): only the values + GAE launch has a specialised form, and it gives the generic launch's bits
+        assert torch.equal(g0, g1) and torch.equal(m0, m1) and torch.equal(p0, p1)
+        return
     assert float(g0.abs().sum()) > 0 and not torch.equal(g0, torch.zeros_like(g0))
     P = cfg.P
     for name, sl in (("policy", slice(0, P)), ("value", slice(P, None))):
         scale = float(g0[sl].abs().max())
         torch.testing.assert_close(g1[sl], g0[sl], atol=2e-6 * max(scale, 1e-3), rtol=2e-5, msg=lambda m: f"{name}: {m}")
     np.testing.assert_allclose(m1.numpy(), m0.numpy(), rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("X,B,T", [(3, 128, 40), (4, 2000, 3), (5, 33, 9)])
+def test_ppo_values_lean_kernel_is_bit_identical_at_two_hidden_layers(dev, X, B, T):
+    """The reference's own PPO shapes (64 x 2): k_ppo_vg_lean (values + GAE + moment partials on the value network's resident images)
+    against k_ppo_values_gae — the loss launch is the generic one in both runs, so gradients, metrics and parameters must be identical."""
+    test_ppo_lean_kernel_matches_generic_kernel(dev, X, B, T, True, True, False, hidden=(64, 64))
