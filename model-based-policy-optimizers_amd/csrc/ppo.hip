@@ -877,7 +877,7 @@ static int ppo_grads_impl(const mbpo_ppo_desc *d, void *stream, bool fuse_apply)
     L.slabs = A.slabs; L.extras = A.extras; L.M = pl.M;
     L.entropy_cost = d->entropy_cost; L.clip_eps = d->clipping_epsilon; L.normalize_advantage = d->normalize_advantage;
     L.stamps = g_ppo_stamps;
-    rc = ppo_lean_launch(L, d->x_dim, pl.n_slabs, stream);
+    rc = ppo_lean_launch(L, d->x_dim, d->policy_layers - 2, pl.n_slabs, stream);
     if (rc != MBPO_OK) return rc;
   } else if (pl.H == 64) {
     const bool wide = net_is_wide(A.sh_pi) || net_is_wide(A.sh_v);

@@ -41,10 +41,10 @@ __device__ __forceinline__ float pl_ftanh(float x) {
   return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
-template <int X>
+template <int X, int NH>      // NH: 64 x 64 layers per network — 2 (64 x 3 networks) or 1 (64 x 2: tests/test_ppo.py, the reference's experiments)
 struct PNet {
   static constexpr int D = 2 * X + 6;                                     // obs, action, reward, discount, next_obs, log_prob, raw_action, truncation
-  static constexpr int W1 = X * LH + LH, OUT = W1 + 2 * HID;              // offsets inside a net: layer 1, output layer
+  static constexpr int W1 = X * LH + LH, OUT = W1 + NH * HID;             // offsets inside a net: layer 1, output layer
   static constexpr int P = OUT + LH * 2 + 2, V = OUT + LH + 1;
 };
 
@@ -89,12 +89,13 @@ __device__ __forceinline__ void hid_wgrad_regs(const float *hin, const float *de
     A.stamps[stamp_base + (i)] = t_;                                                    \
   }
 
-template <int X>
+template <int X, int NH>
 __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
   int stamp_base = 0;
   extern __shared__ __align__(16) float smem[];
-  using N = PNet<X>;
+  using N = PNet<X, NH>;
   constexpr int D = N::D;
+  constexpr int HL = NH;        // index of the last hidden layer: its derivative / delta tile PT(HL), its activation tile PT(3 + HL)
   static_assert(16 * D + 32 <= 512 && X <= LDX, "tile rows + advantage / target lanes must fit the workgroup");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
   float G2[16], G1[16];
   thin_col_request<X>(tw, net_p, lane);
   img_fwd_request(I1, net_p + N::W1, c0, lane);
-  img_fwd_request(I2, net_p + N::W1 + HID, c0, lane);
+  if constexpr (NH == 2) img_fwd_request(I2, net_p + N::W1 + HID, c0, lane);
   const bool out_wave = sub == c;                                 // wave 0 (policy) and wave 5 (value): different SIMDs
   if (out_wave) {
     if (c == 0) {
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
   } else {
     two[0] = net_p[N::OUT + lane];
   }
-  img_dgrad_request(G2, net_p + N::W1 + HID, c0, lane);
+  if constexpr (NH == 2) img_dgrad_request(G2, net_p + N::W1 + HID, c0, lane);
   img_dgrad_request(G1, net_p + N::W1, c0, lane);
 
   // ---- running sums over this workgroup's tiles (registers) ----
@@ -210,12 +211,14 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
     hid_fwd<true>(I1, PT(3), PT(4), PT(1), c0, lane);
     __syncthreads();
     PPO_STAMP(4);
-    hid_fwd<true>(I2, PT(4), PT(5), PT(2), c0, lane);
-    __syncthreads();
+    if constexpr (NH == 2) {
+      hid_fwd<true>(I2, PT(4), PT(5), PT(2), c0, lane);
+      __syncthreads();
+    }
     PPO_STAMP(5);
     // ---- output layers and the loss terms on the waves that hold them (:84-126) ----
     if (out_wave) {
-      const f32x4 y = out_fwd(wo, PT(5), lane);
+      const f32x4 y = out_fwd(wo, PT(3 + HL), lane);
       const int r = lane & 15;
       const bool ok = r0 + r < M;
       if (c == 0) {
@@ -267,14 +270,16 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
     // ---- backward, input gradients first: delta_2, delta_1, delta_0 overwrite the stored derivatives in place ----
     {
       float zq[4];
-      thin_z_preload(zq, PT(2), sub, lane);
-      if (c == 0) thin_dgrad_last<2>(two, s_dy, zq, PT(2), sub, lane);
-      else thin_dgrad_last<1>(*reinterpret_cast<float(*)[1]>(&two[0]), s_dy, zq, PT(2), sub, lane);
+      thin_z_preload(zq, PT(HL), sub, lane);
+      if (c == 0) thin_dgrad_last<2>(two, s_dy, zq, PT(HL), sub, lane);
+      else thin_dgrad_last<1>(*reinterpret_cast<float(*)[1]>(&two[0]), s_dy, zq, PT(HL), sub, lane);
     }
     __syncthreads();
     PPO_STAMP(8);
-    hid_dgrad(G2, PT(2), PT(1), PT(1), c0, lane);
-    __syncthreads();
+    if constexpr (NH == 2) {
+      hid_dgrad(G2, PT(2), PT(1), PT(1), c0, lane);
+      __syncthreads();
+    }
     PPO_STAMP(9);
     hid_dgrad(G1, PT(1), PT(0), PT(0), c0, lane);
     __syncthreads();
@@ -282,10 +287,12 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
     // ---- weight gradients of the four layers: nothing depends on them inside the tile, no barrier between them ----
     {
       f32x4 acc[4], accb;
-      hid_wgrad_regs(PT(4), PT(2), c0, lane, acc, accb);          // dW2 = h1^T delta_2
+      if constexpr (NH == 2) {
+        hid_wgrad_regs(PT(4), PT(2), c0, lane, acc, accb);          // dW2 = h1^T delta_2
 #pragma unroll
-      for (int a = 0; a < 4; ++a) S2[a] = first ? acc[a] : S2[a] + acc[a];
-      S2b = first ? accb : S2b + accb;
+        for (int a = 0; a < 4; ++a) S2[a] = first ? acc[a] : S2[a] + acc[a];
+        S2b = first ? accb : S2b + accb;
+      }
       hid_wgrad_regs(PT(3), PT(1), c0, lane, acc, accb);          // dW1 = h0^T delta_1
 #pragma unroll
       for (int a = 0; a < 4; ++a) S1[a] = first ? acc[a] : S1[a] + acc[a];
@@ -317,7 +324,7 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
       if (sub < NO) {
         float acc = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc = fmaf(PT(5)[r * LDH + lane], s_dy[r * 4 + sub], acc);
+        for (int r = 0; r < 16; ++r) acc = fmaf(PT(3 + HL)[r * LDH + lane], s_dy[r * 4 + sub], acc);
         s_last = first ? acc : s_last + acc;
       }
       if (sub == 0 && lane < NO) {
@@ -341,12 +348,12 @@ __global__ void __launch_bounds__(512) k_ppo_lean(const PpoLeanArgs A) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const float o2[4] = {S2[a][0], S2[a][1], S2[a][2], S2[a][3]}, o1[4] = {S1[a][0], S1[a][1], S1[a][2], S1[a][3]};
-      store_vec_global<4>(slab + N::W1 + HID + (4 * r + a) * LH + c0 + 4 * g, o2);
+      if constexpr (NH == 2) store_vec_global<4>(slab + N::W1 + HID + (4 * r + a) * LH + c0 + 4 * g, o2);
       store_vec_global<4>(slab + N::W1 + (4 * r + a) * LH + c0 + 4 * g, o1);
     }
     if (r == 0) {
       const float o2[4] = {S2b[0], S2b[1], S2b[2], S2b[3]}, o1[4] = {S1b[0], S1b[1], S1b[2], S1b[3]};
-      store_vec_global<4>(slab + N::W1 + HID + LH * LH + c0 + 4 * g, o2);
+      if constexpr (NH == 2) store_vec_global<4>(slab + N::W1 + HID + LH * LH + c0 + 4 * g, o2);
       store_vec_global<4>(slab + N::W1 + LH * LH + c0 + 4 * g, o1);
     }
     if (sub <= X) slab[sub * LH + lane] = s_first0;                    // rows 0..3 (or the bias when X < 4 and sub == X)
@@ -583,21 +590,27 @@ bool ppo_vg_lean_supports(int x_dim, const int *value_dims, int value_layers, in
 bool ppo_lean_supports(int x_dim, int u_dim, const int *policy_dims, int policy_layers, int policy_act, const int *value_dims, int value_layers,
                        int value_act) {
   if (u_dim != 1 || x_dim < 2 || x_dim > 6) return false;
-  if (policy_layers != 4 || value_layers != 4 || policy_act != MBPO_ACT_SWISH || value_act != MBPO_ACT_SWISH) return false;
-  for (int l = 1; l <= 3; ++l)
+  if ((policy_layers != 4 && policy_layers != 3) || value_layers != policy_layers || policy_act != MBPO_ACT_SWISH || value_act != MBPO_ACT_SWISH) return false;
+  for (int l = 1; l < policy_layers; ++l)
     if (policy_dims[l] != LH || value_dims[l] != LH) return false;
-  return policy_dims[0] == x_dim && policy_dims[4] == 2 && value_dims[0] == x_dim && value_dims[4] == 1;
+  return policy_dims[0] == x_dim && policy_dims[policy_layers] == 2 && value_dims[0] == x_dim && value_dims[value_layers] == 1;
 }
 
-int ppo_lean_launch(const PpoLeanArgs &A, int x_dim, int n_wgs, void *stream) {
+int ppo_lean_launch(const PpoLeanArgs &A, int x_dim, int n_hid, int n_wgs, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   int rc;
-#define PL_X_(X_)                                                                                   \
-  if (x_dim == X_) {                                                                                \
-    rc = mbpo_ensure_lds<k_ppo_lean<X_>>(PPO_LEAN_LDS_BYTES, "ppo_lean");                           \
-    if (rc != MBPO_OK) return rc;                                                                   \
-    hipLaunchKernelGGL(k_ppo_lean<X_>, dim3(n_wgs), dim3(512), PPO_LEAN_LDS_BYTES, st, A);          \
-    return MBPO_OK;                                                                                 \
+#define PL_X_(X_)                                                                                        \
+  if (x_dim == X_ && n_hid == 2) {                                                                       \
+    rc = mbpo_ensure_lds<k_ppo_lean<X_, 2>>(PPO_LEAN_LDS_BYTES, "ppo_lean");                             \
+    if (rc != MBPO_OK) return rc;                                                                        \
+    hipLaunchKernelGGL((k_ppo_lean<X_, 2>), dim3(n_wgs), dim3(512), PPO_LEAN_LDS_BYTES, st, A);          \
+    return MBPO_OK;                                                                                      \
+  }                                                                                                      \
+  if (x_dim == X_ && n_hid == 1) {                                                                       \
+    rc = mbpo_ensure_lds<k_ppo_lean<X_, 1>>(PPO_LEAN_LDS_BYTES, "ppo_lean");                             \
+    if (rc != MBPO_OK) return rc;                                                                        \
+    hipLaunchKernelGGL((k_ppo_lean<X_, 1>), dim3(n_wgs), dim3(512), PPO_LEAN_LDS_BYTES, st, A);          \
+    return MBPO_OK;                                                                                      \
   }
   PL_X_(2) PL_X_(3) PL_X_(4) PL_X_(5) PL_X_(6)
 #undef PL_X_

@@ -17,11 +17,11 @@ struct PpoLeanArgs {
   unsigned long long *stamps;           // measurement hook (mbpo_debug_set_ppo_stamps): s_memtime per section of workgroup 0's first tiles, or NULL
 };
 
-// policy x -> 64^3 -> 2, value x -> 64^3 -> 1, swish, u = 1, x = 2 .. 6
+// policy x -> 64^3 -> 2, value x -> 64^3 -> 1 (or both 64^2), swish, u = 1, x = 2 .. 6
 bool ppo_lean_supports(int x_dim, int u_dim, const int *policy_dims, int policy_layers, int policy_act, const int *value_dims, int value_layers,
                        int value_act);
 // one workgroup per CU (n_wgs <= tiles), each walks tiles blockIdx.x, + n_wgs, ... and leaves ONE slab
-int ppo_lean_launch(const PpoLeanArgs &A, int x_dim, int n_wgs, void *stream);
+int ppo_lean_launch(const PpoLeanArgs &A, int x_dim, int n_hid, int n_wgs, void *stream);      // n_hid: 2 (64 x 3) or 1 (64 x 2, both networks)
 
 // ---- values + GAE + advantage-moment partials in one launch (ppo.hip k_ppo_values_gae) for the same value network ----
 struct PpoVgLeanArgs {
