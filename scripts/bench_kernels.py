@@ -282,6 +282,7 @@ def main():
 
     if want("ppo_case"): ppo_case(4, 1, (64, 64, 64), 512, 5, 100)
     if want("ppo_case"): attempt(ppo_case, 4, 1, (64, 64, 64), 512, 40, 50)
+    if want("ppo_case"): attempt(ppo_case, 3, 1, (64, 64), 128, 40, 100)        # the reference's own PPO test shape (tests/test_ppo.py:30-56)
 
     # ---------------------------------------------------------------- B1-B5: BPTT actor gradient (C5)
     def bptt_case(X, U, E, H, n, reps):
